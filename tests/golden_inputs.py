@@ -1,0 +1,97 @@
+"""Seeded inputs shared by tools/gen_golden.py (which runs the real reference) and the tests.
+
+Everything here is deterministic torch-CPU / numpy RNG, so the generator and
+the tests see identical inputs without the inputs being stored in the fixtures.
+"""
+import numpy as np
+import torch
+
+CONFIGS = {
+    # S: configs 1-4 of BASELINE.json; W: config 5 (wide decoder)
+    "S": dict(ch=3, channels=(8, 16, 8, 8), batch=2, param_seed=101, emb_seed=202, noise_seed=303),
+    "W": dict(ch=8, channels=(16, 32, 16, 16), batch=1, param_seed=111, emb_seed=212, noise_seed=313),
+}
+HYPER = dict(lmbda=200.0, w1=10.0, w2=57.0, lr=1e-3, wemb=5.0, n_points=917 * 936.0)
+
+
+def perturb_state_(sd, seed):
+    """Move every trainable tensor off its trivial initial value, in state-dict order."""
+    g = torch.Generator().manual_seed(seed)
+    for k, v in sd.items():
+        if k.endswith("_init") or k.endswith("pedestal"):
+            continue
+        r = torch.randn(v.shape, generator=g)
+        if k.endswith(".kernel"):
+            v.add_(0.05 * r)
+        elif k.endswith(".b"):
+            v.add_(0.02 * r)
+        elif k.endswith("beta") or k.endswith("gamma"):
+            v.add_(0.01 * r)
+        elif k.endswith("sigma"):
+            v.add_(0.1 * r)
+        elif k.endswith("mu"):
+            v.add_(0.1 * r)
+        else:
+            raise KeyError(k)
+    return sd
+
+
+def make_emb(batch, ch, seed):
+    g = torch.Generator().manual_seed(seed)
+    return 1.0 + 0.5 * torch.randn(batch, ch, 2, 2, 2, generator=g)
+
+
+def noise_stream(seed):
+    """Yields callables shape -> U[0,1) tensor, one per rand_like call, in call order."""
+    g = torch.Generator().manual_seed(seed)
+    while True:
+        yield lambda shape: torch.rand(tuple(shape), generator=g)
+
+
+def sample_index(n, k):
+    rng = np.random.default_rng(n * 7919 + k)
+    return torch.from_numpy(np.sort(rng.choice(n, size=min(k, n), replace=False)))
+
+
+def loss_case_inputs():
+    g = torch.Generator().manual_seed(77)
+    cases = {}
+    shape = (2, 1, 8, 16, 16)
+    p = torch.rand(shape, generator=g)
+    gt = (torch.rand(shape, generator=g) < 0.05).float()
+    dist = torch.rand(shape, generator=g) * 8 * (1 - gt)
+    cases["random"] = (p, gt, dist)
+    # saturated predictions: exact 0 / 1 and values beyond the 1e-9 clamp
+    p2 = p.clone()
+    flat = p2.view(-1)
+    flat[0::7] = 0.0
+    flat[1::7] = 1.0
+    flat[2::7] = 1e-12
+    flat[3::7] = 1.0 - 1e-7
+    cases["saturated"] = (p2, gt, dist)
+    # empty ground truth (no occupied voxel) and full ground truth
+    cases["empty_gt"] = (p, torch.zeros(shape), dist + 1.0)
+    cases["full_gt"] = (p, torch.ones(shape), torch.zeros(shape))
+    return cases
+
+
+def gdn_case_inputs():
+    g = torch.Generator().manual_seed(88)
+    cases = {}
+    for name, c in (("c3", 3), ("c8", 8)):
+        x = torch.randn(2, c, 4, 4, 4, generator=g)
+        beta = torch.sqrt(torch.ones(c) + 2.0 ** -36) + 0.05 * torch.randn(c, generator=g)
+        gamma = torch.sqrt(0.1 * torch.eye(c) + 2.0 ** -36) + 0.02 * torch.randn(c, c, generator=g).abs()
+        gy = torch.randn(2, c, 4, 4, 4, generator=g)
+        cases[name] = (x, beta, gamma, gy)
+    # parameters below their floors: pins the LowerBound gradient rule
+    c = 4
+    x = torch.randn(2, c, 2, 2, 2, generator=g)
+    beta = torch.tensor([1e-4, 0.5, 1e-5, 1.0])
+    gamma = torch.sqrt(0.1 * torch.eye(c) + 2.0 ** -36)
+    gamma[0, 1] = 1e-7
+    gamma[2, 3] = -0.3
+    gamma[1, 0] = 2e-6
+    gy = torch.randn(2, c, 2, 2, 2, generator=g)
+    cases["below_bound"] = (x, beta, gamma, gy)
+    return cases
