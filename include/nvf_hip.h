@@ -1,0 +1,176 @@
+/*
+ * nvf_hip.h -- C ABI of libnvf_hip.so: the gfx950 (MI355X) kernels under NVFPCC's
+ * per-block neural-volumetric-field hot path.
+ *
+ * The reference has NO native boundary on this path: NVFPCC.py calls the Python
+ * operator classes of utils/network.py, gdn_3d.py and utils/loss.py, which call
+ * torch aten ops.  This header is the boundary this build introduces underneath
+ * those classes; every entry point names the reference call site it replaces
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every tensor is fp32, contiguous, NCDHW, resident in device memory;
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library
+ *     never allocates, frees or keeps a pointer after returning;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises; outputs are overwritten unless the argument says accumulate;
+ *   - return 0 on success, a positive hipError_t from the launch, or a negative
+ *     NVF_E* code for a rejected argument; no C++ exception crosses the ABI;
+ *   - summation order inside a kernel depends only on the output element, never
+ *     on the batch size or grid, so results are batch- and rank-count-invariant.
+ */
+#ifndef NVF_HIP_H
+#define NVF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVF_OK 0
+#define NVF_EINVAL (-1)      /* bad shape / null pointer / unsupported combination */
+#define NVF_EWORKSPACE (-2)  /* workspace too small */
+
+#define NVF_ACT_NONE 0
+#define NVF_ACT_RELU 1
+#define NVF_ACT_SIGMOID 2
+
+int nvf_version(void);
+
+/* ---- weight packing -------------------------------------------------------
+ * Re-lays an effective kernel into the two layouts the direct-conv kernels read
+ * from scalar registers: w_fwd[ci][k][co] and w_bwd[co][k'][ci].
+ * conv  : w is [Cout][Cin][K^3] (F.conv3d, network.py:687,741); w_bwd taps are flipped.
+ * convT : w is [Cin][Cout][K^3] (F.conv_transpose3d, network.py:621); w_bwd keeps tap order.
+ * Either output may be NULL. */
+int nvf_pack_conv_weight(const float* w, int cout, int cin, int k, float* w_fwd, float* w_bwd, void* stream);
+int nvf_pack_convT_weight(const float* w, int cin, int cout, int k, float* w_fwd, float* w_bwd, void* stream);
+
+/* ---- effective parameters (network.py:611-620, 677-686, 735-740) ------------
+ * w_eff = f_q(kernel) + kernel_init, b_eff = b + b_init for one layer.
+ * q = 1: kernel + (U-.5)/16 with U from `u` if non-NULL else Philox(seed, stream_id);
+ * q = 2: round(16 k)/16 (half-to-even); any other q: raw kernel. */
+int nvf_effective_params(const float* kernel, const float* kernel_init, const float* u, float* w_eff, int n,
+                         const float* b, const float* b_init, float* b_eff, int nb, int q, uint64_t seed,
+                         uint64_t stream_id, void* stream);
+
+/* ---- gather convolution (F.conv3d fwd; bwd-data of conv3d and conv_transpose3d) --
+ * y[b,co,o] = act(bias[co] + sum_{ci,k} x[b,ci, stride*o - pad + k] * w[ci][k][co])
+ *             (+ addend[b,co,o]) (* (mask[b,co,o] > 0))
+ * w is a packed w_fwd (forward) or w_bwd (backward-data; then cin/cout are swapped
+ * by the caller and pad = K-1-p for conv, pad = p with stride 2 for convT).
+ * bias, addend, mask may be NULL.  Replaces F.conv3d at network.py:687,741 and the
+ * autograd backward of network.py:621,687. */
+int nvf_conv3d_gather(const float* x, const float* w, const float* bias, float* y, const float* addend,
+                      const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din,
+                      int hin, int win, int dout, int hout, int wout, int act, int naive, void* stream);
+
+/* ---- transposed convolution k5 s2 forward (F.conv_transpose3d, network.py:621) ---
+ * y[b,co,o] = act(bias[co] + sum_{ci,k : o+pad-k = 2i} x[b,ci,i] * w[ci][k][co]),
+ * dout = 2*din + 3 (pad 0) or 2*din (pad 2, output_padding 1).  w is w_fwd. */
+int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
+                         int pad, int din, int hin, int win, int dout, int hout, int wout, int act, int naive,
+                         void* stream);
+
+/* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
+ * dw[a][b][k] (+)= sum_{n,i} p[n,a,i] * q[n,b, stride*i - pad + k]      (out_mode 0)
+ * dw[b][a][K^3-1-k] (+)= same sum                                        (out_mode 1)
+ * conv  : p = dY, q = X, stride 1          -> dw[cout][cin][k]
+ * convT : p = X,  q = dY, stride 2         -> dw[cin][cout][k]
+ * head  : p = X,  q = dlogit, out_mode 1   -> dw[1][cin][k]
+ * Two launches: per-workgroup partial sums into `workspace`, then a fixed-order
+ * reduction (deterministic; no float atomics).  nvf_wgrad_workspace() gives the
+ * byte size for a batch. */
+size_t nvf_wgrad_workspace(int batch, int a, int b, int k, int dp, int hp, int wp);
+int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch, int a,
+              int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq, int out_mode,
+              int accumulate, int naive, void* stream);
+
+/* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
+ * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */
+size_t nvf_channel_sum_workspace(int c);
+int nvf_channel_sum(const float* x, float* out, void* workspace, size_t workspace_bytes, int batch, int c,
+                    int spatial, int accumulate, void* stream);
+
+/* ---- GDN / IGDN (gdn_3d.py:72-95, 137-159; LowerBound gdn_3d.py:13-29) ----------
+ * beta = max(beta_hat, beta_bound)^2 - 2^-36, gamma = max(gamma_hat, 2^-18)^2 - 2^-36;
+ * norm[c] = sqrt(beta[c] + sum_j gamma[c][j] x[j]^2); y = x / norm (GDN) or x * norm (IGDN).
+ * bwd overwrites dx, dbeta_hat[c], dgamma_hat[c][j] (LowerBound pass-through rule applied to
+ * the summed gradient); workspace: nvf_gdn_bwd_workspace(c) bytes; c <= 32. */
+int nvf_gdn_fwd(const float* x, const float* beta_hat, const float* gamma_hat, float* y, int batch, int c,
+                int spatial, int inverse, void* stream);
+size_t nvf_gdn_bwd_workspace(int c);
+int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* gamma_hat, const float* dy, float* dx,
+                float* dbeta_hat, float* dgamma_hat, void* workspace, size_t workspace_bytes, int batch, int c,
+                int spatial, int inverse, void* stream);
+
+/* ---- latent quantisation + Gaussian rate (network.py:4514-4539, 145-161) --------
+ * x_rounded = round(x) (half-to-even); v = x + (U-.5) (mode 0 = train) or x_rounded (mode 1 = eval);
+ * bits[0] = sum -log2(max(Phi((v-mu+.5)/|s|) - Phi((v-mu-.5)/|s|), 1e-8)).
+ * U comes from `u` if non-NULL, else Philox keyed by (seed, block_ids[b], step): one stream per
+ * leaf block, so the noise does not depend on how blocks are sharded over GPUs; block_ids NULL
+ * means 0..B-1.  Gradients (each optional, overwritten) are already multiplied by the upstream
+ * gradient g = g_host * (g_dev ? *g_dev : 1): dx = g dbits/dx (identity through the round and
+ * the noise), dsigma[c], dmu[c].  The LowerBound at 1e-8 passes when like >= 1e-8 or the incoming
+ * gradient is negative (network.py:66-72). */
+int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma, const float* mu,
+                    float* x_rounded, float* bits, float* dx, float* dsigma, float* dmu, const float* g_dev,
+                    float g_host, int batch, int c, int spatial, int mode, uint64_t seed, uint64_t step,
+                    void* stream);
+
+/* ---- weight rate (network.py:4777-4778, 301-305): one quantised kernel ---------
+ * bits[0] = sum -log2(max(Phi((w-mu+1/32)/|s|) - Phi((w-mu-1/32)/|s|), 1e-8)), w = round(16 k)/16.
+ * dk[i], dsigma[0], dmu[0] (optional) get g * d bits / d(.), overwritten or accumulated. */
+int nvf_weight_rate(const float* kernel, int n, const float* sigma, const float* mu, float* bits, float* dk,
+                    float* dsigma, float* dmu, const float* g_dev, float g_host, int accumulate, void* stream);
+
+/* workspace (bytes) for the two-stage reductions of nvf_focal_loss / nvf_metrics */
+size_t nvf_reduce_workspace(void);
+
+/* ---- losses (utils/loss.py:61-72, 94-111) fused with their gradient ------------
+ * loss[0] (+)= sum -a_t (1-p_t)^2 w ln(p_t),  p_t = max(p or 1-p, 1e-9), a_t = alpha or 1-alpha,
+ * w = 1 (dist NULL: get_focal_dense) or dist + gt*beta (get_surf_focal_dense).
+ * dp (optional) receives g * d loss / d p with g = g_host * (g_dev ? *g_dev : 1). */
+int nvf_focal_loss(const float* p, const float* gt, const float* dist, float alpha, float beta, float* loss,
+                   float* dp, const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, int64_t n,
+                   int accumulate, void* stream);
+
+/* metrics (utils/loss.py:74-84, 113-121): out[0..5] (+)= tp, ap, tn, an at thh_acc; sse, denom at thh_sse */
+int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
+                void* workspace, size_t workspace_bytes, int64_t n, int accumulate, void* stream);
+
+/* dlogit = dp * p * (1 - p)   (sigmoid backward of network.py:4761,4764,4768) */
+int nvf_sigmoid_bwd(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
+
+/* 2x2x2 max pooling, stride 2 (MultiscaleProcessor, NVFPCC.py:76-88) */
+int nvf_maxpool2(const float* x, float* y, int batch_channels, int d, int h, int w, void* stream);
+
+/* ---- optimiser (torch.optim.Adam defaults, NVFPCC.py:116,124) -------------------
+ * one fused update over a flat buffer; step counts from 1. */
+int nvf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
+
+/* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose
+ * dst[idx[r],:] += src[r,:] (indices unique within a call) */
+int nvf_gather_rows(const float* src, const int64_t* idx, float* dst, int rows, int width, void* stream);
+int nvf_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int width, void* stream);
+
+/* U[0,1) floats, Philox4x32-10 keyed by (seed, stream_id), counter = element index */
+int nvf_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* ---- occupancy thresholding + compaction (NVFPCC.py:520,532-535,631-634) --------
+ * For each block b, voxel (z,y,x) with p > thh: coords (origin[b] + (z,y,x)) appended in
+ * raster order (b, z, y, x) -- the order torch.nonzero gives.  counts[b] = points of
+ * block b.  Two-phase: call with coords == NULL to get counts, exclusive-scan them on
+ * the host or device into offsets, then call again with coords/offsets. */
+int nvf_threshold_count(const float* p, float thh, int32_t* counts, int batch, int voxels, void* stream);
+int nvf_threshold_compact(const float* p, float thh, const int32_t* offsets, const int32_t* origins,
+                          int32_t* coords, int batch, int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVF_HIP_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libnvf_hip.so (the C ABI declared in include/nvf_hip.h).
+
+The library is the only compute path: there is no CPU fallback.  ``lib()`` raises if the
+shared object is missing (run ``python -m nvfpcc_amd.build`` or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvf_hip.so")
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+L = C.c_int64
+U = C.c_uint64
+Z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nvf_hip.h one to one
+PROTOTYPES = {
+    "nvf_version": (I, []),
+    "nvf_pack_conv_weight": (I, [P, I, I, I, P, P, P]),
+    "nvf_pack_convT_weight": (I, [P, I, I, I, P, P, P]),
+    "nvf_effective_params": (I, [P, P, P, P, I, P, P, P, I, I, U, U, P]),
+    "nvf_conv3d_gather": (I, [P, P, P, P, P, P] + [I] * 14 + [P]),
+    "nvf_convT3d_k5s2_fwd": (I, [P, P, P, P] + [I] * 12 + [P]),
+    "nvf_wgrad_workspace": (Z, [I] * 7),
+    "nvf_wgrad": (I, [P, P, P, P, Z] + [I] * 15 + [P]),
+    "nvf_channel_sum_workspace": (Z, [I]),
+    "nvf_channel_sum": (I, [P, P, P, Z, I, I, I, I, P]),
+    "nvf_gdn_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "nvf_gdn_bwd_workspace": (Z, [I]),
+    "nvf_gdn_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "nvf_latent_rate": (I, [P] * 11 + [F, I, I, I, I, U, U, P]),
+    "nvf_weight_rate": (I, [P, I, P, P, P, P, P, P, P, F, I, P]),
+    "nvf_reduce_workspace": (Z, []),
+    "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, P]),
+    "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P]),
+    "nvf_sigmoid_bwd": (I, [P, P, P, L, P]),
+    "nvf_maxpool2": (I, [P, P, I, I, I, I, P]),
+    "nvf_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
+    "nvf_gather_rows": (I, [P, P, P, I, I, P]),
+    "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
+    "nvf_uniform": (I, [P, L, U, U, P]),
+    "nvf_threshold_count": (I, [P, F, P, I, I, P]),
+    "nvf_threshold_compact": (I, [P, F, P, P, P, I, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle with every prototype declared."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(python -m nvfpcc_amd.build). There is no CPU fallback for the NVF hot path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(h, name)   # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+class NvfError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "NVF_EINVAL (rejected argument)", -2: "NVF_EWORKSPACE (workspace too small)"}.get(
+            rc, f"hipError_t {rc}")
+        raise NvfError(f"{what} failed: {kind}")

@@ -1,0 +1,474 @@
+// Direct 3-D convolutions for the NVF decoder on gfx950.
+//
+// Reference call sites replaced: F.conv3d (utils/network.py:687, 741),
+// F.conv_transpose3d (network.py:621) and their autograd backward-data passes.
+//
+// Design (MI355X): the decoder's channel counts are 1..32, so an implicit GEMM
+// would leave most of an MFMA tile's N dimension empty (Cout = 8).  Instead
+// each thread register-tiles VX consecutive x-outputs x all Cout channels, the
+// input tile (with halo) is staged once per workgroup in LDS, and the weights
+// are read through *scalar* loads (s_load_dwordx16) so every v_pk_fma_f32 takes
+// its weight operand from SGPRs: no LDS or VGPR traffic for weights at all, and
+// each LDS input value feeds K*Cout FMAs.  Per output element the accumulation
+// order is fixed (ci, kz, ky, kx; one fmaf chain), independent of batch size,
+// tile or grid, so encode at any batch size equals decode at batch 1 bit for bit.
+#include "nvf_common.h"
+
+struct ConvDims {
+  int din, hin, win, dout, hout, wout, pad, act, tiles_x, tiles_y, tiles_z;
+};
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* __restrict__ w, int cout, int cin, int k3, float* __restrict__ wf,
+                                 float* __restrict__ wb) {
+  int n = cout * cin * k3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int t = i % k3, ci = (i / k3) % cin, co = i / (k3 * cin);
+    float v = w[i];
+    if (wf) wf[(ci * k3 + t) * cout + co] = v;
+    if (wb) wb[(co * k3 + (k3 - 1 - t)) * cin + ci] = v;
+  }
+}
+
+__global__ void pack_convT_kernel(const float* __restrict__ w, int cin, int cout, int k3, float* __restrict__ wf,
+                                  float* __restrict__ wb) {
+  int n = cout * cin * k3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int t = i % k3, co = (i / k3) % cout, ci = i / (k3 * cout);
+    float v = w[i];
+    if (wf) wf[(ci * k3 + t) * cout + co] = v;
+    if (wb) wb[(co * k3 + t) * cin + ci] = v;
+  }
+}
+
+extern "C" int nvf_pack_conv_weight(const float* w, int cout, int cin, int k, float* w_fwd, float* w_bwd,
+                                    void* stream) {
+  if (!w || cout <= 0 || cin <= 0 || k <= 0) return NVF_EINVAL;
+  int n = cout * cin * k * k * k;
+  pack_conv_kernel<<<(n + 255) / 256, 256, 0, nvf_stream(stream)>>>(w, cout, cin, k * k * k, w_fwd, w_bwd);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+extern "C" int nvf_pack_convT_weight(const float* w, int cin, int cout, int k, float* w_fwd, float* w_bwd,
+                                     void* stream) {
+  if (!w || cout <= 0 || cin <= 0 || k <= 0) return NVF_EINVAL;
+  int n = cout * cin * k * k * k;
+  pack_convT_kernel<<<(n + 255) / 256, 256, 0, nvf_stream(stream)>>>(w, cin, cout, k * k * k, w_fwd, w_bwd);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gather convolution, one thread per output element (any shape; also the
+// bit-exact cross-check of the tiled kernel: same fmaf order)
+// ---------------------------------------------------------------------------
+__global__ void conv_gather_naive(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ y,
+                                  const float* __restrict__ addend, const float* __restrict__ mask, int cin,
+                                  int cout, int k, int stride, ConvDims d, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int ox = idx % d.wout;
+  long r = idx / d.wout;
+  int oy = r % d.hout;
+  r /= d.hout;
+  int oz = r % d.dout;
+  r /= d.dout;
+  int co = r % cout;
+  long b = r / cout;
+  const float* xb = x + b * cin * (long)d.din * d.hin * d.win;
+  int k3 = k * k * k;
+  float acc = 0.f;
+  for (int ci = 0; ci < cin; ++ci)
+    for (int kz = 0; kz < k; ++kz) {
+      int iz = oz * stride - d.pad + kz;
+      for (int ky = 0; ky < k; ++ky) {
+        int iy = oy * stride - d.pad + ky;
+        for (int kx = 0; kx < k; ++kx) {
+          int ix = ox * stride - d.pad + kx;
+          float xv = 0.f;
+          if (iz >= 0 && iz < d.din && iy >= 0 && iy < d.hin && ix >= 0 && ix < d.win)
+            xv = xb[((long)ci * d.din + iz) * d.hin * d.win + iy * d.win + ix];
+          acc = fmaf(xv, w[(ci * k3 + (kz * k + ky) * k + kx) * cout + co], acc);
+        }
+      }
+    }
+  float o = nvf_act(acc + (bias ? bias[co] : 0.f), d.act);
+  if (addend) o += addend[idx];
+  if (mask) o = mask[idx] > 0.f ? o : 0.f;
+  y[idx] = o;
+}
+
+// ---------------------------------------------------------------------------
+// gather convolution, LDS-tiled, register-tiled, scalar-register weights
+// ---------------------------------------------------------------------------
+template <int CIN_, int COUT_, int KS_, int S_, int VX_, int NCX_, int TY_, int TZ_, int CC_>
+struct GCfg {
+  static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, S = S_, VX = VX_, NCX = NCX_, TY = TY_, TZ = TZ_, CC = CC_;
+  static constexpr int TX = NCX * VX;
+  static constexpr int NIN = (VX - 1) * S + KS;   // inputs one thread reads per (c,kz,ky)
+  static constexpr int NIN4 = (NIN + 3) / 4 * 4;  // rounded to whole ds_read_b128
+  static constexpr int IX = (TX - 1) * S + KS;    // staged tile extents
+  static constexpr int IY = (TY - 1) * S + KS;
+  static constexpr int IZ = (TZ - 1) * S + KS;
+  static constexpr int RS = (NCX - 1) * VX * S + NIN4;  // LDS row stride (>= IX, 16-B aligned reads)
+  static constexpr int NACT = NCX * TY * TZ;
+  static constexpr int NT = (NACT + 63) / 64 * 64;
+  static constexpr int LDSF = CC * IZ * IY * RS;
+  static_assert((VX * S) % 4 == 0, "thread row start must be 16-byte aligned");
+  static_assert(RS >= IX, "row stride");
+  static_assert(CIN % CC == 0, "channel chunk");
+  static_assert(LDSF * 4 <= 160 * 1024, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           const float* __restrict__ addend,
+                                                           const float* __restrict__ mask, ConvDims d) {
+  constexpr int CIN = C::CIN, COUT = C::COUT, KS = C::KS, S = C::S, VX = C::VX, NCX = C::NCX, TY = C::TY, TZ = C::TZ,
+                CC = C::CC;
+  constexpr int RS = C::RS, IY = C::IY, IZ = C::IZ, IX = C::IX, NT = C::NT, NIN4 = C::NIN4;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDSF];
+  const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
+  const int tile = blockIdx.x % ntile, b = blockIdx.x / ntile;
+  const int tx_i = tile % d.tiles_x, ty_i = (tile / d.tiles_x) % d.tiles_y, tz_i = tile / (d.tiles_x * d.tiles_y);
+  const int ox0 = tx_i * C::TX, oy0 = ty_i * TY, oz0 = tz_i * TZ;
+  const int tid = threadIdx.x;
+  const int cx = tid % NCX, ty = (tid / NCX) % TY, tz = tid / (NCX * TY);
+  const bool active = tid < C::NACT;
+  float acc[COUT][VX];
+#pragma unroll
+  for (int i = 0; i < COUT; ++i)
+#pragma unroll
+    for (int j = 0; j < VX; ++j) acc[i][j] = 0.f;
+  const float* xb = x + (size_t)b * CIN * d.din * d.hin * d.win;
+  const int gz0 = oz0 * S - d.pad, gy0 = oy0 * S - d.pad, gx0 = ox0 * S - d.pad;
+  const int plane = d.hin * d.win;
+#pragma unroll 1
+  for (int c0 = 0; c0 < CIN; c0 += CC) {
+    if (c0) __syncthreads();
+    for (int e = tid; e < C::LDSF; e += NT) {
+      int xx = e % RS;
+      int r = e / RS;
+      int yy = r % IY;
+      r /= IY;
+      int zz = r % IZ;
+      int c = r / IZ;
+      int gx = gx0 + xx, gy = gy0 + yy, gz = gz0 + zz;
+      float v = 0.f;
+      if (xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din)
+        v = xb[((size_t)(c0 + c) * d.din + gz) * plane + gy * d.win + gx];
+      lds[e] = v;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int c = 0; c < CC; ++c) {
+#pragma unroll 1
+        for (int kz = 0; kz < KS; ++kz) {
+#pragma unroll
+          for (int ky = 0; ky < KS; ++ky) {
+            const float4* row =
+                (const float4*)(lds + ((c * IZ + tz * S + kz) * IY + ty * S + ky) * RS + cx * VX * S);
+            float in[NIN4];
+#pragma unroll
+            for (int i = 0; i < NIN4 / 4; ++i) {
+              float4 t = row[i];
+              in[4 * i] = t.x;
+              in[4 * i + 1] = t.y;
+              in[4 * i + 2] = t.z;
+              in[4 * i + 3] = t.w;
+            }
+            const float* wr = w + (size_t)((((c0 + c) * KS + kz) * KS + ky) * KS) * COUT;  // wave-uniform
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+              for (int co = 0; co < COUT; ++co) {
+                const float wv = wr[kx * COUT + co];
+#pragma unroll
+                for (int v = 0; v < VX; ++v) acc[co][v] = fmaf(in[v * S + kx], wv, acc[co][v]);
+              }
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const int oz = oz0 + tz, oy = oy0 + ty;
+  if (oz >= d.dout || oy >= d.hout) return;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    const float bv = bias ? bias[co] : 0.f;
+    const size_t base = (((size_t)b * COUT + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
+#pragma unroll
+    for (int v = 0; v < VX; ++v) {
+      const int ox = ox0 + cx * VX + v;
+      if (ox < d.wout) {
+        float o = nvf_act(acc[co][v] + bv, d.act);
+        if (addend) o += addend[base + ox];
+        if (mask) o = mask[base + ox] > 0.f ? o : 0.f;
+        y[base + ox] = o;
+      }
+    }
+  }
+}
+
+template <class C>
+static int launch_gather(const float* x, const float* w, const float* bias, float* y, const float* addend,
+                         const float* mask, int batch, ConvDims d, hipStream_t s) {
+  d.tiles_x = (d.wout + C::TX - 1) / C::TX;
+  d.tiles_y = (d.hout + C::TY - 1) / C::TY;
+  d.tiles_z = (d.dout + C::TZ - 1) / C::TZ;
+  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch);
+  conv_gather_tiled<C><<<grid, C::NT, 0, s>>>(x, w, bias, y, addend, mask, d);
+  return NVF_OK;
+}
+
+extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bias, float* y, const float* addend,
+                                 const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din,
+                                 int hin, int win, int dout, int hout, int wout, int act, int naive, void* stream) {
+  if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || k <= 0 || stride <= 0) return NVF_EINVAL;
+  if (din <= 0 || hin <= 0 || win <= 0 || dout <= 0 || hout <= 0 || wout <= 0) return NVF_EINVAL;
+  ConvDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0};
+  hipStream_t s = nvf_stream(stream);
+  int rc = 1;  // 1 = not dispatched yet
+  if (!naive) {
+#define NVF_G(CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC)                                           \
+  if (rc == 1 && cin == CI && cout == CO && k == KS && stride == ST && wout >= WLO && wout <= WHI)     \
+    rc = launch_gather<GCfg<CI, CO, KS, ST, VX, NCX, TY, TZ, CC>>(x, w, bias, y, addend, mask, batch, d, s);
+    // narrow decoder (chanstr 8,16,8,8)
+    NVF_G(8, 8, 4, 1, 33, 40, 8, 5, 12, 4, 2)   // conv2 backward-data (35^3)
+    NVF_G(8, 8, 4, 1, 21, 32, 8, 4, 16, 4, 2)   // conv2 forward (32^3)
+    NVF_G(8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2)   // conv1 backward-data (19^3)
+    NVF_G(8, 8, 4, 1, 9, 16, 4, 4, 16, 4, 2)    // conv1 forward (16^3)
+    NVF_G(8, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4)   // conv2_cls forward (32^3)
+    NVF_G(8, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4)    // conv1_cls forward (16^3)
+    NVF_G(1, 8, 3, 1, 17, 32, 8, 4, 16, 4, 1)   // conv2_cls backward-data
+    NVF_G(1, 8, 3, 1, 9, 16, 4, 4, 16, 4, 1)    // conv1_cls backward-data
+    NVF_G(8, 8, 5, 2, 9, 16, 4, 4, 16, 4, 1)    // up2 backward-data (35^3 -> 16^3)
+    NVF_G(8, 16, 5, 2, 5, 8, 4, 2, 8, 8, 2)     // up1 backward-data (19^3 -> 8^3)
+    // wide decoder (chanstr 16,32,16,16)
+    NVF_G(16, 16, 4, 1, 33, 36, 4, 9, 7, 4, 2)  // conv2 backward-data
+    NVF_G(16, 16, 4, 1, 21, 32, 4, 8, 8, 4, 2)  // conv2 forward
+    NVF_G(16, 16, 4, 1, 17, 20, 4, 5, 10, 5, 2) // conv1 backward-data
+    NVF_G(16, 16, 4, 1, 9, 16, 4, 4, 16, 4, 2)  // conv1 forward
+    NVF_G(16, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4)  // conv2_cls forward
+    NVF_G(16, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4)   // conv1_cls forward
+    NVF_G(1, 16, 3, 1, 17, 32, 4, 8, 8, 4, 1)   // conv2_cls backward-data
+    NVF_G(1, 16, 3, 1, 9, 16, 4, 4, 16, 4, 1)   // conv1_cls backward-data
+    NVF_G(16, 16, 5, 2, 9, 16, 4, 4, 16, 4, 1)  // up2 backward-data
+    NVF_G(16, 32, 5, 2, 5, 8, 2, 4, 8, 8, 2)    // up1 backward-data
+#undef NVF_G
+  }
+  if (rc == 1) {
+    long total = (long)batch * cout * dout * hout * wout;
+    conv_gather_naive<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(x, w, bias, y, addend, mask, cin, cout, k,
+                                                                      stride, d, total);
+    rc = NVF_OK;
+  }
+  NVF_LAUNCH_CHECK();
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// transposed convolution k=5 stride=2, forward
+//   y[co,o] = bias + sum_ci sum_{k : (o+pad-k) even} x[ci,(o+pad-k)/2] w[ci][k][co]
+// ---------------------------------------------------------------------------
+__global__ void convT_k5s2_naive(const float* __restrict__ x, const float* __restrict__ w,
+                                 const float* __restrict__ bias, float* __restrict__ y, int cin, int cout, ConvDims d,
+                                 long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int ox = idx % d.wout;
+  long r = idx / d.wout;
+  int oy = r % d.hout;
+  r /= d.hout;
+  int oz = r % d.dout;
+  r /= d.dout;
+  int co = r % cout;
+  long b = r / cout;
+  const float* xb = x + b * cin * (long)d.din * d.hin * d.win;
+  float acc = 0.f;
+  for (int ci = 0; ci < cin; ++ci)
+    for (int kz = 0; kz < 5; ++kz) {
+      int uz = oz + d.pad - kz;
+      if (uz < 0 || (uz & 1) || (uz >> 1) >= d.din) continue;
+      for (int ky = 0; ky < 5; ++ky) {
+        int uy = oy + d.pad - ky;
+        if (uy < 0 || (uy & 1) || (uy >> 1) >= d.hin) continue;
+        for (int kx = 0; kx < 5; ++kx) {
+          int ux = ox + d.pad - kx;
+          if (ux < 0 || (ux & 1) || (ux >> 1) >= d.win) continue;
+          float xv = xb[((long)ci * d.din + (uz >> 1)) * d.hin * d.win + (uy >> 1) * d.win + (ux >> 1)];
+          acc = fmaf(xv, w[(ci * 125 + (kz * 5 + ky) * 5 + kx) * cout + co], acc);
+        }
+      }
+    }
+  y[idx] = nvf_act(acc + (bias ? bias[co] : 0.f), d.act);
+}
+
+// Tiled form.  Work is indexed by "cells" m = (o + pad) >> 1 per axis: a cell owns the
+// two outputs o = 2m - pad + e (e = parity) and reads inputs i = m - j, j = 0..2 (even
+// parity: taps k = 0,2,4) or j = 0..1 (odd parity: taps 1,3): 125 taps per cell, none
+// multiplied by an inserted zero.  A thread owns VX consecutive cells along x, both x
+// parities and all Cout channels, and walks the four (z,y) parity classes in turn.
+template <int CIN_, int COUT_, int VX_, int NCX_, int TY_, int TZ_>
+struct TCfg {
+  static constexpr int CIN = CIN_, COUT = COUT_, VX = VX_, NCX = NCX_, TY = TY_, TZ = TZ_;
+  static constexpr int TX = NCX * VX;
+  static constexpr int NIN = VX + 2;
+  static constexpr int NIN4 = (NIN + 3) / 4 * 4;
+  static constexpr int IX = TX + 2, IY = TY + 2, IZ = TZ + 2;
+  static constexpr int RS = (NCX - 1) * VX + NIN4;
+  static constexpr int NACT = NCX * TY * TZ;
+  static constexpr int NT = (NACT + 63) / 64 * 64;
+  static constexpr int LDSF = CIN * IZ * IY * RS;
+  static_assert(VX % 4 == 0, "alignment");
+  static_assert(RS >= IX, "row stride");
+  static_assert(LDSF * 4 <= 160 * 1024, "LDS");
+};
+
+template <class C, int EZ, int EY>
+__device__ __forceinline__ void convT_class(const float* lds, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ y, const ConvDims& d,
+                                            int b, int cx, int ty, int tz, int mx0, int my, int mz) {
+  constexpr int CIN = C::CIN, COUT = C::COUT, VX = C::VX, RS = C::RS, IY = C::IY, IZ = C::IZ, NIN4 = C::NIN4;
+  float acc[2][COUT][VX];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < COUT; ++i)
+#pragma unroll
+      for (int j = 0; j < VX; ++j) acc[e][i][j] = 0.f;
+#pragma unroll 1
+  for (int c = 0; c < CIN; ++c) {
+#pragma unroll
+    for (int jz = 0; jz < 3 - EZ; ++jz) {
+#pragma unroll
+      for (int jy = 0; jy < 3 - EY; ++jy) {
+        const float4* row = (const float4*)(lds + ((c * IZ + tz + 2 - jz) * IY + ty + 2 - jy) * RS + cx * VX);
+        float in[NIN4];
+#pragma unroll
+        for (int i = 0; i < NIN4 / 4; ++i) {
+          float4 t = row[i];
+          in[4 * i] = t.x;
+          in[4 * i + 1] = t.y;
+          in[4 * i + 2] = t.z;
+          in[4 * i + 3] = t.w;
+        }
+        const int kz = EZ + 2 * jz, ky = EY + 2 * jy;
+        const float* wr = w + (size_t)((c * 5 + kz) * 5 + ky) * 5 * COUT;  // wave-uniform
+#pragma unroll
+        for (int ex = 0; ex < 2; ++ex)
+#pragma unroll
+          for (int jx = 0; jx < 3 - ex; ++jx)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+              const float wv = wr[(ex + 2 * jx) * COUT + co];
+#pragma unroll
+              for (int v = 0; v < VX; ++v) acc[ex][co][v] = fmaf(in[v + 2 - jx], wv, acc[ex][co][v]);
+            }
+      }
+    }
+  }
+  const int oz = 2 * mz + EZ - d.pad, oy = 2 * my + EY - d.pad;
+  if (oz < 0 || oz >= d.dout || oy < 0 || oy >= d.hout) return;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    const float bv = bias ? bias[co] : 0.f;
+    const size_t base = (((size_t)b * COUT + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
+#pragma unroll
+    for (int v = 0; v < VX; ++v)
+#pragma unroll
+      for (int ex = 0; ex < 2; ++ex) {
+        const int ox = 2 * (mx0 + v) + ex - d.pad;
+        if (ox >= 0 && ox < d.wout) y[base + ox] = nvf_act(acc[ex][co][v] + bv, d.act);
+      }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void convT_k5s2_tiled(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          ConvDims d) {
+  constexpr int CIN = C::CIN, VX = C::VX, NCX = C::NCX, TY = C::TY, TZ = C::TZ, RS = C::RS, IY = C::IY, IZ = C::IZ,
+                IX = C::IX, NT = C::NT;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDSF];
+  const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
+  const int tile = blockIdx.x % ntile, b = blockIdx.x / ntile;
+  const int tx_i = tile % d.tiles_x, ty_i = (tile / d.tiles_x) % d.tiles_y, tz_i = tile / (d.tiles_x * d.tiles_y);
+  const int mlo = d.pad >> 1;
+  const int cx0 = mlo + tx_i * C::TX, cy0 = mlo + ty_i * TY, cz0 = mlo + tz_i * TZ;  // first cell of the tile
+  const int tid = threadIdx.x;
+  const float* xb = x + (size_t)b * CIN * d.din * d.hin * d.win;
+  const int plane = d.hin * d.win;
+  for (int e = tid; e < C::LDSF; e += NT) {
+    int xx = e % RS;
+    int r = e / RS;
+    int yy = r % IY;
+    r /= IY;
+    int zz = r % IZ;
+    int c = r / IZ;
+    int gx = cx0 - 2 + xx, gy = cy0 - 2 + yy, gz = cz0 - 2 + zz;
+    float v = 0.f;
+    if (xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din)
+      v = xb[((size_t)c * d.din + gz) * plane + gy * d.win + gx];
+    lds[e] = v;
+  }
+  __syncthreads();
+  if (tid >= C::NACT) return;
+  const int cx = tid % NCX, ty = (tid / NCX) % TY, tz = tid / (NCX * TY);
+  const int mx0 = cx0 + cx * VX, my = cy0 + ty, mz = cz0 + tz;
+  convT_class<C, 0, 0>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 0, 1>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 1, 0>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 1, 1>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
+}
+
+template <class C>
+static int launch_convT(const float* x, const float* w, const float* bias, float* y, int batch, ConvDims d,
+                        hipStream_t s) {
+  const int mlo = d.pad >> 1;
+  // cells per axis: m in [mlo, (dim_out - 1 + pad) >> 1]
+  const int ncx = ((d.wout - 1 + d.pad) >> 1) - mlo + 1;
+  const int ncy = ((d.hout - 1 + d.pad) >> 1) - mlo + 1;
+  const int ncz = ((d.dout - 1 + d.pad) >> 1) - mlo + 1;
+  d.tiles_x = (ncx + C::TX - 1) / C::TX;
+  d.tiles_y = (ncy + C::TY - 1) / C::TY;
+  d.tiles_z = (ncz + C::TZ - 1) / C::TZ;
+  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch);
+  convT_k5s2_tiled<C><<<grid, C::NT, 0, s>>>(x, w, bias, y, d);
+  return NVF_OK;
+}
+
+extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int cin,
+                                    int cout, int pad, int din, int hin, int win, int dout, int hout, int wout,
+                                    int act, int naive, void* stream) {
+  if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0) return NVF_EINVAL;
+  if (pad != 0 && pad != 2) return NVF_EINVAL;
+  const int extra = pad == 0 ? 3 : 0;  // (in-1)*2 - 2*pad + 5 + output_padding
+  if (dout != 2 * din + extra || hout != 2 * hin + extra || wout != 2 * win + extra) return NVF_EINVAL;
+  ConvDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0};
+  hipStream_t s = nvf_stream(stream);
+  int rc = 1;
+  if (!naive) {
+#define NVF_T(CI, CO, WIN, VX, NCX, TY, TZ) \
+  if (rc == 1 && cin == CI && cout == CO && win == WIN) rc = launch_convT<TCfg<CI, CO, VX, NCX, TY, TZ>>(x, w, bias, y, batch, d, s);
+    NVF_T(8, 8, 16, 4, 5, 6, 6)     // up2 narrow: 16^3 -> 35^3 (18 cells / axis)
+    NVF_T(16, 8, 8, 4, 3, 5, 5)     // up1 narrow: 8^3 -> 19^3 (10 cells / axis)
+    NVF_T(16, 16, 16, 4, 5, 6, 6)   // up2 wide
+    NVF_T(32, 16, 8, 4, 3, 5, 5)    // up1 wide
+#undef NVF_T
+  }
+  if (rc == 1) {
+    long total = (long)batch * cout * dout * hout * wout;
+    convT_k5s2_naive<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(x, w, bias, y, cin, cout, d, total);
+    rc = NVF_OK;
+  }
+  NVF_LAUNCH_CHECK();
+  return rc;
+}

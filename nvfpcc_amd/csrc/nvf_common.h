@@ -1,0 +1,70 @@
+// Shared device helpers for libnvf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nvf_hip.h"
+
+#define NVF_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+static inline hipStream_t nvf_stream(void* s) { return (hipStream_t)s; }
+
+__device__ __forceinline__ float nvf_act(float v, int act) {
+  if (act == NVF_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == NVF_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// ---- Philox4x32-10 counter RNG ------------------------------------------------
+// key = seed (64 bit), counter = (index lo, index hi, stream lo, stream hi).
+__device__ __forceinline__ void nvf_philox(uint64_t seed, uint64_t stream_id, uint64_t index, uint32_t out[4]) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32);
+  uint32_t c2 = (uint32_t)stream_id, c3 = (uint32_t)(stream_id >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one U[0,1) float per element index (24 random mantissa bits, like torch's uniform)
+__device__ __forceinline__ float nvf_uniform01(uint64_t seed, uint64_t stream_id, uint64_t index) {
+  uint32_t r[4];
+  nvf_philox(seed, stream_id, index >> 2, r);
+  uint32_t v = r[index & 3];
+  return (float)(v >> 8) * (1.0f / 16777216.0f);
+}
+
+// wave64 sum via DPP-free shuffles (width 64)
+__device__ __forceinline__ float nvf_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block sum of up to 1024 threads; result valid in thread 0. `red` holds >= 16 floats.
+__device__ __forceinline__ float nvf_block_sum(float v, float* red) {
+  v = nvf_wave_sum(v);
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) s += red[i];
+  }
+  return s;
+}

@@ -1,0 +1,633 @@
+// Element-wise, normalisation, rate, loss, optimiser and compaction kernels of the NVF
+// hot path on gfx950.  All of them are HBM- or latency-bound byte movers; the rules that
+// matter are coalesced (16 B / lane where the layout allows) accesses, one pass over the
+// data with the gradient fused into the forward where the caller wants it, and fixed-order
+// two-stage reductions instead of float atomics so results are reproducible.
+#include "nvf_common.h"
+
+#define NVF_GRID(n, bs) ((unsigned)(((n) + (bs)-1) / (bs)))
+
+extern "C" int nvf_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------
+// generic fixed-order finaliser: out[j] (+)= sum_g part[g*ncol + j]
+// ---------------------------------------------------------------------------
+__global__ void finalize_partials(const float* __restrict__ part, float* __restrict__ out, int nrow, int ncol,
+                                  int accumulate) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncol) return;
+  float s = 0.f;
+  for (int g = 0; g < nrow; ++g) s += part[(size_t)g * ncol + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+// ---------------------------------------------------------------------------
+// effective parameters (network.py:611-620, 677-686, 735-740)
+// ---------------------------------------------------------------------------
+__global__ void effective_params_kernel(const float* __restrict__ kernel, const float* __restrict__ kernel_init,
+                                        const float* __restrict__ u, float* __restrict__ w_eff, int n,
+                                        const float* __restrict__ b, const float* __restrict__ b_init,
+                                        float* __restrict__ b_eff, int nb, int q, uint64_t seed, uint64_t stream_id) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float k = kernel[i];
+    if (q == 1) {
+      float uu = u ? u[i] : nvf_uniform01(seed, stream_id, (uint64_t)i);
+      k = k + (uu - 0.5f) * 0.0625f;
+    } else if (q == 2) {
+      k = rintf(k * 16.f) / 16.f;
+    }
+    w_eff[i] = k + kernel_init[i];
+  } else if (i < n + nb) {
+    int j = i - n;
+    b_eff[j] = b[j] + b_init[j];
+  }
+}
+
+extern "C" int nvf_effective_params(const float* kernel, const float* kernel_init, const float* u, float* w_eff, int n,
+                                    const float* b, const float* b_init, float* b_eff, int nb, int q, uint64_t seed,
+                                    uint64_t stream_id, void* stream) {
+  if (!kernel || !kernel_init || !w_eff || n <= 0 || nb < 0) return NVF_EINVAL;
+  if (nb > 0 && (!b || !b_init || !b_eff)) return NVF_EINVAL;
+  effective_params_kernel<<<NVF_GRID(n + nb, 256), 256, 0, nvf_stream(stream)>>>(kernel, kernel_init, u, w_eff, n, b,
+                                                                                  b_init, b_eff, nb, q, seed,
+                                                                                  stream_id);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// GDN / IGDN (gdn_3d.py:72-95, 137-159)
+// ---------------------------------------------------------------------------
+#define NVF_PEDESTAL 1.4551915228366852e-11f  /* 2^-36 */
+#define NVF_BETA_BOUND 1.0000072759311445e-03f /* sqrt(1e-6 + 2^-36) */
+#define NVF_GAMMA_BOUND 3.814697265625e-06f   /* 2^-18 */
+
+__device__ __forceinline__ float gdn_beta(float bh) {
+  float m = fmaxf(bh, NVF_BETA_BOUND);
+  return m * m - NVF_PEDESTAL;
+}
+__device__ __forceinline__ float gdn_gamma(float gh) {
+  float m = fmaxf(gh, NVF_GAMMA_BOUND);
+  return m * m - NVF_PEDESTAL;
+}
+
+__global__ void gdn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ beta_hat,
+                               const float* __restrict__ gamma_hat, float* __restrict__ y, int batch, int c,
+                               int spatial, int inverse) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (b, ch, s)
+  long total = (long)batch * c * spatial;
+  if (idx >= total) return;
+  int s = idx % spatial;
+  int ch = (idx / spatial) % c;
+  long b = idx / ((long)spatial * c);
+  const float* xb = x + b * c * spatial + s;
+  float acc = gdn_beta(beta_hat[ch]);
+  for (int j = 0; j < c; ++j) {
+    float xj = xb[(long)j * spatial];
+    acc = fmaf(gdn_gamma(gamma_hat[ch * c + j]), xj * xj, acc);
+  }
+  float nrm = sqrtf(acc);
+  float xv = xb[(long)ch * spatial];
+  y[idx] = inverse ? xv * nrm : xv / nrm;
+}
+
+extern "C" int nvf_gdn_fwd(const float* x, const float* beta_hat, const float* gamma_hat, float* y, int batch, int c,
+                           int spatial, int inverse, void* stream) {
+  if (!x || !beta_hat || !gamma_hat || !y || batch <= 0 || c <= 0 || spatial <= 0) return NVF_EINVAL;
+  long total = (long)batch * c * spatial;
+  gdn_fwd_kernel<<<NVF_GRID(total, 256), 256, 0, nvf_stream(stream)>>>(x, beta_hat, gamma_hat, y, batch, c, spatial,
+                                                                       inverse);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// backward: one thread per voxel (b, s).  t_c = dy_c x_c / n_c (IGDN) or -dy_c x_c / n_c^3 (GDN);
+// dx_i = dy_i n_i^{+-1} + x_i sum_c t_c gamma_ci ; dbeta_c = sum t_c / 2 ; dgamma_cj = sum t_c x_j^2 / 2.
+// Per-workgroup partial parameter sums go to a slab; gdn_bwd_final adds the slabs in order and
+// applies the re-parametrisation chain rule with the LowerBound pass-through rule (gdn_3d.py:24-29).
+static const int kGdnMaxC = 32;
+static const int kGdnThreads = 128;
+static const int kGdnMaxSlabs = 256;
+
+__global__ __launch_bounds__(kGdnThreads) void gdn_bwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ beta_hat,
+                                                              const float* __restrict__ gamma_hat,
+                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              float* __restrict__ slabs, int batch, int c, int spatial,
+                                                              int inverse, int vox_per_wg) {
+  extern __shared__ float sm[];             // ts[c][T+1], xs[c][T+1]
+  const int T = kGdnThreads, LD = T + 1;
+  float* ts = sm;
+  float* xs = sm + c * LD;
+  const int tid = threadIdx.x;
+  const int ncol = c + c * c;
+  const long nvox = (long)batch * spatial;
+  const long v_lo = (long)blockIdx.x * vox_per_wg;
+  long v_hi = v_lo + vox_per_wg;
+  if (v_hi > nvox) v_hi = nvox;
+  // per-thread running parameter partials live in LDS-free registers only for the pairs this thread owns
+  float own[(kGdnMaxC + kGdnMaxC * kGdnMaxC + kGdnThreads - 1) / kGdnThreads];
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(own) / sizeof(float)); ++i) own[i] = 0.f;
+
+  for (long base = v_lo; base < v_hi; base += T) {
+    const long v = base + tid;
+    const bool live = v < v_hi;
+    const long b = live ? v / spatial : 0;
+    const int s = live ? (int)(v % spatial) : 0;
+    const float* xb = x + b * c * spatial + s;
+    const float* gb = dy + b * c * spatial + s;
+    for (int ch = 0; ch < c; ++ch) {
+      float t = 0.f, xsq = 0.f;
+      if (live) {
+        float acc = gdn_beta(beta_hat[ch]);
+        for (int j = 0; j < c; ++j) {
+          float xj = xb[(long)j * spatial];
+          acc = fmaf(gdn_gamma(gamma_hat[ch * c + j]), xj * xj, acc);
+        }
+        float nrm = sqrtf(acc);
+        float xv = xb[(long)ch * spatial], g = gb[(long)ch * spatial];
+        t = inverse ? g * xv / nrm : -g * xv / (nrm * nrm * nrm);
+        xsq = xv * xv;
+      }
+      ts[ch * LD + tid] = t;
+      xs[ch * LD + tid] = xsq;
+    }
+    __syncthreads();
+    if (live) {
+      for (int i = 0; i < c; ++i) {
+        float acc = gdn_beta(beta_hat[i]);
+        for (int j = 0; j < c; ++j) acc = fmaf(gdn_gamma(gamma_hat[i * c + j]), xs[j * LD + tid], acc);
+        float nrm = sqrtf(acc);
+        float mix = 0.f;
+        for (int ch = 0; ch < c; ++ch) mix = fmaf(ts[ch * LD + tid], gdn_gamma(gamma_hat[ch * c + i]), mix);
+        float xv = xb[(long)i * spatial], g = gb[(long)i * spatial];
+        dx[(b * c + i) * spatial + s] = (inverse ? g * nrm : g / nrm) + xv * mix;
+      }
+    }
+    // parameter partials: column p < c is dbeta_p, column c + ch*c + j is dgamma_{ch,j}
+    int slot = 0;
+    for (int p = tid; p < ncol; p += T, ++slot) {
+      float sum = 0.f;
+      if (p < c) {
+        for (int k = 0; k < T; ++k) sum += ts[p * LD + k];
+      } else {
+        int ch = (p - c) / c, j = (p - c) % c;
+        for (int k = 0; k < T; ++k) sum = fmaf(ts[ch * LD + k], xs[j * LD + k], sum);
+      }
+      own[slot] += 0.5f * sum;
+    }
+    __syncthreads();
+  }
+  int slot = 0;
+  for (int p = tid; p < ncol; p += T, ++slot) slabs[(size_t)blockIdx.x * ncol + p] = own[slot];
+}
+
+__global__ void gdn_bwd_final(const float* __restrict__ slabs, const float* __restrict__ beta_hat,
+                              const float* __restrict__ gamma_hat, float* __restrict__ dbeta_hat,
+                              float* __restrict__ dgamma_hat, int nslab, int c) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int ncol = c + c * c;
+  if (p >= ncol) return;
+  float s = 0.f;
+  for (int g = 0; g < nslab; ++g) s += slabs[(size_t)g * ncol + p];
+  if (p < c) {
+    float h = beta_hat[p];
+    float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);   // d/d(clamped) of clamped^2 - pedestal
+    dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+  } else {
+    float h = gamma_hat[p - c];
+    float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
+    dgamma_hat[p - c] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+  }
+}
+
+extern "C" size_t nvf_gdn_bwd_workspace(int c) { return (size_t)kGdnMaxSlabs * (c + c * c) * sizeof(float); }
+
+extern "C" int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* gamma_hat, const float* dy, float* dx,
+                           float* dbeta_hat, float* dgamma_hat, void* workspace, size_t workspace_bytes, int batch,
+                           int c, int spatial, int inverse, void* stream) {
+  if (!x || !beta_hat || !gamma_hat || !dy || !dx || !dbeta_hat || !dgamma_hat || !workspace) return NVF_EINVAL;
+  if (batch <= 0 || c <= 0 || c > kGdnMaxC || spatial <= 0) return NVF_EINVAL;
+  if (workspace_bytes < nvf_gdn_bwd_workspace(c)) return NVF_EWORKSPACE;
+  long nvox = (long)batch * spatial;
+  long per = (nvox + kGdnMaxSlabs - 1) / kGdnMaxSlabs;
+  per = (per + kGdnThreads - 1) / kGdnThreads * kGdnThreads;
+  int nslab = (int)((nvox + per - 1) / per);
+  size_t lds = (size_t)2 * c * (kGdnThreads + 1) * sizeof(float);
+  hipStream_t s = nvf_stream(stream);
+  gdn_bwd_kernel<<<nslab, kGdnThreads, lds, s>>>(x, beta_hat, gamma_hat, dy, dx, (float*)workspace, batch, c, spatial,
+                                                 inverse, (int)per);
+  gdn_bwd_final<<<NVF_GRID(c + c * c, 64), 64, 0, s>>>((const float*)workspace, beta_hat, gamma_hat, dbeta_hat,
+                                                       dgamma_hat, nslab, c);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian rate helpers (network.py:145-161)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float std_cdf(float z) { return 0.5f * (1.f + erff(z / 1.41421356237309515f)); }
+__device__ __forceinline__ float std_pdf(float z) { return 0.3989422804014327f * expf(-0.5f * z * z); }
+
+struct RateTerm {
+  float bits, dv, dmu, dsig;  // value and derivatives w.r.t. v, mu, |sigma|
+};
+
+// gsign: sign of the gradient arriving at `bits` (LowerBound passes when like >= 1e-8 OR the
+// incoming gradient on `like` is negative; that gradient is gsign * (-1/(like ln2))).
+__device__ __forceinline__ RateTerm rate_term(float v, float mu, float sabs, float half, float gsign) {
+  const float inv_ln2 = 1.4426950408889634f;
+  float up = (v - mu + half) / sabs, lo = (v - mu - half) / sabs;
+  float like = std_cdf(up) - std_cdf(lo);
+  float cl = fmaxf(like, 1e-8f);
+  RateTerm r;
+  r.bits = -1.f * logf(cl) / 0.6931471805599453f;
+  float dbits_dlike = -inv_ln2 / cl;
+  bool pass = (like >= 1e-8f) || (gsign * dbits_dlike < 0.f);
+  if (!pass) dbits_dlike = 0.f;
+  float pu = std_pdf(up), pl = std_pdf(lo);
+  r.dv = dbits_dlike * (pu - pl) / sabs;
+  r.dmu = -r.dv;
+  r.dsig = dbits_dlike * (-(pu * up - pl * lo) / sabs);
+  return r;
+}
+
+// latent quantisation + rate: one workgroup, channel-major loops (fixed order, C + 1 block reductions)
+__global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                           const int64_t* __restrict__ block_ids,
+                                                           const float* __restrict__ sigma,
+                                                           const float* __restrict__ mu, float* __restrict__ x_rounded,
+                                                           float* __restrict__ bits, float* __restrict__ dx,
+                                                           float* __restrict__ dsigma, float* __restrict__ dmu,
+                                                           const float* __restrict__ g_dev, float g_host, int batch,
+                                                           int c, int spatial, int mode, uint64_t seed, uint64_t step) {
+  __shared__ float red[16];
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+  float total_bits = 0.f;
+  for (int ch = 0; ch < c; ++ch) {
+    const float sraw = sigma[ch], sabs = fabsf(sraw), m = mu[ch];
+    float sb = 0.f, ss = 0.f, sm_ = 0.f;
+    for (long e = threadIdx.x; e < (long)batch * spatial; e += blockDim.x) {
+      long b = e / spatial;
+      int s = (int)(e % spatial);
+      long idx = (b * c + ch) * spatial + s;
+      float xv = x[idx];
+      float xr = rintf(xv);
+      if (x_rounded) x_rounded[idx] = xr;
+      float v = xr;
+      if (mode == 0) {
+        float uu;
+        if (u) {
+          uu = u[idx];
+        } else {
+          uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
+          uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + s));
+        }
+        v = xv + (uu - 0.5f);
+      }
+      RateTerm r = rate_term(v, m, sabs, 0.5f, gsign);
+      sb += r.bits;
+      ss += r.dsig;
+      sm_ += r.dmu;
+      if (dx) dx[idx] = g * r.dv;
+    }
+    float tb = nvf_block_sum(sb, red);
+    float tsg = nvf_block_sum(ss, red);
+    float tm = nvf_block_sum(sm_, red);
+    if (threadIdx.x == 0) {
+      total_bits += tb;
+      float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
+      if (dsigma) dsigma[ch] = g * tsg * sgn;
+      if (dmu) dmu[ch] = g * tm;
+    }
+  }
+  if (threadIdx.x == 0 && bits) bits[0] = total_bits;
+}
+
+extern "C" int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma,
+                               const float* mu, float* x_rounded, float* bits, float* dx, float* dsigma, float* dmu,
+                               const float* g_dev, float g_host, int batch, int c, int spatial, int mode,
+                               uint64_t seed, uint64_t step, void* stream) {
+  if (!x || !sigma || !mu || batch <= 0 || c <= 0 || spatial <= 0) return NVF_EINVAL;
+  if (mode != 0 && mode != 1) return NVF_EINVAL;
+  latent_rate_kernel<<<1, 1024, 0, nvf_stream(stream)>>>(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dsigma, dmu,
+                                                         g_dev, g_host, batch, c, spatial, mode, seed, step);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// weight rate of one quantised kernel (network.py:4777-4778, 301-305)
+__global__ __launch_bounds__(1024) void weight_rate_kernel(const float* __restrict__ kernel, int n,
+                                                           const float* __restrict__ sigma,
+                                                           const float* __restrict__ mu, float* __restrict__ bits,
+                                                           float* __restrict__ dk, float* __restrict__ dsigma,
+                                                           float* __restrict__ dmu, const float* __restrict__ g_dev,
+                                                           float g_host, int accumulate) {
+  __shared__ float red[16];
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+  const float sraw = sigma[0], sabs = fabsf(sraw), m = mu[0];
+  float sb = 0.f, ss = 0.f, sm_ = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = rintf(kernel[i] * 16.f) / 16.f;
+    RateTerm r = rate_term(v, m, sabs, 0.03125f, gsign);
+    sb += r.bits;
+    ss += r.dsig;
+    sm_ += r.dmu;
+    if (dk) dk[i] = accumulate ? dk[i] + g * r.dv : g * r.dv;
+  }
+  float tb = nvf_block_sum(sb, red);
+  float tsg = nvf_block_sum(ss, red);
+  float tm = nvf_block_sum(sm_, red);
+  if (threadIdx.x == 0) {
+    if (bits) bits[0] = tb;
+    float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
+    if (dsigma) dsigma[0] = accumulate ? dsigma[0] + g * tsg * sgn : g * tsg * sgn;
+    if (dmu) dmu[0] = accumulate ? dmu[0] + g * tm : g * tm;
+  }
+}
+
+extern "C" int nvf_weight_rate(const float* kernel, int n, const float* sigma, const float* mu, float* bits, float* dk,
+                               float* dsigma, float* dmu, const float* g_dev, float g_host, int accumulate,
+                               void* stream) {
+  if (!kernel || !sigma || !mu || n <= 0) return NVF_EINVAL;
+  weight_rate_kernel<<<1, 1024, 0, nvf_stream(stream)>>>(kernel, n, sigma, mu, bits, dk, dsigma, dmu, g_dev, g_host,
+                                                         accumulate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// focal losses fused with their gradient (utils/loss.py:61-72, 94-111)
+// ---------------------------------------------------------------------------
+static const int kLossMaxWG = 1024;
+
+__global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ p, const float* __restrict__ gt,
+                                                    const float* __restrict__ dist, float alpha, float beta,
+                                                    float* __restrict__ part, float* __restrict__ dp,
+                                                    const float* __restrict__ g_dev, float g_host, long n) {
+  __shared__ float red[16];
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  const float a1 = alpha, a0 = 1.f - alpha;  // fp32 "-alpha + 1" as the reference evaluates it
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pv = p[i], gv = gt[i];
+    bool occ = gv != 0.f;
+    float F = occ ? pv : 1.f - pv;
+    float at = occ ? a1 : a0;
+    float w = 1.f;
+    if (dist) w = dist[i] + (occ ? beta : 0.f);
+    float Fc = fmaxf(F, 1e-9f);
+    float om = 1.f - Fc;
+    float lg = logf(Fc);
+    s += -1.f * at * (om * om) * w * lg;
+    if (dp) {
+      float d = 0.f;
+      if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
+      dp[i] = g * (occ ? d : -d);
+    }
+  }
+  float t = nvf_block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+extern "C" size_t nvf_reduce_workspace(void) { return (size_t)kLossMaxWG * 8 * sizeof(float); }
+
+extern "C" int nvf_focal_loss(const float* p, const float* gt, const float* dist, float alpha, float beta, float* loss,
+                              float* dp, const float* g_dev, float g_host, void* workspace, size_t workspace_bytes,
+                              int64_t n, int accumulate, void* stream) {
+  if (!p || !gt || !loss || !workspace || n <= 0) return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  int nwg = (int)((n + 256 * 8 - 1) / (256 * 8));
+  if (nwg > kLossMaxWG) nwg = kLossMaxWG;
+  hipStream_t s = nvf_stream(stream);
+  focal_kernel<<<nwg, 256, 0, s>>>(p, gt, dist, alpha, beta, (float*)workspace, dp, g_dev, g_host, (long)n);
+  finalize_partials<<<1, 64, 0, s>>>((const float*)workspace, loss, nwg, 1, accumulate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// metrics (utils/loss.py:74-84, 113-121): tp, ap, tn, an at thh_acc; sse, denom at thh_sse
+__global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ p, const float* __restrict__ gt,
+                                                      const float* __restrict__ dist, float thh_acc, float thh_sse,
+                                                      float* __restrict__ part, long n) {
+  __shared__ float red[16];
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pv = p[i];
+    bool occ = gt[i] != 0.f;
+    v[0] += (pv > thh_acc && occ) ? 1.f : 0.f;
+    v[1] += occ ? 1.f : 0.f;
+    v[2] += (pv <= thh_acc && !occ) ? 1.f : 0.f;
+    v[3] += occ ? 0.f : 1.f;
+    if (pv > thh_sse) {
+      float dv = dist ? dist[i] : 0.f;
+      v[4] += dv * dv;
+      v[5] += 1.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float t = nvf_block_sum(v[k], red);
+    if (threadIdx.x == 0) part[blockIdx.x * 6 + k] = t;
+  }
+}
+
+extern "C" int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
+                           void* workspace, size_t workspace_bytes, int64_t n, int accumulate, void* stream) {
+  if (!p || !gt || !out || !workspace || n <= 0) return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  int nwg = (int)((n + 256 * 8 - 1) / (256 * 8));
+  if (nwg > kLossMaxWG) nwg = kLossMaxWG;
+  hipStream_t s = nvf_stream(stream);
+  metrics_kernel<<<nwg, 256, 0, s>>>(p, gt, dist, thh_acc, thh_sse, (float*)workspace, (long)n);
+  finalize_partials<<<1, 64, 0, s>>>((const float*)workspace, out, nwg, 6, accumulate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small element-wise kernels
+// ---------------------------------------------------------------------------
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p,
+                                   float* __restrict__ dlogit, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float pv = p[i];
+    dlogit[i] = dp[i] * ((1.f - pv) * pv);
+  }
+}
+
+extern "C" int nvf_sigmoid_bwd(const float* dp, const float* p, float* dlogit, int64_t n, void* stream) {
+  if (!dp || !p || !dlogit || n <= 0) return NVF_EINVAL;
+  sigmoid_bwd_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(dp, p, dlogit, (long)n);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+__global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int d, int h, int w) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int ow = w / 2, oh = h / 2, od = d / 2;
+  int ox = i % ow;
+  long r = i / ow;
+  int oy = r % oh;
+  r /= oh;
+  int oz = r % od;
+  long bc = r / od;
+  const float* xb = x + bc * (long)d * h * w;
+  float m = -INFINITY;
+  for (int dz = 0; dz < 2; ++dz)
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dxx = 0; dxx < 2; ++dxx)
+        m = fmaxf(m, xb[((long)(2 * oz + dz) * h + (2 * oy + dy)) * w + 2 * ox + dxx]);
+  y[i] = m;
+}
+
+extern "C" int nvf_maxpool2(const float* x, float* y, int batch_channels, int d, int h, int w, void* stream) {
+  if (!x || !y || batch_channels <= 0 || d < 2 || h < 2 || w < 2) return NVF_EINVAL;
+  long total = (long)batch_channels * (d / 2) * (h / 2) * (w / 2);
+  maxpool2_kernel<<<NVF_GRID(total, 256), 256, 0, nvf_stream(stream)>>>(x, y, total, d, h, w);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// Adam, torch defaults (A.7 of SURVEY.md): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float step_size, float b1, float b2, float eps,
+                            float bc2_sqrt) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  float mi = m[i] * b1 + gi * (1.f - b1);
+  float vi = v[i] * b2 + (gi * gi) * (1.f - b2);
+  m[i] = mi;
+  v[i] = vi;
+  float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+extern "C" int nvf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int step, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return NVF_EINVAL;
+  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  adam_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(p, g, m, v, (long)n, (float)(lr / bc1), beta1, beta2,
+                                                                eps, (float)sqrt(bc2));
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                   float* __restrict__ dst, int rows, int width) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * width) return;
+  int r = i / width, c = i % width;
+  dst[i] = src[idx[r] * width + c];
+}
+
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                        float* __restrict__ dst, int rows, int width) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * width) return;
+  int r = i / width, c = i % width;
+  dst[idx[r] * width + c] += src[i];
+}
+
+extern "C" int nvf_gather_rows(const float* src, const int64_t* idx, float* dst, int rows, int width, void* stream) {
+  if (!src || !idx || !dst || rows <= 0 || width <= 0) return NVF_EINVAL;
+  gather_rows_kernel<<<NVF_GRID((long)rows * width, 256), 256, 0, nvf_stream(stream)>>>(src, idx, dst, rows, width);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+extern "C" int nvf_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int width,
+                                    void* stream) {
+  if (!src || !idx || !dst || rows <= 0 || width <= 0) return NVF_EINVAL;
+  scatter_add_rows_kernel<<<NVF_GRID((long)rows * width, 256), 256, 0, nvf_stream(stream)>>>(src, idx, dst, rows,
+                                                                                            width);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+__global__ void uniform_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t stream_id) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = nvf_uniform01(seed, stream_id, (uint64_t)i);
+}
+
+extern "C" int nvf_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  if (!out || n <= 0) return NVF_EINVAL;
+  uniform_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(out, (long)n, seed, stream_id);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// occupancy thresholding + compaction (NVFPCC.py:520, 532-535, 631-634)
+// one workgroup per block; raster order kept (ballot prefix inside a wave, wave offsets
+// through LDS, chunks walked in order)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void threshold_count_kernel(const float* __restrict__ p, float thh,
+                                                               int32_t* __restrict__ counts, int voxels) {
+  __shared__ float red[16];
+  const float* pb = p + (size_t)blockIdx.x * voxels;
+  float c = 0.f;
+  for (int i = threadIdx.x; i < voxels; i += blockDim.x) c += pb[i] > thh ? 1.f : 0.f;
+  float t = nvf_block_sum(c, red);  // exact: counts <= 2^24
+  if (threadIdx.x == 0) counts[blockIdx.x] = (int32_t)t;
+}
+
+extern "C" int nvf_threshold_count(const float* p, float thh, int32_t* counts, int batch, int voxels, void* stream) {
+  if (!p || !counts || batch <= 0 || voxels <= 0 || voxels > (1 << 24)) return NVF_EINVAL;
+  threshold_count_kernel<<<batch, 1024, 0, nvf_stream(stream)>>>(p, thh, counts, voxels);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+__global__ __launch_bounds__(1024) void threshold_compact_kernel(const float* __restrict__ p, float thh,
+                                                                 const int32_t* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ origins,
+                                                                 int32_t* __restrict__ coords, int dim) {
+  __shared__ int wave_cnt[16];
+  __shared__ int running;
+  const int b = blockIdx.x, voxels = dim * dim * dim;
+  const float* pb = p + (size_t)b * voxels;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int oz = origins ? origins[3 * b] : 0, oy = origins ? origins[3 * b + 1] : 0, ox = origins ? origins[3 * b + 2] : 0;
+  if (threadIdx.x == 0) running = offsets[b];
+  __syncthreads();
+  for (int base = 0; base < voxels; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    const bool hit = i < voxels && pb[i] > thh;
+    const unsigned long long mask = __ballot(hit);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __popcll(mask);
+    __syncthreads();
+    int off = running;
+    for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+    if (hit) {
+      const int z = i / (dim * dim), y = (i / dim) % dim, x = i % dim;
+      int32_t* o = coords + (size_t)(off + before) * 3;
+      o[0] = oz + z;
+      o[1] = oy + y;
+      o[2] = ox + x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int k = 0; k < nw; ++k) t += wave_cnt[k];
+      running += t;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int nvf_threshold_compact(const float* p, float thh, const int32_t* offsets, const int32_t* origins,
+                                     int32_t* coords, int batch, int dim, void* stream) {
+  if (!p || !offsets || !coords || batch <= 0 || dim <= 0 || dim > 256) return NVF_EINVAL;
+  threshold_compact_kernel<<<batch, 1024, 0, nvf_stream(stream)>>>(p, thh, offsets, origins, coords, dim);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}

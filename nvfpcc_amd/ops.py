@@ -1,0 +1,284 @@
+"""Tensor-level wrappers over the C ABI (include/nvf_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every value is computed by a
+hand-written gfx950 kernel in libnvf_hip.so.  All tensors must be fp32, contiguous and on a
+HIP device; anything else raises (no CPU fallback).
+"""
+import os
+
+import torch
+
+from ._lib import lib, check
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+_NAIVE = int(os.environ.get("NVF_NAIVE", "0"))  # debug: route convs through the one-thread-per-output kernels
+
+
+def set_naive(flag):
+    global _NAIVE
+    _NAIVE = int(bool(flag))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("nvfpcc_amd ops run on the HIP device only (got a CPU tensor); "
+                               "there is no CPU fallback for the NVF hot path")
+        if not t.is_contiguous():
+            raise RuntimeError("nvfpcc_amd ops need contiguous tensors")
+
+
+def _f32(*tensors):
+    _chk(*tensors)
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32, got {t.dtype}")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------- weights
+def pack_conv_weight(w, want_fwd=True, want_bwd=True):
+    """w [Co,Ci,K,K,K] -> (w_fwd [Ci,K^3,Co], w_bwd [Co,K^3 flipped,Ci])."""
+    _f32(w)
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    wf = torch.empty(ci * k ** 3 * co, device=w.device) if want_fwd else None
+    wb = torch.empty(ci * k ** 3 * co, device=w.device) if want_bwd else None
+    check(lib().nvf_pack_conv_weight(_ptr(w), co, ci, k, _ptr(wf), _ptr(wb), _stream()), "nvf_pack_conv_weight")
+    return wf, wb
+
+
+def pack_convT_weight(w, want_fwd=True, want_bwd=True):
+    """w [Ci,Co,K,K,K] -> (w_fwd [Ci,K^3,Co], w_bwd [Co,K^3,Ci])."""
+    _f32(w)
+    ci, co, k = w.shape[0], w.shape[1], w.shape[2]
+    wf = torch.empty(ci * k ** 3 * co, device=w.device) if want_fwd else None
+    wb = torch.empty(ci * k ** 3 * co, device=w.device) if want_bwd else None
+    check(lib().nvf_pack_convT_weight(_ptr(w), ci, co, k, _ptr(wf), _ptr(wb), _stream()), "nvf_pack_convT_weight")
+    return wf, wb
+
+
+def effective_params(kernel, kernel_init, b, b_init, q, u=None, seed=0, stream_id=0):
+    _f32(kernel, kernel_init, b, b_init, u)
+    w_eff = torch.empty_like(kernel)
+    b_eff = torch.empty_like(b) if b is not None else None
+    nb = b.numel() if b is not None else 0
+    check(lib().nvf_effective_params(_ptr(kernel), _ptr(kernel_init), _ptr(u), _ptr(w_eff), kernel.numel(), _ptr(b),
+                                     _ptr(b_init), _ptr(b_eff), nb, int(q), int(seed), int(stream_id), _stream()),
+          "nvf_effective_params")
+    return w_eff, b_eff
+
+
+# ---------------------------------------------------------------- convolutions
+def conv3d_gather(x, w_packed, bias, cout, k, stride, pad, out_spatial, act=ACT_NONE, addend=None, mask=None,
+                  out=None):
+    """y[b,co,o] = act(bias + sum x[b,ci,stride*o - pad + k] w[ci][k][co]) (+addend) (*(mask>0))."""
+    _f32(x, w_packed, bias, addend, mask)
+    B, cin, di, hi, wi = x.shape
+    do, ho, wo = out_spatial
+    if w_packed.numel() != cin * k ** 3 * cout:
+        raise RuntimeError("packed weight size does not match (cin, k, cout)")
+    y = out if out is not None else torch.empty((B, cout, do, ho, wo), device=x.device)
+    for t in (addend, mask):
+        if t is not None and t.shape != y.shape:
+            raise RuntimeError("addend/mask shape must equal the output shape")
+    check(lib().nvf_conv3d_gather(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), _ptr(addend), _ptr(mask), B, cin,
+                                  cout, k, stride, pad, di, hi, wi, do, ho, wo, act, _NAIVE, _stream()),
+          "nvf_conv3d_gather")
+    return y
+
+
+def convT3d_k5s2_fwd(x, w_fwd, bias, cout, pad, act=ACT_NONE, out=None):
+    _f32(x, w_fwd, bias)
+    B, cin, di, hi, wi = x.shape
+    extra = 3 if pad == 0 else 0
+    do, ho, wo = 2 * di + extra, 2 * hi + extra, 2 * wi + extra
+    if w_fwd.numel() != cin * 125 * cout:
+        raise RuntimeError("packed weight size does not match (cin, 5, cout)")
+    y = out if out is not None else torch.empty((B, cout, do, ho, wo), device=x.device)
+    check(lib().nvf_convT3d_k5s2_fwd(_ptr(x), _ptr(w_fwd), _ptr(bias), _ptr(y), B, cin, cout, pad, di, hi, wi, do,
+                                     ho, wo, act, _NAIVE, _stream()), "nvf_convT3d_k5s2_fwd")
+    return y
+
+
+def wgrad(p, q, k, stride, pad, out_mode=0, out=None, accumulate=False):
+    """dw[a][b][k] (out_mode 0) or dw[b][a][flip k] (out_mode 1) = sum p[n,a,i] q[n,b,stride*i-pad+k]."""
+    _f32(p, q)
+    B, a, dp, hp, wp = p.shape
+    b, dq, hq, wq = q.shape[1], q.shape[2], q.shape[3], q.shape[4]
+    shape = (a, b, k, k, k) if out_mode == 0 else (b, a, k, k, k)
+    dw = out if out is not None else torch.empty(shape, device=p.device)
+    nbytes = lib().nvf_wgrad_workspace(B, a, b, k, dp, hp, wp)
+    ws = workspace(nbytes, p.device, "wgrad")
+    check(lib().nvf_wgrad(_ptr(p), _ptr(q), _ptr(dw), _ptr(ws), ws.numel(), B, a, b, k, stride, pad, dp, hp, wp, dq,
+                          hq, wq, out_mode, int(accumulate), _NAIVE, _stream()), "nvf_wgrad")
+    return dw
+
+
+def channel_sum(x, out=None, accumulate=False):
+    _f32(x)
+    B, c = x.shape[0], x.shape[1]
+    spatial = x[0, 0].numel()
+    o = out if out is not None else torch.empty(c, device=x.device)
+    ws = workspace(lib().nvf_channel_sum_workspace(c), x.device, "chsum")
+    check(lib().nvf_channel_sum(_ptr(x), _ptr(o), _ptr(ws), ws.numel(), B, c, spatial, int(accumulate), _stream()),
+          "nvf_channel_sum")
+    return o
+
+
+# ---------------------------------------------------------------- GDN
+def gdn_fwd(x, beta_hat, gamma_hat, inverse):
+    _f32(x, beta_hat, gamma_hat)
+    B, c = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    check(lib().nvf_gdn_fwd(_ptr(x), _ptr(beta_hat), _ptr(gamma_hat), _ptr(y), B, c, x[0, 0].numel(), int(inverse),
+                            _stream()), "nvf_gdn_fwd")
+    return y
+
+
+def gdn_bwd(x, beta_hat, gamma_hat, dy, inverse):
+    _f32(x, beta_hat, gamma_hat, dy)
+    B, c = x.shape[0], x.shape[1]
+    dx = torch.empty_like(x)
+    dbeta = torch.empty_like(beta_hat)
+    dgamma = torch.empty_like(gamma_hat)
+    ws = workspace(lib().nvf_gdn_bwd_workspace(c), x.device, "gdn")
+    check(lib().nvf_gdn_bwd(_ptr(x), _ptr(beta_hat), _ptr(gamma_hat), _ptr(dy), _ptr(dx), _ptr(dbeta), _ptr(dgamma),
+                            _ptr(ws), ws.numel(), B, c, x[0, 0].numel(), int(inverse), _stream()), "nvf_gdn_bwd")
+    return dx, dbeta, dgamma
+
+
+# ---------------------------------------------------------------- rates
+def latent_rate(x, sigma, mu, mode, u=None, block_ids=None, want_grad=False, g_dev=None, g_host=1.0, seed=0,
+                step=0):
+    """Returns (x_rounded, bits[1], dx, dsigma, dmu); the gradient outputs are None unless want_grad."""
+    _f32(x, sigma, mu, u, g_dev)
+    _chk(block_ids)
+    B, c = x.shape[0], x.shape[1]
+    xr = torch.empty_like(x)
+    bits = torch.empty(1, device=x.device)
+    dx = torch.empty_like(x) if want_grad else None
+    ds = torch.empty(c, device=x.device) if want_grad else None
+    dm = torch.empty(c, device=x.device) if want_grad else None
+    check(lib().nvf_latent_rate(_ptr(x), _ptr(u), _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(xr), _ptr(bits),
+                                _ptr(dx), _ptr(ds), _ptr(dm), _ptr(g_dev), float(g_host), B, c, x[0, 0].numel(),
+                                0 if mode == "train" else 1, int(seed), int(step), _stream()), "nvf_latent_rate")
+    return xr, bits, dx, ds, dm
+
+
+def weight_rate(kernel, sigma, mu, bits_out=None, dk=None, dsigma=None, dmu=None, g_dev=None, g_host=1.0,
+                accumulate=False):
+    _f32(kernel, sigma, mu, bits_out, dk, dsigma, dmu, g_dev)
+    bits = bits_out if bits_out is not None else torch.empty(1, device=kernel.device)
+    check(lib().nvf_weight_rate(_ptr(kernel), kernel.numel(), _ptr(sigma), _ptr(mu), _ptr(bits), _ptr(dk),
+                                _ptr(dsigma), _ptr(dmu), _ptr(g_dev), float(g_host), int(accumulate), _stream()),
+          "nvf_weight_rate")
+    return bits
+
+
+# ---------------------------------------------------------------- losses / metrics
+def focal_loss(p, gt, dist, alpha, beta=0.0, want_grad=False, g_dev=None, g_host=1.0, loss_out=None,
+               accumulate=False):
+    _f32(p, gt, dist, g_dev, loss_out)
+    loss = loss_out if loss_out is not None else torch.empty(1, device=p.device)
+    dp = torch.empty_like(p) if want_grad else None
+    ws = workspace(lib().nvf_reduce_workspace(), p.device, "reduce")
+    check(lib().nvf_focal_loss(_ptr(p), _ptr(gt), _ptr(dist), float(alpha), float(beta), _ptr(loss), _ptr(dp),
+                               _ptr(g_dev), float(g_host), _ptr(ws), ws.numel(), p.numel(), int(accumulate),
+                               _stream()), "nvf_focal_loss")
+    return loss, dp
+
+
+def metrics(p, gt, dist, thh_acc, thh_sse, out=None, accumulate=False):
+    _f32(p, gt, dist, out)
+    o = out if out is not None else torch.empty(6, device=p.device)
+    ws = workspace(lib().nvf_reduce_workspace(), p.device, "reduce")
+    check(lib().nvf_metrics(_ptr(p), _ptr(gt), _ptr(dist), float(thh_acc), float(thh_sse), _ptr(o), _ptr(ws),
+                            ws.numel(), p.numel(), int(accumulate), _stream()), "nvf_metrics")
+    return o
+
+
+def sigmoid_bwd(dp, p):
+    _f32(dp, p)
+    out = torch.empty_like(p)
+    check(lib().nvf_sigmoid_bwd(_ptr(dp), _ptr(p), _ptr(out), p.numel(), _stream()), "nvf_sigmoid_bwd")
+    return out
+
+
+def maxpool2(x):
+    _f32(x)
+    B, c, d, h, w = x.shape
+    y = torch.empty((B, c, d // 2, h // 2, w // 2), device=x.device)
+    check(lib().nvf_maxpool2(_ptr(x), _ptr(y), B * c, d, h, w, _stream()), "nvf_maxpool2")
+    return y
+
+
+# ---------------------------------------------------------------- optimiser / rows / rng
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    _f32(p, g, m, v)
+    check(lib().nvf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+                              float(eps), int(step), _stream()), "nvf_adam_step")
+
+
+def gather_rows(src, idx):
+    _f32(src)
+    _chk(idx)
+    if idx.dtype != torch.int64:
+        raise RuntimeError("row indices must be int64")
+    width = src[0].numel()
+    dst = torch.empty((idx.numel(),) + tuple(src.shape[1:]), device=src.device)
+    check(lib().nvf_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), idx.numel(), width, _stream()), "nvf_gather_rows")
+    return dst
+
+
+def scatter_add_rows(src, idx, dst):
+    _f32(src, dst)
+    _chk(idx)
+    check(lib().nvf_scatter_add_rows(_ptr(src), _ptr(idx), _ptr(dst), idx.numel(), src[0].numel(), _stream()),
+          "nvf_scatter_add_rows")
+    return dst
+
+
+def uniform(shape, device, seed, stream_id):
+    out = torch.empty(shape, device=device)
+    check(lib().nvf_uniform(_ptr(out), out.numel(), int(seed), int(stream_id), _stream()), "nvf_uniform")
+    return out
+
+
+# ---------------------------------------------------------------- occupancy -> points
+def threshold_points(p, thh, origins=None):
+    """p [B,1,D,D,D] -> int32 [n,3] points (origin + (z,y,x)) in (b,z,y,x) raster order, plus per-block counts."""
+    _f32(p)
+    B, dim = p.shape[0], p.shape[-1]
+    counts = torch.empty(B, dtype=torch.int32, device=p.device)
+    check(lib().nvf_threshold_count(_ptr(p), float(thh), _ptr(counts), B, dim ** 3, _stream()),
+          "nvf_threshold_count")
+    offsets = (torch.cumsum(counts, 0, dtype=torch.int32) - counts).contiguous()
+    total = int(counts.sum().item())
+    coords = torch.empty((max(total, 1), 3), dtype=torch.int32, device=p.device)
+    if origins is not None:
+        origins = origins.to(device=p.device, dtype=torch.int32).contiguous()
+    check(lib().nvf_threshold_compact(_ptr(p), float(thh), _ptr(offsets), _ptr(origins), _ptr(coords), B, dim,
+                                      _stream()), "nvf_threshold_compact")
+    return coords[:total], counts
