@@ -113,13 +113,13 @@ int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* gamma_hat, c
  * U comes from `u` if non-NULL, else Philox keyed by (seed, block_ids[b], step): one stream per
  * leaf block, so the noise does not depend on how blocks are sharded over GPUs; block_ids NULL
  * means 0..B-1.  Gradients (each optional, overwritten) are already multiplied by the upstream
- * gradient g = g_host * (g_dev ? *g_dev : 1): dx = g dbits/dx (identity through the round and
- * the noise), dsigma[c], dmu[c].  The LowerBound at 1e-8 passes when like >= 1e-8 or the incoming
+ * gradient g = g_host * (g_dev ? *g_dev : 1): dx = dx_addend + g dbits/dx (identity through the
+ * round and the noise; dx_addend, optional, is the decoder's gradient w.r.t. x_rounded), dsigma[c], dmu[c].  The LowerBound at 1e-8 passes when like >= 1e-8 or the incoming
  * gradient is negative (network.py:66-72). */
 int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma, const float* mu,
-                    float* x_rounded, float* bits, float* dx, float* dsigma, float* dmu, const float* g_dev,
-                    float g_host, int batch, int c, int spatial, int mode, uint64_t seed, uint64_t step,
-                    void* stream);
+                    float* x_rounded, float* bits, float* dx, const float* dx_addend, float* dsigma, float* dmu,
+                    const float* g_dev, float g_host, int batch, int c, int spatial, int mode, uint64_t seed,
+                    uint64_t step, void* stream);
 
 /* ---- weight rate (network.py:4777-4778, 301-305): one quantised kernel ---------
  * bits[0] = sum -log2(max(Phi((w-mu+1/32)/|s|) - Phi((w-mu-1/32)/|s|), 1e-8)), w = round(16 k)/16.
@@ -144,6 +144,13 @@ int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_ac
 
 /* dlogit = dp * p * (1 - p)   (sigmoid backward of network.py:4761,4764,4768) */
 int nvf_sigmoid_bwd(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
+
+/* out = dy where y > 0 else 0   (ReLU backward of network.py:4760-4766) */
+int nvf_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);
+
+/* get_se (utils/loss.py:123-128): out[b,0,:] = ((p > thh) * dist)^2, out[b,1,:] = p; out is [B,2,spatial] */
+int nvf_squared_error_map(const float* p, const float* dist, float thh, float* out, int batch, int spatial,
+                          void* stream);
 
 /* 2x2x2 max pooling, stride 2 (MultiscaleProcessor, NVFPCC.py:76-88) */
 int nvf_maxpool2(const float* x, float* y, int batch_channels, int d, int h, int w, void* stream);

@@ -31,12 +31,14 @@ PROTOTYPES = {
     "nvf_gdn_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "nvf_gdn_bwd_workspace": (Z, [I]),
     "nvf_gdn_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
-    "nvf_latent_rate": (I, [P] * 11 + [F, I, I, I, I, U, U, P]),
+    "nvf_latent_rate": (I, [P] * 12 + [F, I, I, I, I, U, U, P]),
     "nvf_weight_rate": (I, [P, I, P, P, P, P, P, P, P, F, I, P]),
     "nvf_reduce_workspace": (Z, []),
     "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, P]),
     "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P]),
     "nvf_sigmoid_bwd": (I, [P, P, P, L, P]),
+    "nvf_relu_bwd": (I, [P, P, P, L, P]),
+    "nvf_squared_error_map": (I, [P, P, F, P, I, I, P]),
     "nvf_maxpool2": (I, [P, P, I, I, I, I, P]),
     "nvf_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
                                                            const float* __restrict__ sigma,
                                                            const float* __restrict__ mu, float* __restrict__ x_rounded,
                                                            float* __restrict__ bits, float* __restrict__ dx,
+                                                           const float* __restrict__ dx_addend,
                                                            float* __restrict__ dsigma, float* __restrict__ dmu,
                                                            const float* __restrict__ g_dev, float g_host, int batch,
                                                            int c, int spatial, int mode, uint64_t seed, uint64_t step) {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
       sb += r.bits;
       ss += r.dsig;
       sm_ += r.dmu;
-      if (dx) dx[idx] = g * r.dv;
+      if (dx) dx[idx] = (dx_addend ? dx_addend[idx] : 0.f) + g * r.dv;
     }
     float tb = nvf_block_sum(sb, red);
     float tsg = nvf_block_sum(ss, red);
@@ -308,13 +309,15 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
 }
 
 extern "C" int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma,
-                               const float* mu, float* x_rounded, float* bits, float* dx, float* dsigma, float* dmu,
-                               const float* g_dev, float g_host, int batch, int c, int spatial, int mode,
+                               const float* mu, float* x_rounded, float* bits, float* dx, const float* dx_addend,
+                               float* dsigma, float* dmu, const float* g_dev, float g_host, int batch, int c,
+                               int spatial, int mode,
                                uint64_t seed, uint64_t step, void* stream) {
   if (!x || !sigma || !mu || batch <= 0 || c <= 0 || spatial <= 0) return NVF_EINVAL;
   if (mode != 0 && mode != 1) return NVF_EINVAL;
-  latent_rate_kernel<<<1, 1024, 0, nvf_stream(stream)>>>(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dsigma, dmu,
-                                                         g_dev, g_host, batch, c, spatial, mode, seed, step);
+  latent_rate_kernel<<<1, 1024, 0, nvf_stream(stream)>>>(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dx_addend,
+                                                         dsigma, dmu, g_dev, g_host, batch, c, spatial, mode, seed,
+                                                         step);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -464,6 +467,41 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dp, const float* __
 extern "C" int nvf_sigmoid_bwd(const float* dp, const float* p, float* dlogit, int64_t n, void* stream) {
   if (!dp || !p || !dlogit || n <= 0) return NVF_EINVAL;
   sigmoid_bwd_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(dp, p, dlogit, (long)n);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                                long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+extern "C" int nvf_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+  if (!dy || !y || !out || n <= 0) return NVF_EINVAL;
+  relu_bwd_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(dy, y, out, (long)n);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// get_se (utils/loss.py:123-128): out[b,0,:] = ((p > thh) * dist)^2, out[b,1,:] = p
+__global__ void se_kernel(const float* __restrict__ p, const float* __restrict__ dist, float thh,
+                          float* __restrict__ out, long n, int spatial) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  long b = i / spatial;
+  int s = (int)(i % spatial);
+  float pv = p[i];
+  float d = pv > thh ? dist[i] : 0.f;
+  out[(2 * b) * spatial + s] = d * d;
+  out[(2 * b + 1) * spatial + s] = pv;
+}
+
+extern "C" int nvf_squared_error_map(const float* p, const float* dist, float thh, float* out, int batch, int spatial,
+                                     void* stream) {
+  if (!p || !dist || !out || batch <= 0 || spatial <= 0) return NVF_EINVAL;
+  long n = (long)batch * spatial;
+  se_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(p, dist, thh, out, n, spatial);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

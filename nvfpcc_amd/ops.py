@@ -171,9 +171,9 @@ def gdn_bwd(x, beta_hat, gamma_hat, dy, inverse):
 
 # ---------------------------------------------------------------- rates
 def latent_rate(x, sigma, mu, mode, u=None, block_ids=None, want_grad=False, g_dev=None, g_host=1.0, seed=0,
-                step=0):
+                step=0, dx_addend=None):
     """Returns (x_rounded, bits[1], dx, dsigma, dmu); the gradient outputs are None unless want_grad."""
-    _f32(x, sigma, mu, u, g_dev)
+    _f32(x, sigma, mu, u, g_dev, dx_addend)
     _chk(block_ids)
     B, c = x.shape[0], x.shape[1]
     xr = torch.empty_like(x)
@@ -182,7 +182,8 @@ def latent_rate(x, sigma, mu, mode, u=None, block_ids=None, want_grad=False, g_d
     ds = torch.empty(c, device=x.device) if want_grad else None
     dm = torch.empty(c, device=x.device) if want_grad else None
     check(lib().nvf_latent_rate(_ptr(x), _ptr(u), _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(xr), _ptr(bits),
-                                _ptr(dx), _ptr(ds), _ptr(dm), _ptr(g_dev), float(g_host), B, c, x[0, 0].numel(),
+                                _ptr(dx), _ptr(dx_addend), _ptr(ds), _ptr(dm), _ptr(g_dev), float(g_host), B, c,
+                                x[0, 0].numel(),
                                 0 if mode == "train" else 1, int(seed), int(step), _stream()), "nvf_latent_rate")
     return xr, bits, dx, ds, dm
 
@@ -223,6 +224,23 @@ def sigmoid_bwd(dp, p):
     _f32(dp, p)
     out = torch.empty_like(p)
     check(lib().nvf_sigmoid_bwd(_ptr(dp), _ptr(p), _ptr(out), p.numel(), _stream()), "nvf_sigmoid_bwd")
+    return out
+
+
+def relu_bwd(dy, y):
+    _f32(dy, y)
+    out = torch.empty_like(y)
+    check(lib().nvf_relu_bwd(_ptr(dy), _ptr(y), _ptr(out), y.numel(), _stream()), "nvf_relu_bwd")
+    return out
+
+
+def squared_error_map(p, dist, thh):
+    _f32(p, dist)
+    B = p.shape[0]
+    spatial = p[0].numel()
+    out = torch.empty((B, 2) + tuple(p.shape[2:]), device=p.device)
+    check(lib().nvf_squared_error_map(_ptr(p), _ptr(dist), float(thh), _ptr(out), B, spatial, _stream()),
+          "nvf_squared_error_map")
     return out
 
 
