@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Throughput of the NVF train step on MI355X (BASELINE.json metric: leaf-blocks/s of the NVF train step,
+32^3 blocks, chanstr 8,16,8,8, ch 3).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one mini-batch decoder update (gather latents -> forward, mode 'train', q = 1 -> GT pyramid
+-> 3 focal losses + rate terms -> backward -> [RCCL all-reduce of the flat decoder gradient] -> fused Adam),
+NVFPCC.py:149-223 minus its logging syncs, on `--batch` blocks PER GPU (weak scaling: the global
+mini-batch is batch x N).  Inputs (grids, latent table, weights) are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_MACS = {"8,16,8,8": 201190992, "16,32,16,16": 788428800}      # SURVEY.md section 2.1 / BASELINE.md section 3
+CONV2_MACS = {"8,16,8,8": 134217728, "16,32,16,16": 536870912}     # per block, each of fwd / bwd-data / bwd-weight
+BYTES_PER_BLOCK = {"8,16,8,8": 15050624, "16,32,16,16": 29092224}  # layer-granular HBM model, SURVEY.md 8(d)
+PEAK_FP32_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: fp32 vector = matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_engine(args, device, world):
+    from nvfpcc_amd import network, dist as nd
+    from nvfpcc_amd.engine import TrainEngine
+    from nvfpcc_amd.model import Net
+    from nvfpcc_amd.seeds import synthetic_seed
+    from nvfpcc_amd.synth import make_blocks
+    network.reset_seed(synthetic_seed())
+    net = Net(None, "Gaussian", args.ch, args.chanstr, verbose=False).to(device)
+    distinct = min(args.blocks, args.distinct)
+    gts, dists = make_blocks(distinct)
+    reps = (args.blocks + distinct - 1) // distinct
+    gt = torch.from_numpy(np.tile(gts, (reps, 1, 1, 1, 1))[:args.blocks]).float().to(device)
+    dist_t = torch.from_numpy(np.tile(dists, (reps, 1, 1, 1, 1))[:args.blocks]).float().to(device)
+    eng = TrainEngine(net, gt, dist_t, n_points_total=float(gt.sum().item()), lmbda=200.0, w1=10.0, w2=57.0,
+                      lr=1e-3, wemb=5.0, seed=0)
+    nd.attach(eng, world)
+    return eng
+
+
+class KernelProbe:
+    """HIP-event brackets around chosen C-ABI launches inside the timed region (same stream)."""
+
+    def __init__(self):
+        self.events = {}
+
+    def wrap(self, ops, fn_name, label, match):
+        orig = getattr(ops, fn_name)
+        probe = self
+
+        def wrapped(*a, **k):
+            if probe.enabled and match(*a, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = orig(*a, **k)
+                e.record()
+                probe.events.setdefault(label, []).append((s, e))
+                return out
+            return orig(*a, **k)
+        setattr(ops, fn_name, wrapped)
+
+    enabled = False
+
+    def summary(self):
+        return {k: float(np.mean([s.elapsed_time(e) for s, e in v])) * 1e3 for k, v in self.events.items()}  # us
+
+
+def cpu_baseline(args, seconds=20.0):
+    """The oracle (CPU restatement of the reference's step) on this box's host cores: bounded sample."""
+    from oracle import nvf_oracle as O
+    from nvfpcc_amd.seeds import synthetic_seed
+    from nvfpcc_amd.synth import make_blocks
+    B = args.batch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = max(1, cores // 2) if cores > 16 else cores     # physical cores on an SMT host
+    torch.set_num_threads(threads)
+    gts, dists = make_blocks(B)
+    gt, dist = torch.from_numpy(gts).float(), torch.from_numpy(dists).float()
+    channels = tuple(int(c) for c in args.chanstr.split(","))
+    tr = O.OracleTrainer(args.ch, channels, synthetic_seed(), n_leaf=B, n_points=float(gt.sum()), lr=1e-3, wemb=5.0)
+    idx = torch.arange(B)
+    tr.train_step(idx, gt, dist, q=1)   # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds or n < 3:
+        tr.train_step(idx, gt, dist, q=1)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * B / dt, 2), "unit": "blocks/s", "cores": threads, "kind": "port",
+            "sample": f"{n} train steps of batch {B} (oracle/nvf_oracle.py OracleTrainer, torch {torch.__version__} CPU, "
+                      f"{threads} threads, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=16, help="blocks per GPU per step (reference --batchsize 16)")
+    ap.add_argument("--blocks", type=int, default=917, help="leaf blocks resident per GPU (longdress l5: 917)")
+    ap.add_argument("--distinct", type=int, default=128, help="distinct synthetic blocks generated, then tiled")
+    ap.add_argument("--ch", type=int, default=3)
+    ap.add_argument("--chanstr", default="8,16,8,8")
+    ap.add_argument("--q", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also time batch 256 and the full-batch latent step")
+    ap.add_argument("--naive", action="store_true", help="debug: one-thread-per-output kernels")
+    args = ap.parse_args()
+
+    from nvfpcc_amd import dist as nd, ops
+    rank, local_rank, world = nd.init()
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    ops.set_naive(args.naive)
+    eng = build_engine(args, device, world)
+    B = args.batch
+
+    # epoch order shared by every rank (seeded), global mini-batch = B * world
+    rng = np.random.default_rng(1234)
+    order = np.concatenate([rng.permutation(args.blocks) for _ in range(
+        (args.steps + args.warmup + 2) * B * world // args.blocks + 2)])
+    counts = eng.counts
+
+    def step(i):
+        ids, whole = nd.shard_minibatch(order, i, B * world, rank, world)
+        eng.train_step(ids, args.q, n_pts=float(counts[whole].sum()))
+
+    probe = KernelProbe()
+    c3 = int(args.chanstr.split(",")[3])
+    probe.wrap(ops, "conv3d_gather", "conv2_fwd",
+               lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
+    probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",
+               lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 35 and x.shape[1] == c3)
+    probe.wrap(ops, "wgrad", "conv2_bwd_weight(2 launches)",
+               lambda p_, q_, k, s, pad, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    probe.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    probe.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = eng.loss_value()
+    blocks_per_s = args.steps * B * world / dt
+
+    extra = {}
+    if args.sweep and rank == 0 and world == 1:
+        for b2 in (256,):
+            for i in range(3):
+                eng.train_step(order[i * b2:(i + 1) * b2], args.q)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n2 = 10
+            for i in range(n2):
+                eng.train_step(order[i * b2:(i + 1) * b2], args.q)
+            torch.cuda.synchronize()
+            extra[f"train_step_B{b2}_blocks_per_s"] = round(n2 * b2 / (time.perf_counter() - t1), 1)
+        eng.latent_step(args.q)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(3):
+            eng.latent_step(args.q)
+        torch.cuda.synchronize()
+        extra[f"latent_step_N{args.blocks}_blocks_per_s"] = round(3 * args.blocks / (time.perf_counter() - t1), 1)
+
+    if rank == 0:
+        kern_us = probe.summary()
+        macs = CONV2_MACS.get(args.chanstr)
+        roofline = None
+        if kern_us and macs:
+            single = {k: v for k, v in kern_us.items() if "2 launches" not in k}
+            label = max(single, key=single.get)
+            us = single[label]
+            flops = 2.0 * macs * B
+            if label == "conv2_bwd_data":
+                flops = flops  # algorithmic MACs of the layer (the 35^3 gather form computes a halo on top)
+            achieved = flops / (us * 1e-6) / 1e12
+            roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(us, 2), "flops_per_launch": flops,
+                        "all_kernels_avg_us": {k: round(v, 2) for k, v in kern_us.items()}}
+        fwd = FWD_MACS.get(args.chanstr)
+        out = {
+            "metric": "leaf-blocks/sec NVF train step (32^3, chanstr=%s)" % args.chanstr,
+            "value": round(blocks_per_s, 1), "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train_step: decoder mini-batch update, NVFPCC.py:149-223 (fwd mode=train q=%d, "
+                                   "3 focal losses + rate terms, bwd, fused Adam)" % args.q,
+                       "batch_per_gpu": B, "global_batch": B * world, "blocks_resident": args.blocks,
+                       "ch": args.ch, "chanstr": args.chanstr, "parallelism": f"dp{world}",
+                       "data_detail": f"{min(args.blocks, args.distinct)} distinct synthetic 32^3 quadric-sheet blocks "
+                                      f"(2.5-3.5% occupancy, exact EDT distance) tiled to {args.blocks}; seed-init weights"},
+            "loss_last_step": round(loss, 3),
+        }
+        if fwd:
+            tf = blocks_per_s / world * 6.0 * fwd / 1e12
+            out["step_level"] = {"fp32_tflops_per_gpu": round(tf, 3), "frac_of_fp32_peak": round(tf / PEAK_FP32_TFLOPS, 4),
+                                 "hbm_fraction_layer_granular_model": round(
+                                     blocks_per_s / world * BYTES_PER_BLOCK[args.chanstr] / (PEAK_HBM_GBS * 1e9), 4)}
+        if roofline:
+            out["roofline"] = roofline
+        if extra:
+            out["sweep"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,15 @@ int nvf_effective_params(const float* kernel, const float* kernel_init, const fl
                          const float* b, const float* b_init, float* b_eff, int nb, int q, uint64_t seed,
                          uint64_t stream_id, void* stream);
 
+/* All layers of a decoder in one launch.  `table_dev` is a device array of `nlayers` records
+ *   { const float *kernel, *kernel_init, *b, *b_init; float *w_fwd, *w_bwd, *b_eff;
+ *     int32 dim0, dim1, k3, kind (0 conv / 1 convT), quantised, layer_id, nbias, pad; }
+ * (nvf_layer_desc_size() bytes each).  Writes w_eff = f_q(kernel) + kernel_init directly in the packed
+ * layouts and b_eff = b + b_init.  Weight noise (q = 1): Philox(seed, ((step + *step_dev) << 8) | layer_id). */
+size_t nvf_layer_desc_size(void);
+int nvf_prepare_weights(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
+                        const uint64_t* step_dev, void* stream);
+
 /* ---- gather convolution (F.conv3d fwd; bwd-data of conv3d and conv_transpose3d) --
  * y[b,co,o] = act(bias[co] + sum_{ci,k} x[b,ci, stride*o - pad + k] * w[ci][k][co])
  *             (+ addend[b,co,o]) (* (mask[b,co,o] > 0))
@@ -133,10 +142,11 @@ size_t nvf_reduce_workspace(void);
 /* ---- losses (utils/loss.py:61-72, 94-111) fused with their gradient ------------
  * loss[0] (+)= sum -a_t (1-p_t)^2 w ln(p_t),  p_t = max(p or 1-p, 1e-9), a_t = alpha or 1-alpha,
  * w = 1 (dist NULL: get_focal_dense) or dist + gt*beta (get_surf_focal_dense).
- * dp (optional) receives g * d loss / d p with g = g_host * (g_dev ? *g_dev : 1). */
+ * dp (optional) receives g * d loss / d p with g = g_host * (g_dev ? *g_dev : 1); with chain_sigmoid
+ * it is further multiplied by p (1 - p), i.e. it is the gradient w.r.t. the head's logit. */
 int nvf_focal_loss(const float* p, const float* gt, const float* dist, float alpha, float beta, float* loss,
                    float* dp, const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, int64_t n,
-                   int accumulate, void* stream);
+                   int accumulate, int chain_sigmoid, void* stream);
 
 /* metrics (utils/loss.py:74-84, 113-121): out[0..5] (+)= tp, ap, tn, an at thh_acc; sse, denom at thh_sse */
 int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,

@@ -22,6 +22,8 @@ PROTOTYPES = {
     "nvf_pack_conv_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_pack_convT_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_effective_params": (I, [P, P, P, P, I, P, P, P, I, I, U, U, P]),
+    "nvf_layer_desc_size": (Z, []),
+    "nvf_prepare_weights": (I, [P, I, I, U, U, P, P]),
     "nvf_conv3d_gather": (I, [P, P, P, P, P, P] + [I] * 14 + [P]),
     "nvf_convT3d_k5s2_fwd": (I, [P, P, P, P] + [I] * 12 + [P]),
     "nvf_wgrad_workspace": (Z, [I] * 7),
@@ -34,7 +36,7 @@ PROTOTYPES = {
     "nvf_latent_rate": (I, [P] * 12 + [F, I, I, I, I, U, U, P]),
     "nvf_weight_rate": (I, [P, I, P, P, P, P, P, P, P, F, I, P]),
     "nvf_reduce_workspace": (Z, []),
-    "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, P]),
+    "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, I, P]),
     "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P]),
     "nvf_sigmoid_bwd": (I, [P, P, P, L, P]),
     "nvf_relu_bwd": (I, [P, P, P, L, P]),

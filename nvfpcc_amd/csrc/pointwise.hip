@@ -56,6 +56,62 @@ extern "C" int nvf_effective_params(const float* kernel, const float* kernel_ini
   return NVF_OK;
 }
 
+// All layers of the decoder in ONE launch: w_eff = f_q(kernel) + kernel_init written straight into
+// the two scalar-load layouts (w_fwd[ci][k][co], w_bwd[co][k'][ci]) and b_eff = b + b_init.
+struct NvfLayerDesc {
+  const float* kernel;
+  const float* kernel_init;
+  const float* b;
+  const float* b_init;
+  float* w_fwd;
+  float* w_bwd;
+  float* b_eff;
+  int32_t dim0, dim1, k3;   // kernel is [dim0][dim1][k3]
+  int32_t kind;             // 0: conv [cout][cin][k] (w_bwd taps flipped); 1: convT [cin][cout][k]
+  int32_t quantised;        // 1: Q-layer (q applies); 0: I-layer (raw kernel)
+  int32_t layer_id;         // weight-noise stream id
+  int32_t nbias, pad_;
+};
+
+__global__ void prepare_weights_kernel(const NvfLayerDesc* __restrict__ table, int q, uint64_t seed, uint64_t step,
+                                       const uint64_t* __restrict__ step_dev) {
+  const NvfLayerDesc d = table[blockIdx.y];
+  const int n = d.dim0 * d.dim1 * d.k3;
+  const int qq = d.quantised ? q : 0;
+  const uint64_t st = step + (step_dev ? step_dev[0] : 0ull);
+  const uint64_t sid = (st << 8) | (uint64_t)d.layer_id;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + d.nbias; i += gridDim.x * blockDim.x) {
+    if (i < n) {
+      float k = d.kernel[i];
+      if (qq == 1) k = k + (nvf_uniform01(seed, sid, (uint64_t)i) - 0.5f) * 0.0625f;
+      else if (qq == 2) k = rintf(k * 16.f) / 16.f;
+      const float w = k + d.kernel_init[i];
+      const int t = i % d.k3, i1 = (i / d.k3) % d.dim1, i0 = i / (d.k3 * d.dim1);
+      if (d.kind == 0) {  // i0 = co, i1 = ci
+        if (d.w_fwd) d.w_fwd[(i1 * d.k3 + t) * d.dim0 + i0] = w;
+        if (d.w_bwd) d.w_bwd[(i0 * d.k3 + (d.k3 - 1 - t)) * d.dim1 + i1] = w;
+      } else {            // i0 = ci, i1 = co
+        if (d.w_fwd) d.w_fwd[(i0 * d.k3 + t) * d.dim1 + i1] = w;
+        if (d.w_bwd) d.w_bwd[(i1 * d.k3 + t) * d.dim0 + i0] = w;
+      }
+    } else {
+      const int j = i - n;
+      d.b_eff[j] = d.b[j] + d.b_init[j];
+    }
+  }
+}
+
+extern "C" size_t nvf_layer_desc_size(void) { return sizeof(NvfLayerDesc); }
+
+extern "C" int nvf_prepare_weights(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
+                                   const uint64_t* step_dev, void* stream) {
+  if (!table_dev || nlayers <= 0) return NVF_EINVAL;
+  prepare_weights_kernel<<<dim3(16, nlayers), 256, 0, nvf_stream(stream)>>>((const NvfLayerDesc*)table_dev, q, seed,
+                                                                           step, step_dev);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 // ---------------------------------------------------------------------------
 // GDN / IGDN (gdn_3d.py:72-95, 137-159)
 // ---------------------------------------------------------------------------
@@ -371,7 +427,8 @@ static const int kLossMaxWG = 1024;
 __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ p, const float* __restrict__ gt,
                                                     const float* __restrict__ dist, float alpha, float beta,
                                                     float* __restrict__ part, float* __restrict__ dp,
-                                                    const float* __restrict__ g_dev, float g_host, long n) {
+                                                    const float* __restrict__ g_dev, float g_host, long n,
+                                                    int chain_sigmoid) {
   __shared__ float red[16];
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
   const float a1 = alpha, a0 = 1.f - alpha;  // fp32 "-alpha + 1" as the reference evaluates it
@@ -390,7 +447,8 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ p,
     if (dp) {
       float d = 0.f;
       if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
-      dp[i] = g * (occ ? d : -d);
+      float dd = g * (occ ? d : -d);
+      dp[i] = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
     }
   }
   float t = nvf_block_sum(s, red);
@@ -401,13 +459,14 @@ extern "C" size_t nvf_reduce_workspace(void) { return (size_t)kLossMaxWG * 8 * s
 
 extern "C" int nvf_focal_loss(const float* p, const float* gt, const float* dist, float alpha, float beta, float* loss,
                               float* dp, const float* g_dev, float g_host, void* workspace, size_t workspace_bytes,
-                              int64_t n, int accumulate, void* stream) {
+                              int64_t n, int accumulate, int chain_sigmoid, void* stream) {
   if (!p || !gt || !loss || !workspace || n <= 0) return NVF_EINVAL;
   if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
   int nwg = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (nwg > kLossMaxWG) nwg = kLossMaxWG;
   hipStream_t s = nvf_stream(stream);
-  focal_kernel<<<nwg, 256, 0, s>>>(p, gt, dist, alpha, beta, (float*)workspace, dp, g_dev, g_host, (long)n);
+  focal_kernel<<<nwg, 256, 0, s>>>(p, gt, dist, alpha, beta, (float*)workspace, dp, g_dev, g_host, (long)n,
+                                   chain_sigmoid);
   finalize_partials<<<1, 64, 0, s>>>((const float*)workspace, loss, nwg, 1, accumulate);
   NVF_LAUNCH_CHECK();
   return NVF_OK;

@@ -1,0 +1,85 @@
+"""Data parallelism over leaf blocks: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-device (NVFPCC.py:105); this is what the build adds.
+Leaf blocks are independent given the shared decoder and every loss term is a SUM over blocks, so
+
+  * mini-batch phase: position j of the epoch order goes to rank j mod W; after backward ONE
+    all-reduce (SUM) of the flat fp32 gradient buffer (52 219 floats = 209 KB at chanstr 8,16,8,8 --
+    latency-bound on xGMI, far below the per-link bandwidth regime), then every rank applies the same
+    fused Adam update to its replica;
+  * the weight-rate term is identical on every rank, so its gradient is scaled by 1/W before the SUM;
+  * n_pts (points of the global mini-batch) is computed on the host from per-block counts: no collective;
+  * weight noise (q = 1) is keyed by (seed, step, layer) and so identical on all ranks; latent noise is
+    keyed by block id, so results do not depend on W;
+  * latent phase / eval: contiguous block shards, no collective inside the step; one all-gather of the
+    updated latent rows per epoch.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for one process)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_minibatch(order, step, batch, rank, world):
+    """Block ids of mini-batch `step` owned by `rank`: position j of the epoch order -> rank j mod W.
+    Returns (ids of this rank, ids of the whole mini-batch)."""
+    whole = np.asarray(order[step * batch:(step + 1) * batch], np.int64)
+    return whole[rank::world], whole
+
+
+def shard_range(n, rank, world):
+    """Static contiguous shard [lo, hi) of n blocks for the latent / eval / decode phases."""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def allreduce_sum_(flat):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def allgather_rows_(table, rank, world):
+    """Re-synchronise a replicated [N, ...] table after every rank updated its shard_range rows."""
+    if not (dist.is_initialized() and world > 1):
+        return table
+    n = table.shape[0]
+    per = (n + world - 1) // world
+    width = table[0].numel()
+    pad = torch.zeros(per * world, width, device=table.device, dtype=table.dtype)
+    lo, hi = shard_range(n, rank, world)
+    mine = torch.zeros(per, width, device=table.device, dtype=table.dtype)
+    mine[:hi - lo] = table[lo:hi].reshape(hi - lo, width)
+    dist.all_gather_into_tensor(pad, mine) if hasattr(dist, "all_gather_into_tensor") else \
+        dist.all_gather(list(pad.chunk(world)), mine)
+    table.copy_(pad[:n].reshape(table.shape))
+    return table
+
+
+def attach(engine, world):
+    """Wire an engine for data parallelism."""
+    if world > 1:
+        engine.rate_grad_scale = 1.0 / world
+        engine.grad_hook = allreduce_sum_
+    return engine

@@ -1,0 +1,291 @@
+"""Hand-sequenced NVF train / latent / eval steps on the gfx950 kernels.
+
+The reference runs one step as ~1 500 aten ops driven by autograd with ~14 host syncs
+(NVFPCC.py:149-250).  Here a step is a fixed list of C-ABI launches on one HIP stream, with
+
+  * every leaf block's grids and the latent table resident in HBM (no DataLoader process),
+  * all 28 decoder parameter tensors living in ONE flat buffer (and their gradients in another),
+    so Adam is a single fused launch and the data-parallel exchange is a single RCCL all-reduce,
+  * all ten layers' effective weights produced by one table-driven launch,
+  * the ReLU / sigmoid backward, the head gradients' addition and the loss gradient fused into the
+    kernels that produce or consume them,
+  * no host synchronisation inside a step (rate coefficients come from per-block point counts
+    precomputed on the host).
+
+Result-preserving shortcuts taken from the reference's own data flow: the mini-batch phase never
+uses the latent gradients (they are zeroed at NVFPCC.py:226) and the latent phase never uses the
+decoder weight gradients (zeroed at NVFPCC.py:150), so each phase skips the half it discards.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import lib, check
+from .network import NoiseState
+
+R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
+TRUNK = ("up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls")
+HEADS = ("conv1_cls", "conv0_cls")
+
+_DESC = np.dtype([("kernel", "<u8"), ("kernel_init", "<u8"), ("b", "<u8"), ("b_init", "<u8"), ("w_fwd", "<u8"),
+                  ("w_bwd", "<u8"), ("b_eff", "<u8"), ("dim0", "<i4"), ("dim1", "<i4"), ("k3", "<i4"),
+                  ("kind", "<i4"), ("quantised", "<i4"), ("layer_id", "<i4"), ("nbias", "<i4"), ("pad", "<i4")])
+
+
+class _Layer:
+    __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad")
+
+
+class TrainEngine:
+    def __init__(self, net, gt_all, dist_all, n_points_total, lmbda, w1, w2, lr, wemb, emb=None, seed=0):
+        assert lib().nvf_layer_desc_size() == _DESC.itemsize
+        self.net = net
+        self.dev = gt_all.device
+        self.gt, self.dist = gt_all.contiguous(), dist_all.contiguous()
+        self.N_leaf = self.gt.shape[0]
+        self.n_points_total = float(n_points_total)
+        self.lmbda, self.w1, self.w2 = float(lmbda), float(w1), float(w2)
+        self.lr, self.lr_emb = float(lr), float(lr) * float(wemb)
+        self.seed = int(seed)
+        self.noise_step = 0
+        self.rate_grad_scale = 1.0   # 1/world_size under data parallelism: the weight-rate term is replicated
+        self.grad_hook = None        # called on flat_g between backward and Adam (RCCL all-reduce)
+        self.opt_step = 0
+        self.emb_step = 0
+        self.ch = net.entropy_coder.sigma.shape[1]
+        self.channels = net.reconstructor.channels
+        # GT pyramid and per-block occupied-voxel counts, once (MultiscaleProcessor, NVFPCC.py:76-88)
+        self.gt16 = ops.maxpool2(self.gt)
+        self.gt8 = ops.maxpool2(self.gt16)
+        self.counts = self.gt.sum(dim=(1, 2, 3, 4)).double().cpu().numpy()
+        # latent table + its Adam state (NVFPCC.py:120-124)
+        self.emb = (torch.ones(self.N_leaf, self.ch, 2, 2, 2, device=self.dev) if emb is None
+                    else emb.detach().to(self.dev).float().contiguous().clone())
+        self.emb_m = torch.zeros_like(self.emb)
+        self.emb_v = torch.zeros_like(self.emb)
+        self._flatten_parameters()
+        self._build_layers()
+        self.last = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _flatten_parameters(self):
+        named = list(self.net.named_parameters())
+        total = sum(p.numel() for _, p in named)
+        self.flat_p = torch.empty(total, device=self.dev)
+        self.flat_g = torch.zeros(total, device=self.dev)
+        self.flat_m = torch.zeros(total, device=self.dev)
+        self.flat_v = torch.zeros(total, device=self.dev)
+        self.slices = {}
+        off = 0
+        for name, p in named:
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            p.grad = self.flat_g[off:off + n].view(p.shape)
+            self.slices[name] = (off, n)
+            off += n
+
+    def _g(self, name):
+        off, n = self.slices[name]
+        return self.flat_g[off:off + n]
+
+    def _build_layers(self):
+        rec = self.net.reconstructor
+        mods = [("latent", self.net.latent_gen.h_analysis_2, "latent_gen.h_analysis_2")]
+        mods += [(n, getattr(rec, n), "reconstructor." + n) for n in TRUNK + HEADS]
+        self.layers = {}
+        table = np.zeros(len(mods), _DESC)
+        for i, (name, m, prefix) in enumerate(mods):
+            L = _Layer()
+            L.name, L.mod = name, m
+            L.kind = 1 if m.kernel.shape[2] == 5 else 0      # k=5 layers are the transposed convs
+            L.k = m.kernel.shape[2]
+            n = m.kernel.numel()
+            L.w_fwd = torch.empty(n, device=self.dev)
+            L.w_bwd = torch.empty(n, device=self.dev)
+            L.b_eff = torch.empty(m.b.numel(), device=self.dev)
+            L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
+            L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
+            self.layers[name] = L
+            t = table[i]
+            t["kernel"], t["kernel_init"] = m.kernel.data_ptr(), m.kernel_init.data_ptr()
+            t["b"], t["b_init"] = m.b.data_ptr(), m.b_init.data_ptr()
+            t["w_fwd"], t["w_bwd"], t["b_eff"] = L.w_fwd.data_ptr(), L.w_bwd.data_ptr(), L.b_eff.data_ptr()
+            t["dim0"], t["dim1"], t["k3"] = m.kernel.shape[0], m.kernel.shape[1], L.k ** 3
+            t["kind"] = L.kind
+            t["quantised"] = 1 if name in TRUNK else 0
+            t["layer_id"] = m.layer_id
+            t["nbias"] = m.b.numel()
+        self._table_host = table
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.dev)
+        self.nlayers = len(mods)
+
+    def prepare_weights(self, q):
+        check(lib().nvf_prepare_weights(self.table.data_ptr(), self.nlayers, int(q), self.seed, self.noise_step, None,
+                                        torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights")
+
+    # ------------------------------------------------------------------ forward
+    def _convT(self, L, x, act):
+        return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
+
+    def _conv(self, L, x, act):
+        osz = tuple(s + 2 * L.pad - L.k + 1 for s in x.shape[2:])
+        return ops.conv3d_gather(x, L.w_fwd, L.b_eff, L.cout, L.k, 1, L.pad, osz, act)
+
+    def forward(self, e, mode, block_ids):
+        """e [B,ch,2,2,2] latents-before-latent_gen.  Returns the dict of saved activations."""
+        net, Ls = self.net, self.layers
+        a = {"e": e}
+        a["h"] = self._conv(Ls["latent"], e, NONE)
+        g2 = net.latent_gen.gdn_2
+        a["lat"] = ops.gdn_fwd(a["h"], g2.beta, g2.gamma, False)
+        ec = net.entropy_coder
+        a["x0"], a["lbits"], _, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
+                                                       block_ids=block_ids, seed=self.seed, step=self.noise_step)
+        a["a0"] = self._convT(Ls["up0"], a["x0"], NONE)
+        ig = net.reconstructor.activation
+        a["h0"] = ops.gdn_fwd(a["a0"], ig.beta, ig.gamma, True)
+        a["y1"] = self._convT(Ls["conv0"], a["h0"], R)
+        a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
+        a["y2"] = self._convT(Ls["up1"], a["y1"], R)
+        a["y3"] = self._conv(Ls["conv1"], a["y2"], R)
+        a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
+        a["y4"] = self._convT(Ls["up2"], a["y3"], R)
+        a["y5"] = self._conv(Ls["conv2"], a["y4"], R)
+        a["p2"] = self._conv(Ls["conv2_cls"], a["y5"], S)
+        return a
+
+    # ------------------------------------------------------------------ backward
+    def _bwd_conv(self, L, g_out, x_in, mask, want_w, addend=None, need_dx=True):
+        """g_out: gradient w.r.t. the layer's pre-activation output.  Returns d x_in (masked by `mask`)."""
+        if want_w:
+            if L.cout == 1:
+                ops.wgrad(x_in, g_out, L.k, 1, L.k - 1 - L.pad, out_mode=1, out=L.gk)
+            else:
+                ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
+            ops.channel_sum(g_out, out=L.gb)
+        if not need_dx:
+            return None
+        return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
+                                 addend=addend, mask=mask)
+
+    def _bwd_convT(self, L, g_out, x_in, mask, want_w, addend=None, need_dx=True):
+        if want_w:
+            ops.wgrad(x_in, g_out, 5, 2, L.pad, out_mode=0, out=L.gk)
+            ops.channel_sum(g_out, out=L.gb)
+        if not need_dx:
+            return None
+        return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
+                                 mask=mask)
+
+    def backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
+        """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g."""
+        net, Ls = self.net, self.layers
+        loss = torch.zeros(4, device=self.dev)   # [main, head0, head1, unused]
+        _, dl2 = ops.focal_loss(a["p2"], gt, dist, 0.9, 1.0, want_grad=True, loss_out=loss[0:1], chain_sigmoid=True)
+        _, dl0 = ops.focal_loss(a["p0"], gt8, None, 0.85, want_grad=True, loss_out=loss[1:2], chain_sigmoid=True)
+        _, dl1 = ops.focal_loss(a["p1"], gt16, None, 0.85, want_grad=True, loss_out=loss[2:3], chain_sigmoid=True)
+        g5 = self._bwd_conv(Ls["conv2_cls"], dl2, a["y5"], a["y5"], want_w)
+        g4 = self._bwd_conv(Ls["conv2"], g5, a["y4"], a["y4"], want_w)
+        t1 = self._bwd_conv(Ls["conv1_cls"], dl1, a["y3"], None, want_w)
+        g3 = self._bwd_convT(Ls["up2"], g4, a["y3"], a["y3"], want_w, addend=t1)
+        g2 = self._bwd_conv(Ls["conv1"], g3, a["y2"], a["y2"], want_w)
+        t0 = self._bwd_conv(Ls["conv0_cls"], dl0, a["y1"], None, want_w)
+        g1 = self._bwd_convT(Ls["up1"], g2, a["y1"], a["y1"], want_w, addend=t0)
+        dh0 = self._bwd_convT(Ls["conv0"], g1, a["h0"], None, want_w)
+        ig = net.reconstructor.activation
+        da0, dbeta, dgamma = ops.gdn_bwd(a["a0"], ig.beta, ig.gamma, dh0, True)
+        dx0 = self._bwd_convT(Ls["up0"], da0, a["x0"], None, want_w)
+        # latent rate (+ the decoder's gradient through the straight-through round)
+        ec = net.entropy_coder
+        g_lat = self.lmbda * self.w1 / n_pts
+        _, _, dlat, dsig, dmu = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
+                                                block_ids=block_ids, want_grad=True, g_host=g_lat, seed=self.seed,
+                                                step=self.noise_step, dx_addend=dx0)
+        g2m = net.latent_gen.gdn_2
+        dh, dbeta_l, dgamma_l = ops.gdn_bwd(a["h"], g2m.beta, g2m.gamma, dlat, False)
+        de = self._bwd_conv(Ls["latent"], dh, a["e"], None, want_w, need_dx=want_emb)
+        if want_w:
+            self._g("reconstructor.activation.beta").copy_(dbeta)
+            self._g("reconstructor.activation.gamma").copy_(dgamma.reshape(-1))
+            self._g("latent_gen.gdn_2.beta").copy_(dbeta_l)
+            self._g("latent_gen.gdn_2.gamma").copy_(dgamma_l.reshape(-1))
+            self._g("entropy_coder.sigma").copy_(dsig)
+            self._g("entropy_coder.mu").copy_(dmu)
+        # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients
+        lm = net.reconstructor.likelihood_model
+        nbits = torch.empty(7, device=self.dev)
+        g_net = self.lmbda * self.w2 / self.n_points_total
+        gs, gm = self._g("reconstructor.likelihood_model.sigma"), self._g("reconstructor.likelihood_model.mu")
+        if want_w:
+            gs.zero_()
+            gm.zero_()
+        for i, n in enumerate(TRUNK):
+            L = Ls[n]
+            if want_w:   # dk is ADDED to the conv weight gradient wgrad already wrote; dsigma/dmu add up over layers
+                ops.weight_rate(L.mod.kernel, lm.sigma, lm.mu, bits_out=nbits[i:i + 1], dk=L.gk.view(-1), dsigma=gs,
+                                dmu=gm, g_host=g_net * self.rate_grad_scale, accumulate=True)
+            else:
+                ops.weight_rate(L.mod.kernel, lm.sigma, lm.mu, bits_out=nbits[i:i + 1])
+        self.last = {"loss_terms": loss, "latent_bits": a["lbits"], "net_bits": nbits, "n_pts": n_pts}
+        return de
+
+    # ------------------------------------------------------------------ steps
+    def _batch(self, idx_dev):
+        return (ops.gather_rows(self.gt, idx_dev), ops.gather_rows(self.dist, idx_dev),
+                ops.gather_rows(self.gt16, idx_dev), ops.gather_rows(self.gt8, idx_dev))
+
+    def train_step(self, idx_host, q, idx_dev=None, update=True, n_pts=None):
+        """One mini-batch decoder update (NVFPCC.py:149-223, minus logging).  Under data parallelism
+        ``idx_host`` is this rank's share of the global mini-batch and ``n_pts`` the occupied-voxel count
+        of the WHOLE mini-batch (host-known: every rank derives the same epoch order)."""
+        idx_host = np.asarray(idx_host, np.int64)
+        if idx_dev is None:
+            idx_dev = torch.from_numpy(idx_host).to(self.dev)
+        if q == 1:
+            self.noise_step += 1
+        if n_pts is None:
+            n_pts = float(self.counts[idx_host].sum())
+        gt, dist, gt16, gt8 = self._batch(idx_dev)
+        self.prepare_weights(q)
+        e = ops.gather_rows(self.emb, idx_dev)
+        a = self.forward(e, "train", idx_dev)
+        self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False)
+        if self.grad_hook is not None:
+            self.grad_hook(self.flat_g)
+        if update:
+            self.opt_step += 1
+            ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.opt_step)
+        return a
+
+    def latent_step(self, q, lo=0, hi=None, update=True):
+        """Full-batch latent update over blocks [lo, hi) (NVFPCC.py:225-251); no weight gradients."""
+        hi = self.N_leaf if hi is None else hi
+        if q == 1:
+            self.noise_step += 1
+        ids = torch.arange(lo, hi, device=self.dev)
+        n_pts = float(self.counts.sum())          # the reference divides by the points of ALL blocks
+        self.prepare_weights(q)
+        e = self.emb[lo:hi]
+        a = self.forward(e, "train", ids)
+        de = self.backward(a, self.gt[lo:hi], self.dist[lo:hi], self.gt16[lo:hi], self.gt8[lo:hi], n_pts, "train",
+                           ids, want_w=False, want_emb=True)
+        if update:
+            self.emb_step += 1
+            ops.adam_step(self.emb[lo:hi].view(-1), de.view(-1), self.emb_m[lo:hi].view(-1),
+                          self.emb_v[lo:hi].view(-1), self.lr_emb, self.emb_step)
+        return a, de
+
+    def eval_forward(self, lo=0, hi=None, q=2):
+        hi = self.N_leaf if hi is None else hi
+        ids = torch.arange(lo, hi, device=self.dev)
+        self.prepare_weights(q)
+        return self.forward(self.emb[lo:hi], "eval", ids)
+
+    def loss_value(self):
+        """Host scalar of the last step's objective (one sync; logging only)."""
+        t = self.last
+        terms = t["loss_terms"].cpu().numpy()
+        b_latent = t["latent_bits"].item() / t["n_pts"]
+        b_net = t["net_bits"].sum().item() / self.n_points_total
+        return float(terms[0] + terms[1] + terms[2] + self.lmbda * (b_latent * self.w1 + b_net * self.w2))

@@ -200,14 +200,14 @@ def weight_rate(kernel, sigma, mu, bits_out=None, dk=None, dsigma=None, dmu=None
 
 # ---------------------------------------------------------------- losses / metrics
 def focal_loss(p, gt, dist, alpha, beta=0.0, want_grad=False, g_dev=None, g_host=1.0, loss_out=None,
-               accumulate=False):
+               accumulate=False, chain_sigmoid=False, dp_out=None):
     _f32(p, gt, dist, g_dev, loss_out)
     loss = loss_out if loss_out is not None else torch.empty(1, device=p.device)
-    dp = torch.empty_like(p) if want_grad else None
+    dp = dp_out if dp_out is not None else (torch.empty_like(p) if want_grad else None)
     ws = workspace(lib().nvf_reduce_workspace(), p.device, "reduce")
     check(lib().nvf_focal_loss(_ptr(p), _ptr(gt), _ptr(dist), float(alpha), float(beta), _ptr(loss), _ptr(dp),
                                _ptr(g_dev), float(g_host), _ptr(ws), ws.numel(), p.numel(), int(accumulate),
-                               _stream()), "nvf_focal_loss")
+                               int(chain_sigmoid), _stream()), "nvf_focal_loss")
     return loss, dp
 
 
