@@ -176,6 +176,7 @@ def main():
 
     extra = {}
     if args.sweep and rank == 0 and world == 1:
+        order = np.concatenate([rng.permutation(args.blocks) for _ in range(13 * 256 // args.blocks + 2)])
         for b2 in (256,):
             for i in range(3):
                 eng.train_step(order[i * b2:(i + 1) * b2], args.q)

@@ -71,17 +71,19 @@ int nvf_prepare_weights(const void* table_dev, int nlayers, int q, uint64_t seed
  *             (+ addend[b,co,o]) (* (mask[b,co,o] > 0))
  * w is a packed w_fwd (forward) or w_bwd (backward-data; then cin/cout are swapped
  * by the caller and pad = K-1-p for conv, pad = p with stride 2 for convT).
- * bias, addend, mask may be NULL.  Replaces F.conv3d at network.py:687,741 and the
+ * bias, addend, mask may be NULL.  variant: 0 = tuned LDS-tiled kernel (falls back to 1 for shapes without a
+ * tiled instantiation), 1 = one-thread-per-output kernel (same fmaf order: bit-identical), >= 2 = tuning alternates.
+ * Replaces F.conv3d at network.py:687,741 and the
  * autograd backward of network.py:621,687. */
 int nvf_conv3d_gather(const float* x, const float* w, const float* bias, float* y, const float* addend,
                       const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din,
-                      int hin, int win, int dout, int hout, int wout, int act, int naive, void* stream);
+                      int hin, int win, int dout, int hout, int wout, int act, int variant, void* stream);
 
 /* ---- transposed convolution k5 s2 forward (F.conv_transpose3d, network.py:621) ---
  * y[b,co,o] = act(bias[co] + sum_{ci,k : o+pad-k = 2i} x[b,ci,i] * w[ci][k][co]),
  * dout = 2*din + 3 (pad 0) or 2*din (pad 2, output_padding 1).  w is w_fwd. */
 int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int cin, int cout,
-                         int pad, int din, int hin, int win, int dout, int hout, int wout, int act, int naive,
+                         int pad, int din, int hin, int win, int dout, int hout, int wout, int act, int variant,
                          void* stream);
 
 /* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
@@ -96,7 +98,7 @@ int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, floa
 size_t nvf_wgrad_workspace(int batch, int a, int b, int k, int dp, int hp, int wp);
 int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch, int a,
               int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq, int out_mode,
-              int accumulate, int naive, void* stream);
+              int accumulate, int variant, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */

@@ -105,20 +105,29 @@ __global__ void conv_gather_naive(const float* __restrict__ x, const float* __re
 // ---------------------------------------------------------------------------
 // gather convolution, LDS-tiled, register-tiled, scalar-register weights
 // ---------------------------------------------------------------------------
-template <int CIN_, int COUT_, int KS_, int S_, int VX_, int NCX_, int TY_, int TZ_, int CC_>
+template <int CIN_, int COUT_, int KS_, int S_, int VX_, int NCX_, int TY_, int TZ_, int CC_, int KYU_ = 0, int COG_ = 0>
 struct GCfg {
   static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, S = S_, VX = VX_, NCX = NCX_, TY = TY_, TZ = TZ_, CC = CC_;
+  // output channels per workgroup: small layers split Cout over workgroups (grid.x carries the group) to get
+  // enough threads in flight; the input tile is then staged once per group (L2 hits)
+  static constexpr int COG = COG_ > 0 ? COG_ : COUT_;
+  static constexpr int NCOG = COUT_ / COG;
+  static constexpr int LV = (VX_ * S_) % 4 == 0 ? 4 : ((VX_ * S_) % 2 == 0 ? 2 : 1);  // LDS read width (floats)
+  // ky-loop unroll: the weights of one (c,kz,ky) step are KS*COUT scalar registers; unrolling ky multiplies
+  // that, and past ~100 SGPRs the compiler spills them to VGPR lanes (v_readlane per FMA operand).
+  static constexpr int KYU = KYU_ > 0 ? KYU_ : (KS * COG <= 32 ? KS : 1);
   static constexpr int TX = NCX * VX;
   static constexpr int NIN = (VX - 1) * S + KS;   // inputs one thread reads per (c,kz,ky)
-  static constexpr int NIN4 = (NIN + 3) / 4 * 4;  // rounded to whole ds_read_b128
+  static constexpr int NIN4 = (NIN + LV - 1) / LV * LV;  // rounded to whole LDS reads
   static constexpr int IX = (TX - 1) * S + KS;    // staged tile extents
   static constexpr int IY = (TY - 1) * S + KS;
   static constexpr int IZ = (TZ - 1) * S + KS;
   static constexpr int RS = (NCX - 1) * VX * S + NIN4;  // LDS row stride (>= IX, 16-B aligned reads)
   static constexpr int NACT = NCX * TY * TZ;
-  static constexpr int NT = (NACT + 63) / 64 * 64;
   static constexpr int LDSF = CC * IZ * IY * RS;
-  static_assert((VX * S) % 4 == 0, "thread row start must be 16-byte aligned");
+  // threads beyond NACT only help staging the tile (keeps enough global loads in flight for small tiles)
+  static constexpr int NT = ((NACT + 63) / 64 * 64 < 256 && LDSF >= 2048) ? 256 : (NACT + 63) / 64 * 64;
+  static_assert(COUT_ % COG == 0, "channel groups");
   static_assert(RS >= IX, "row stride");
   static_assert(CIN % CC == 0, "channel chunk");
   static_assert(LDSF * 4 <= 160 * 1024, "LDS");
@@ -131,18 +140,20 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
                                                            const float* __restrict__ mask, ConvDims d) {
   constexpr int CIN = C::CIN, COUT = C::COUT, KS = C::KS, S = C::S, VX = C::VX, NCX = C::NCX, TY = C::TY, TZ = C::TZ,
                 CC = C::CC;
-  constexpr int RS = C::RS, IY = C::IY, IZ = C::IZ, IX = C::IX, NT = C::NT, NIN4 = C::NIN4;
+  constexpr int RS = C::RS, IY = C::IY, IZ = C::IZ, IX = C::IX, NT = C::NT, NIN4 = C::NIN4, COG = C::COG, LV = C::LV;
   __shared__ __attribute__((aligned(16))) float lds[C::LDSF];
   const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
-  const int tile = blockIdx.x % ntile, b = blockIdx.x / ntile;
+  const int co0 = (blockIdx.x % C::NCOG) * COG;            // wave-uniform
+  const int wg = blockIdx.x / C::NCOG;
+  const int tile = wg % ntile, b = wg / ntile;
   const int tx_i = tile % d.tiles_x, ty_i = (tile / d.tiles_x) % d.tiles_y, tz_i = tile / (d.tiles_x * d.tiles_y);
   const int ox0 = tx_i * C::TX, oy0 = ty_i * TY, oz0 = tz_i * TZ;
   const int tid = threadIdx.x;
   const int cx = tid % NCX, ty = (tid / NCX) % TY, tz = tid / (NCX * TY);
   const bool active = tid < C::NACT;
-  float acc[COUT][VX];
+  float acc[COG][VX];
 #pragma unroll
-  for (int i = 0; i < COUT; ++i)
+  for (int i = 0; i < COG; ++i)
 #pragma unroll
     for (int j = 0; j < VX; ++j) acc[i][j] = 0.f;
   const float* xb = x + (size_t)b * CIN * d.din * d.hin * d.win;
@@ -151,43 +162,31 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
 #pragma unroll 1
   for (int c0 = 0; c0 < CIN; c0 += CC) {
     if (c0) __syncthreads();
-    for (int e = tid; e < C::LDSF; e += NT) {
-      int xx = e % RS;
-      int r = e / RS;
-      int yy = r % IY;
-      r /= IY;
-      int zz = r % IZ;
-      int c = r / IZ;
-      int gx = gx0 + xx, gy = gy0 + yy, gz = gz0 + zz;
-      float v = 0.f;
-      if (xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din)
-        v = xb[((size_t)(c0 + c) * d.din + gz) * plane + gy * d.win + gx];
-      lds[e] = v;
-    }
+    nvf_stage_rows<NT, CC * IZ * IY, RS, RS, 8>(
+        xb, lds, tid,
+        [&](int r, int xx, bool& ok) -> size_t {
+          const int yy = r % IY, t = r / IY, zz = t % IZ, c = t / IZ;
+          const int gx = gx0 + xx, gy = gy0 + yy, gz = gz0 + zz;
+          ok = xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din;
+          return ((size_t)(c0 + c) * d.din + gz) * plane + (size_t)gy * d.win + gx;
+        },
+        [&](int r, int xx) { return r * RS + xx; });
     __syncthreads();
     if (active) {
 #pragma unroll 1
       for (int c = 0; c < CC; ++c) {
 #pragma unroll 1
         for (int kz = 0; kz < KS; ++kz) {
-#pragma unroll
+#pragma unroll C::KYU
           for (int ky = 0; ky < KS; ++ky) {
-            const float4* row =
-                (const float4*)(lds + ((c * IZ + tz * S + kz) * IY + ty * S + ky) * RS + cx * VX * S);
+            const float* rowp = lds + ((c * IZ + tz * S + kz) * IY + ty * S + ky) * RS + cx * VX * S;
             float in[NIN4];
-#pragma unroll
-            for (int i = 0; i < NIN4 / 4; ++i) {
-              float4 t = row[i];
-              in[4 * i] = t.x;
-              in[4 * i + 1] = t.y;
-              in[4 * i + 2] = t.z;
-              in[4 * i + 3] = t.w;
-            }
-            const float* wr = w + (size_t)((((c0 + c) * KS + kz) * KS + ky) * KS) * COUT;  // wave-uniform
+            nvf_lds_row<NIN4, LV>(rowp, in);
+            const float* wr = w + (size_t)((((c0 + c) * KS + kz) * KS + ky) * KS) * COUT + co0;  // wave-uniform
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-              for (int co = 0; co < COUT; ++co) {
+              for (int co = 0; co < COG; ++co) {
                 const float wv = wr[kx * COUT + co];
 #pragma unroll
                 for (int v = 0; v < VX; ++v) acc[co][v] = fmaf(in[v * S + kx], wv, acc[co][v]);
@@ -201,9 +200,9 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
   const int oz = oz0 + tz, oy = oy0 + ty;
   if (oz >= d.dout || oy >= d.hout) return;
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) {
-    const float bv = bias ? bias[co] : 0.f;
-    const size_t base = (((size_t)b * COUT + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
+  for (int co = 0; co < COG; ++co) {
+    const float bv = bias ? bias[co0 + co] : 0.f;
+    const size_t base = (((size_t)b * COUT + co0 + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
 #pragma unroll
     for (int v = 0; v < VX; ++v) {
       const int ox = ox0 + cx * VX + v;
@@ -223,46 +222,88 @@ static int launch_gather(const float* x, const float* w, const float* bias, floa
   d.tiles_x = (d.wout + C::TX - 1) / C::TX;
   d.tiles_y = (d.hout + C::TY - 1) / C::TY;
   d.tiles_z = (d.dout + C::TZ - 1) / C::TZ;
-  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch);
+  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch * C::NCOG);
   conv_gather_tiled<C><<<grid, C::NT, 0, s>>>(x, w, bias, y, addend, mask, d);
   return NVF_OK;
 }
 
 extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bias, float* y, const float* addend,
                                  const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din,
-                                 int hin, int win, int dout, int hout, int wout, int act, int naive, void* stream) {
+                                 int hin, int win, int dout, int hout, int wout, int act, int variant, void* stream) {
   if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0 || k <= 0 || stride <= 0) return NVF_EINVAL;
   if (din <= 0 || hin <= 0 || win <= 0 || dout <= 0 || hout <= 0 || wout <= 0) return NVF_EINVAL;
   ConvDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0};
   hipStream_t s = nvf_stream(stream);
   int rc = 1;  // 1 = not dispatched yet
-  if (!naive) {
-#define NVF_G(CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC)                                           \
-  if (rc == 1 && cin == CI && cout == CO && k == KS && stride == ST && wout >= WLO && wout <= WHI)     \
-    rc = launch_gather<GCfg<CI, CO, KS, ST, VX, NCX, TY, TZ, CC>>(x, w, bias, y, addend, mask, batch, d, s);
-    // narrow decoder (chanstr 8,16,8,8)
-    NVF_G(8, 8, 4, 1, 33, 40, 8, 5, 12, 4, 2)   // conv2 backward-data (35^3)
-    NVF_G(8, 8, 4, 1, 21, 32, 8, 4, 16, 4, 2)   // conv2 forward (32^3)
-    NVF_G(8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2)   // conv1 backward-data (19^3)
-    NVF_G(8, 8, 4, 1, 9, 16, 4, 4, 16, 4, 2)    // conv1 forward (16^3)
-    NVF_G(8, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4)   // conv2_cls forward (32^3)
-    NVF_G(8, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4)    // conv1_cls forward (16^3)
-    NVF_G(1, 8, 3, 1, 17, 32, 8, 4, 16, 4, 1)   // conv2_cls backward-data
-    NVF_G(1, 8, 3, 1, 9, 16, 4, 4, 16, 4, 1)    // conv1_cls backward-data
-    NVF_G(8, 8, 5, 2, 9, 16, 4, 4, 16, 4, 1)    // up2 backward-data (35^3 -> 16^3)
-    NVF_G(8, 16, 5, 2, 5, 8, 4, 2, 8, 8, 2)     // up1 backward-data (19^3 -> 8^3)
-    // wide decoder (chanstr 16,32,16,16)
-    NVF_G(16, 16, 4, 1, 33, 36, 4, 9, 7, 4, 2)  // conv2 backward-data
-    NVF_G(16, 16, 4, 1, 21, 32, 4, 8, 8, 4, 2)  // conv2 forward
-    NVF_G(16, 16, 4, 1, 17, 20, 4, 5, 10, 5, 2) // conv1 backward-data
-    NVF_G(16, 16, 4, 1, 9, 16, 4, 4, 16, 4, 2)  // conv1 forward
-    NVF_G(16, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4)  // conv2_cls forward
-    NVF_G(16, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4)   // conv1_cls forward
-    NVF_G(1, 16, 3, 1, 17, 32, 4, 8, 8, 4, 1)   // conv2_cls backward-data
-    NVF_G(1, 16, 3, 1, 9, 16, 4, 4, 16, 4, 1)   // conv1_cls backward-data
-    NVF_G(16, 16, 5, 2, 9, 16, 4, 4, 16, 4, 1)  // up2 backward-data
-    NVF_G(16, 32, 5, 2, 5, 8, 2, 4, 8, 8, 2)    // up1 backward-data
+  // variant 0: the tuned configuration; 1: one-thread-per-output kernel; >= 2: alternatives kept for tuning runs.
+  // Small batches cannot fill 256 CUs with whole-Cout tiles, so they take the Cout-split (COG) instantiations.
+  if (variant == 0 && batch <= 64) {
+    if (cin == 8 && cout == 8 && k == 5 && stride == 2 && wout >= 9 && wout <= 16) variant = 5;   // up2 backward-data
+    if (cin == 8 && cout == 16 && k == 5 && stride == 2 && wout >= 5 && wout <= 8) variant = 5;   // up1 backward-data
+  }
+  if (variant != 1) {
+#define NVF_GC(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU, COG)                                        \
+  if (rc == 1 && variant == VAR && cin == CI && cout == CO && k == KS && stride == ST && wout >= WLO && wout <= WHI) \
+    rc = launch_gather<GCfg<CI, CO, KS, ST, VX, NCX, TY, TZ, CC, KYU, COG>>(x, w, bias, y, addend, mask, batch, d, s);
+#define NVF_G(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU) \
+  NVF_GC(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU, 0)
+    // ---- narrow decoder (chanstr 8,16,8,8)
+    NVF_G(0, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0)    // conv2 backward-data (35^3)
+    NVF_G(0, 8, 8, 4, 1, 21, 32, 4, 8, 8, 8, 2, 0)    // conv2 forward (32^3)
+    NVF_G(0, 8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0)   // conv1 backward-data (19^3)
+    NVF_G(0, 8, 8, 4, 1, 9, 16, 4, 4, 16, 4, 2, 0)    // conv1 forward (16^3)
+    NVF_G(0, 8, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4, 0)   // conv2_cls forward (32^3)
+    NVF_G(0, 8, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4, 0)    // conv1_cls forward (16^3)
+    NVF_G(0, 16, 1, 3, 1, 5, 8, 4, 2, 8, 8, 4, 0)     // conv0_cls forward (8^3)
+    NVF_G(0, 1, 8, 3, 1, 17, 32, 8, 4, 16, 4, 1, 0)   // conv2_cls backward-data
+    NVF_G(0, 1, 8, 3, 1, 9, 16, 4, 4, 16, 4, 1, 0)    // conv1_cls backward-data
+    NVF_G(0, 1, 16, 3, 1, 5, 8, 4, 2, 8, 8, 1, 0)     // conv0_cls backward-data
+    NVF_G(0, 8, 8, 5, 2, 9, 16, 4, 4, 16, 4, 1, 0)    // up2 backward-data (35^3 -> 16^3)
+    NVF_G(0, 8, 16, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0)     // up1 backward-data (19^3 -> 8^3)
+    NVF_GC(0, 16, 8, 5, 2, 3, 4, 2, 2, 4, 4, 4, 0, 2) // conv0 backward-data (8^3 -> 4^3), Cout split 4 ways
+    NVF_GC(0, 8, 3, 5, 2, 2, 2, 2, 1, 2, 2, 8, 0, 1)  // up0 backward-data (4^3 -> 2^3), ch = 3
+    NVF_GC(0, 8, 8, 5, 2, 2, 2, 2, 1, 2, 2, 8, 0, 1)  // up0 backward-data, ch = 8 (narrow c0 with wide latent)
+    // tuning alternatives
+    NVF_G(2, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0)
+    NVF_G(3, 8, 8, 4, 1, 21, 32, 8, 4, 8, 8, 2, 0)
+    NVF_G(4, 8, 8, 4, 1, 21, 32, 4, 8, 8, 8, 2, 0)
+    NVF_G(5, 8, 8, 4, 1, 21, 32, 8, 4, 16, 8, 1, 0)
+    NVF_G(6, 8, 8, 4, 1, 21, 32, 8, 4, 16, 4, 2, 2)
+    NVF_G(7, 8, 8, 4, 1, 21, 32, 8, 4, 16, 4, 2, 1)
+    NVF_G(8, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 2)
+    NVF_G(2, 8, 8, 4, 1, 33, 40, 4, 10, 6, 4, 2, 0)
+    NVF_G(3, 8, 8, 4, 1, 33, 40, 8, 5, 12, 4, 2, 2)
+    NVF_G(4, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0)
+    NVF_G(5, 8, 8, 4, 1, 33, 40, 4, 9, 7, 8, 2, 0)
+    NVF_G(2, 8, 8, 5, 2, 9, 16, 4, 4, 16, 4, 1, 5)
+    NVF_G(3, 8, 8, 5, 2, 9, 16, 4, 4, 8, 4, 2, 0)
+    NVF_G(4, 8, 8, 5, 2, 9, 16, 2, 8, 8, 4, 2, 0)
+    NVF_G(2, 8, 16, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0)
+    NVF_G(3, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 4, 0)
+    NVF_G(4, 8, 16, 5, 2, 5, 8, 4, 2, 8, 4, 4, 0)
+    NVF_GC(5, 8, 16, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0, 4)
+    NVF_GC(6, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 4, 0, 4)
+    NVF_GC(5, 8, 8, 5, 2, 9, 16, 2, 8, 8, 4, 2, 0, 4)
+    NVF_GC(6, 8, 8, 5, 2, 9, 16, 4, 4, 8, 4, 2, 0, 4)
+    NVF_GC(5, 16, 8, 5, 2, 3, 4, 2, 2, 4, 4, 4, 0, 1)
+    NVF_GC(6, 16, 8, 5, 2, 3, 4, 2, 2, 4, 4, 8, 0, 4)
+    // ---- wide decoder (chanstr 16,32,16,16)
+    NVF_G(0, 16, 16, 4, 1, 33, 36, 4, 9, 7, 4, 2, 0)  // conv2 backward-data
+    NVF_G(0, 16, 16, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0)  // conv2 forward
+    NVF_G(0, 16, 16, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0) // conv1 backward-data
+    NVF_G(0, 16, 16, 4, 1, 9, 16, 4, 4, 16, 4, 2, 0)  // conv1 forward
+    NVF_G(0, 16, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4, 0)  // conv2_cls forward
+    NVF_G(0, 16, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4, 0)   // conv1_cls forward
+    NVF_G(0, 32, 1, 3, 1, 5, 8, 4, 2, 8, 8, 4, 0)     // conv0_cls forward
+    NVF_G(0, 1, 16, 3, 1, 17, 32, 4, 8, 8, 4, 1, 0)   // conv2_cls backward-data
+    NVF_G(0, 1, 16, 3, 1, 9, 16, 4, 4, 16, 4, 1, 0)   // conv1_cls backward-data
+    NVF_G(0, 1, 32, 3, 1, 5, 8, 4, 2, 8, 8, 1, 0)     // conv0_cls backward-data
+    NVF_G(0, 16, 16, 5, 2, 9, 16, 4, 4, 16, 4, 1, 0)  // up2 backward-data
+    NVF_G(0, 16, 32, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0)    // up1 backward-data
+    NVF_GC(0, 32, 16, 5, 2, 3, 4, 2, 2, 4, 4, 4, 0, 2) // conv0 backward-data
+    NVF_GC(0, 16, 8, 5, 2, 2, 2, 2, 1, 2, 2, 8, 0, 1) // up0 backward-data (ch = 8)
 #undef NVF_G
+#undef NVF_GC
   }
   if (rc == 1) {
     long total = (long)batch * cout * dout * hout * wout;
@@ -316,18 +357,21 @@ __global__ void convT_k5s2_naive(const float* __restrict__ x, const float* __res
 // parity: taps k = 0,2,4) or j = 0..1 (odd parity: taps 1,3): 125 taps per cell, none
 // multiplied by an inserted zero.  A thread owns VX consecutive cells along x, both x
 // parities and all Cout channels, and walks the four (z,y) parity classes in turn.
-template <int CIN_, int COUT_, int VX_, int NCX_, int TY_, int TZ_>
+template <int CIN_, int COUT_, int VX_, int NCX_, int TY_, int TZ_, int COG_ = 0>
 struct TCfg {
   static constexpr int CIN = CIN_, COUT = COUT_, VX = VX_, NCX = NCX_, TY = TY_, TZ = TZ_;
+  static constexpr int COG = COG_ > 0 ? COG_ : COUT_;
+  static constexpr int NCOG = COUT_ / COG;
+  static constexpr int LV = VX_ % 4 == 0 ? 4 : (VX_ % 2 == 0 ? 2 : 1);
   static constexpr int TX = NCX * VX;
   static constexpr int NIN = VX + 2;
-  static constexpr int NIN4 = (NIN + 3) / 4 * 4;
+  static constexpr int NIN4 = (NIN + LV - 1) / LV * LV;
   static constexpr int IX = TX + 2, IY = TY + 2, IZ = TZ + 2;
   static constexpr int RS = (NCX - 1) * VX + NIN4;
   static constexpr int NACT = NCX * TY * TZ;
-  static constexpr int NT = (NACT + 63) / 64 * 64;
   static constexpr int LDSF = CIN * IZ * IY * RS;
-  static_assert(VX % 4 == 0, "alignment");
+  static constexpr int NT = ((NACT + 63) / 64 * 64 < 256 && LDSF >= 2048) ? 256 : (NACT + 63) / 64 * 64;
+  static_assert(COUT_ % COG == 0, "channel groups");
   static_assert(RS >= IX, "row stride");
   static_assert(LDSF * 4 <= 160 * 1024, "LDS");
 };
@@ -335,13 +379,14 @@ struct TCfg {
 template <class C, int EZ, int EY>
 __device__ __forceinline__ void convT_class(const float* lds, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ y, const ConvDims& d,
-                                            int b, int cx, int ty, int tz, int mx0, int my, int mz) {
-  constexpr int CIN = C::CIN, COUT = C::COUT, VX = C::VX, RS = C::RS, IY = C::IY, IZ = C::IZ, NIN4 = C::NIN4;
-  float acc[2][COUT][VX];
+                                            int b, int co0, int cx, int ty, int tz, int mx0, int my, int mz) {
+  constexpr int CIN = C::CIN, COUT = C::COUT, COG = C::COG, VX = C::VX, RS = C::RS, IY = C::IY, IZ = C::IZ,
+                NIN4 = C::NIN4;
+  float acc[2][COG][VX];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int i = 0; i < COUT; ++i)
+    for (int i = 0; i < COG; ++i)
 #pragma unroll
       for (int j = 0; j < VX; ++j) acc[e][i][j] = 0.f;
 #pragma unroll 1
@@ -350,24 +395,16 @@ __device__ __forceinline__ void convT_class(const float* lds, const float* __res
     for (int jz = 0; jz < 3 - EZ; ++jz) {
 #pragma unroll
       for (int jy = 0; jy < 3 - EY; ++jy) {
-        const float4* row = (const float4*)(lds + ((c * IZ + tz + 2 - jz) * IY + ty + 2 - jy) * RS + cx * VX);
         float in[NIN4];
-#pragma unroll
-        for (int i = 0; i < NIN4 / 4; ++i) {
-          float4 t = row[i];
-          in[4 * i] = t.x;
-          in[4 * i + 1] = t.y;
-          in[4 * i + 2] = t.z;
-          in[4 * i + 3] = t.w;
-        }
+        nvf_lds_row<NIN4, C::LV>(lds + ((c * IZ + tz + 2 - jz) * IY + ty + 2 - jy) * RS + cx * VX, in);
         const int kz = EZ + 2 * jz, ky = EY + 2 * jy;
-        const float* wr = w + (size_t)((c * 5 + kz) * 5 + ky) * 5 * COUT;  // wave-uniform
+        const float* wr = w + (size_t)((c * 5 + kz) * 5 + ky) * 5 * COUT + co0;  // wave-uniform
 #pragma unroll
         for (int ex = 0; ex < 2; ++ex)
 #pragma unroll
           for (int jx = 0; jx < 3 - ex; ++jx)
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) {
+            for (int co = 0; co < COG; ++co) {
               const float wv = wr[(ex + 2 * jx) * COUT + co];
 #pragma unroll
               for (int v = 0; v < VX; ++v) acc[ex][co][v] = fmaf(in[v + 2 - jx], wv, acc[ex][co][v]);
@@ -378,9 +415,9 @@ __device__ __forceinline__ void convT_class(const float* lds, const float* __res
   const int oz = 2 * mz + EZ - d.pad, oy = 2 * my + EY - d.pad;
   if (oz < 0 || oz >= d.dout || oy < 0 || oy >= d.hout) return;
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) {
-    const float bv = bias ? bias[co] : 0.f;
-    const size_t base = (((size_t)b * COUT + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
+  for (int co = 0; co < COG; ++co) {
+    const float bv = bias ? bias[co0 + co] : 0.f;
+    const size_t base = (((size_t)b * COUT + co0 + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
 #pragma unroll
     for (int v = 0; v < VX; ++v)
 #pragma unroll
@@ -399,34 +436,32 @@ __global__ __launch_bounds__(C::NT) void convT_k5s2_tiled(const float* __restric
                 IX = C::IX, NT = C::NT;
   __shared__ __attribute__((aligned(16))) float lds[C::LDSF];
   const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
-  const int tile = blockIdx.x % ntile, b = blockIdx.x / ntile;
+  const int co0 = (blockIdx.x % C::NCOG) * C::COG;
+  const int wg = blockIdx.x / C::NCOG;
+  const int tile = wg % ntile, b = wg / ntile;
   const int tx_i = tile % d.tiles_x, ty_i = (tile / d.tiles_x) % d.tiles_y, tz_i = tile / (d.tiles_x * d.tiles_y);
   const int mlo = d.pad >> 1;
   const int cx0 = mlo + tx_i * C::TX, cy0 = mlo + ty_i * TY, cz0 = mlo + tz_i * TZ;  // first cell of the tile
   const int tid = threadIdx.x;
   const float* xb = x + (size_t)b * CIN * d.din * d.hin * d.win;
   const int plane = d.hin * d.win;
-  for (int e = tid; e < C::LDSF; e += NT) {
-    int xx = e % RS;
-    int r = e / RS;
-    int yy = r % IY;
-    r /= IY;
-    int zz = r % IZ;
-    int c = r / IZ;
-    int gx = cx0 - 2 + xx, gy = cy0 - 2 + yy, gz = cz0 - 2 + zz;
-    float v = 0.f;
-    if (xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din)
-      v = xb[((size_t)c * d.din + gz) * plane + gy * d.win + gx];
-    lds[e] = v;
-  }
+  nvf_stage_rows<NT, CIN * IZ * IY, RS, RS, 8>(
+      xb, lds, tid,
+      [&](int r, int xx, bool& ok) -> size_t {
+        const int yy = r % IY, t = r / IY, zz = t % IZ, c = t / IZ;
+        const int gx = cx0 - 2 + xx, gy = cy0 - 2 + yy, gz = cz0 - 2 + zz;
+        ok = xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din;
+        return ((size_t)c * d.din + gz) * plane + (size_t)gy * d.win + gx;
+      },
+      [&](int r, int xx) { return r * RS + xx; });
   __syncthreads();
   if (tid >= C::NACT) return;
   const int cx = tid % NCX, ty = (tid / NCX) % TY, tz = tid / (NCX * TY);
   const int mx0 = cx0 + cx * VX, my = cy0 + ty, mz = cz0 + tz;
-  convT_class<C, 0, 0>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
-  convT_class<C, 0, 1>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
-  convT_class<C, 1, 0>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
-  convT_class<C, 1, 1>(lds, w, bias, y, d, b, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 0, 0>(lds, w, bias, y, d, b, co0, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 0, 1>(lds, w, bias, y, d, b, co0, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 1, 0>(lds, w, bias, y, d, b, co0, cx, ty, tz, mx0, my, mz);
+  convT_class<C, 1, 1>(lds, w, bias, y, d, b, co0, cx, ty, tz, mx0, my, mz);
 }
 
 template <class C>
@@ -440,14 +475,14 @@ static int launch_convT(const float* x, const float* w, const float* bias, float
   d.tiles_x = (ncx + C::TX - 1) / C::TX;
   d.tiles_y = (ncy + C::TY - 1) / C::TY;
   d.tiles_z = (ncz + C::TZ - 1) / C::TZ;
-  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch);
+  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch * C::NCOG);
   convT_k5s2_tiled<C><<<grid, C::NT, 0, s>>>(x, w, bias, y, d);
   return NVF_OK;
 }
 
 extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, float* y, int batch, int cin,
                                     int cout, int pad, int din, int hin, int win, int dout, int hout, int wout,
-                                    int act, int naive, void* stream) {
+                                    int act, int variant, void* stream) {
   if (!x || !w || !y || batch <= 0 || cin <= 0 || cout <= 0) return NVF_EINVAL;
   if (pad != 0 && pad != 2) return NVF_EINVAL;
   const int extra = pad == 0 ? 3 : 0;  // (in-1)*2 - 2*pad + 5 + output_padding
@@ -455,13 +490,28 @@ extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float*
   ConvDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0};
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
-  if (!naive) {
-#define NVF_T(CI, CO, WIN, VX, NCX, TY, TZ) \
-  if (rc == 1 && cin == CI && cout == CO && win == WIN) rc = launch_convT<TCfg<CI, CO, VX, NCX, TY, TZ>>(x, w, bias, y, batch, d, s);
-    NVF_T(8, 8, 16, 4, 5, 6, 6)     // up2 narrow: 16^3 -> 35^3 (18 cells / axis)
-    NVF_T(16, 8, 8, 4, 3, 5, 5)     // up1 narrow: 8^3 -> 19^3 (10 cells / axis)
-    NVF_T(16, 16, 16, 4, 5, 6, 6)   // up2 wide
-    NVF_T(32, 16, 8, 4, 3, 5, 5)    // up1 wide
+  if (variant == 0 && batch <= 64 && cin == 16 && cout == 8 && win == 8) variant = 6;   // up1 forward, small batch
+  if (variant != 1) {
+#define NVF_T(VAR, CI, CO, WIN, VX, NCX, TY, TZ, COG)                      \
+  if (rc == 1 && variant == VAR && cin == CI && cout == CO && win == WIN) \
+    rc = launch_convT<TCfg<CI, CO, VX, NCX, TY, TZ, COG>>(x, w, bias, y, batch, d, s);
+    NVF_T(0, 8, 8, 16, 2, 9, 6, 3, 4)     // up2 narrow: 16^3 -> 35^3 (18 cells / axis), Cout split 2 ways
+    NVF_T(0, 16, 8, 8, 2, 5, 5, 5, 0)     // up1 narrow: 8^3 -> 19^3 (10 cells / axis)
+    NVF_T(6, 16, 8, 8, 2, 5, 5, 5, 4)     // up1 narrow, small batch
+    NVF_T(0, 8, 16, 4, 2, 2, 4, 4, 2)     // conv0 narrow: 4^3 -> 8^3 (4 cells / axis), Cout split 8 ways
+    NVF_T(0, 16, 16, 16, 4, 5, 6, 6, 0)   // up2 wide
+    NVF_T(0, 32, 16, 8, 4, 3, 5, 5, 0)    // up1 wide
+    NVF_T(0, 16, 32, 4, 2, 2, 4, 4, 4)    // conv0 wide
+    NVF_T(2, 8, 8, 16, 4, 5, 6, 3, 0)
+    NVF_T(3, 8, 8, 16, 2, 9, 6, 3, 0)
+    NVF_T(4, 8, 8, 16, 2, 9, 6, 3, 4)
+    NVF_T(5, 8, 8, 16, 4, 5, 6, 6, 4)
+    NVF_T(2, 16, 8, 8, 2, 5, 5, 5, 0)
+    NVF_T(3, 16, 8, 8, 2, 5, 5, 5, 4)
+    NVF_T(4, 16, 8, 8, 2, 5, 10, 5, 2)
+    NVF_T(5, 16, 8, 8, 4, 3, 5, 5, 4)
+    NVF_T(2, 8, 16, 4, 2, 2, 4, 4, 2)
+    NVF_T(3, 8, 16, 4, 2, 2, 4, 4, 8)
 #undef NVF_T
   }
   if (rc == 1) {

@@ -68,3 +68,59 @@ __device__ __forceinline__ float nvf_block_sum(float v, float* red) {
   }
   return s;
 }
+
+// ---- global -> LDS staging of a tile made of ROWS rows of RS floats ------------------------------
+// One wave handles whole rows (lane = x), so the row -> (channel, z, y) decomposition is wave-uniform
+// (scalar ALU) and each row is one coalesced load.  U rows are issued back to back as UNCONDITIONAL
+// loads (out-of-range elements read a safe address and are zeroed afterwards), so U loads are in flight
+// per lane instead of one load / one s_waitcnt vmcnt(0) per element.
+// `src(row, x, ok)` returns the element's offset into `base` and sets ok = element is inside the tensor.
+template <int NT, int ROWS, int RS, int LDS_RS, int U, class Src, class Dst>
+__device__ __forceinline__ void nvf_stage_rows(const float* __restrict__ base, float* lds, int tid, Src src, Dst dst) {
+  static_assert(RS <= 64, "one wave covers a row");
+  constexpr int NW = NT / 64;
+  constexpr int RPW = RS <= 32 ? 2 : 1;                    // short rows: two rows per wave pass
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // SGPR: row math on the SALU
+  const int sub = RPW == 2 ? lane >> 5 : 0;
+  const int xx = RPW == 2 ? lane & 31 : lane;
+#pragma unroll 1
+  for (int r0 = wave * RPW; r0 < ROWS; r0 += NW * RPW * U) {
+    float v[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * NW * RPW + sub;
+      const bool live = r < ROWS && xx < RS;
+      bool inside = false;
+      const size_t off = src(live ? r : 0, live ? xx : 0, inside);
+      ok[u] = live && inside;
+      v[u] = base[ok[u] ? off : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * NW * RPW + sub;
+      if (r < ROWS && xx < RS) lds[dst(r, xx)] = ok[u] ? v[u] : 0.f;
+    }
+  }
+}
+
+// read N floats (N a multiple of LV) from an LDS row whose start is LV*4-byte aligned
+template <int N, int LV>
+__device__ __forceinline__ void nvf_lds_row(const float* p, float* out) {
+  if constexpr (LV == 4) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      float4 t = ((const float4*)p)[i];
+      out[4 * i] = t.x; out[4 * i + 1] = t.y; out[4 * i + 2] = t.z; out[4 * i + 3] = t.w;
+    }
+  } else if constexpr (LV == 2) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      float2 t = ((const float2*)p)[i];
+      out[2 * i] = t.x; out[2 * i + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = p[i];
+  }
+}

@@ -17,6 +17,10 @@
 // result is reproducible run to run (no float atomics).
 #include "nvf_common.h"
 
+static const int kMaxSlabs = 512;
+__global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
+                             int accumulate);
+
 struct WgDims {
   int batch, bc;           // batch, number of q channels
   int dp, hp, wp;          // p grid
@@ -55,10 +59,12 @@ __global__ void wgrad_naive(const float* __restrict__ p, const float* __restrict
   dw[o] = accumulate ? dw[o] + acc : acc;
 }
 
-template <int A_, int KS_, int S_, int NB_, int TX_, int TY_, int TZ_>
+template <int A_, int KS_, int S_, int NB_, int TX_, int TY_, int TZ_, int IXU_ = 0>
 struct WCfg {
   static constexpr int A = A_, KS = KS_, S = S_, NB = NB_, TX = TX_, TY = TY_, TZ = TZ_;
   static constexpr int K3 = KS * KS * KS;
+  // x-loop unroll: each unrolled step holds 4*A scalar registers of p; keep the live set under ~64 SGPRs
+  static constexpr int IXU = IXU_ > 0 ? IXU_ : (A_ <= 8 ? 2 : 1);
   static constexpr int WPB = (K3 + 63) / 64;          // waves per q channel
   static constexpr int NT = NB * WPB * 64;
   static constexpr int QX = (TX - 1) * S + KS, QY = (TY - 1) * S + KS, QZ = (TZ - 1) * S + KS;
@@ -99,19 +105,18 @@ __global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p
     const int x0 = (t % d.tiles_x) * TX, y0 = ((t / d.tiles_x) % d.tiles_y) * TY, z0 = (t / (d.tiles_x * d.tiles_y)) * TZ;
     const int qx0 = x0 * S - d.pad, qy0 = y0 * S - d.pad, qz0 = z0 * S - d.pad;
     if (item != first) __syncthreads();
-    for (int e = tid; e < NB * QZ * QY * QX; e += NT) {
-      int xx = e % QX;
-      int r = e / QX;
-      int yy = r % QY;
-      r /= QY;
-      int zz = r % QZ;
-      int c = r / QZ;
-      int gx = qx0 + xx, gy = qy0 + yy, gz = qz0 + zz;
-      float v = 0.f;
-      if (b0 + c < d.bc && gx >= 0 && gx < d.wq && gy >= 0 && gy < d.hq && gz >= 0 && gz < d.dq)
-        v = q[(((size_t)n * d.bc + b0 + c) * d.dq + gz) * qplane + (size_t)gy * d.wq + gx];
-      lds[c * QCS + zz * QPS + yy * QRS + xx] = v;
-    }
+    nvf_stage_rows<NT, NB * QZ * QY, QX, QRS, 8>(
+        q + (size_t)n * d.bc * d.dq * qplane, lds, tid,
+        [&](int r, int xx, bool& ok) -> size_t {
+          const int yy = r % QY, t2 = r / QY, zz = t2 % QZ, c = t2 / QZ;
+          const int gx = qx0 + xx, gy = qy0 + yy, gz = qz0 + zz;
+          ok = b0 + c < d.bc && gx >= 0 && gx < d.wq && gy >= 0 && gy < d.hq && gz >= 0 && gz < d.dq;
+          return ((size_t)(b0 + c) * d.dq + gz) * qplane + (size_t)gy * d.wq + gx;
+        },
+        [&](int r, int xx) {
+          const int yy = r % QY, t2 = r / QY, zz = t2 % QZ, c = t2 / QZ;
+          return c * QCS + zz * QPS + yy * QRS + xx;
+        });
     __syncthreads();
     const float* pn = p + (size_t)n * A * d.dp * pplane;
 #pragma unroll 1
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p
       for (int iy = 0; iy < TY; ++iy) {
         const float* prow = pn + ((size_t)(z0 + iz) * d.hp + (y0 + iy)) * d.wp + x0;  // wave-uniform
         const float* qrow = lds + lane_off + iz * S * QPS + iy * S * QRS;
-#pragma unroll
+#pragma unroll C::IXU
         for (int ix = 0; ix < TX; ix += 4) {
           float qv[4];
 #pragma unroll
@@ -147,6 +152,147 @@ __global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p
   }
 }
 
+// ---------------------------------------------------------------------------
+// MFMA weight gradient for the 4^3, 8 -> 8 channel convolutions (conv1, conv2: 75 % of all
+// bwd-weight FLOPs).  v_mfma_f32_16x16x4_f32 is an exact fp32 fmaf chain at the fp32 vector rate,
+// and here it loses nothing to the tiny channel counts:
+//   rows  m = (co, sA)  A[m][kk] = dY[co, z, y, x0 + kk - sA]          sA in {0,1}
+//   cols  n = (ci, sB)  B[kk][n] = X [ci, z+kz, y+ky, x0 + kk + 2 sB]  sB in {0,1}
+//   D[m][n] += sum_kk A B  =  dW[co][ci][kz][ky][kx = sA + 2 sB]
+// so one 16x16 tile per (kz,ky) covers the four kx taps with every MFMA lane useful; the K
+// dimension runs along x in groups of four (x padded to a multiple of 4, dY zero outside [0,W)).
+// The A fragment is shared by the 16 (kz,ky) tiles: 17 ds_read_b32 per 16 MFMAs.  Both tiles sit in
+// LDS planar [c][z][y][x] with the channel stride == 4 (mod 32), so the 32 lanes of a ds_read group
+// (8 channels x 4 x-offsets) hit 32 distinct banks and staging stays a plain coalesced copy.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int W_, int TZ_, int TY_>
+struct MCfg {
+  static constexpr int W = W_, TZ = TZ_, TY = TY_;
+  static constexpr int NG = (W + 1 + 3) / 4;             // x groups: x runs over [0, W] (W+1 values)
+  static constexpr int GRS = NG * 4 + 2;                 // dY row: u = x + 1 in [0, 4 NG]
+  static constexpr int XRS = NG * 4 + 2;                 // X row: x + 2 sB up to 4 NG + 1
+  static constexpr int mod32(int v, int r) { return v + ((r - v % 32) + 32) % 32; }
+  static constexpr int GCS = mod32(TZ * TY * GRS, 4);
+  static constexpr int XCS = mod32((TZ + 3) * (TY + 3) * XRS, 4);
+  static constexpr int GOFF = 0, XOFF = 8 * GCS;
+  static constexpr int LDSF = 8 * GCS + 8 * XCS;
+  static constexpr int NT = 256;
+  static_assert(LDSF >= 4096, "the staging area doubles as the 4096-float reduction buffer");
+  static_assert(LDSF * 4 <= 160 * 1024, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g, const float* __restrict__ x,
+                                                     float* __restrict__ slabs, WgDims d) {
+  constexpr int W = C::W, TZ = C::TZ, TY = C::TY, NG = C::NG, GRS = C::GRS, XRS = C::XRS, GCS = C::GCS, XCS = C::XCS;
+  __shared__ float lds[C::LDSF];
+  float* ldsG = lds + C::GOFF;
+  float* ldsX = lds + C::XOFF;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ch = lane & 7, sh = (lane >> 3) & 1, kk = lane >> 4;
+  const int laneA = ch * GCS + kk - sh + 1;
+  const int laneB = ch * XCS + kk + 2 * sh;
+  f32x4 acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int WQ = W + 3;                       // q grid extent (valid conv, k = 4)
+  const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
+  const int first = blockIdx.x * d.items_per_wg;
+  const int last = min(first + d.items_per_wg, d.items);
+#pragma unroll 1
+  for (int item = first; item < last; ++item) {
+    const int n = item / tiles, t = item % tiles;
+    const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
+    if (item != first) __syncthreads();
+    // dY tile, zero-padded in x: u = x + 1
+    const float* gn = g + (size_t)n * 8 * W * W * W;
+    nvf_stage_rows<256, 8 * TZ * TY, GRS, GRS, 8>(
+        gn, ldsG, tid,
+        [&](int r, int u, bool& ok) -> size_t {
+          const int yy = r % TY, t2 = r / TY, zz = t2 % TZ, c = t2 / TZ;
+          ok = u >= 1 && u <= W;
+          return (((size_t)c * W + z0 + zz) * W + y0 + yy) * W + (u - 1);
+        },
+        [&](int r, int u) {
+          const int c = r / (TZ * TY);
+          return c * GCS + (r - c * TZ * TY) * GRS + u;
+        });
+    const float* xn = x + (size_t)n * 8 * WQ * WQ * WQ;
+    nvf_stage_rows<256, 8 * (TZ + 3) * (TY + 3), XRS, XRS, 8>(
+        xn, ldsX, tid,
+        [&](int r, int xx, bool& ok) -> size_t {
+          const int yy = r % (TY + 3), t2 = r / (TY + 3), zz = t2 % (TZ + 3), c = t2 / (TZ + 3);
+          ok = xx < WQ;
+          return (((size_t)c * WQ + z0 + zz) * WQ + y0 + yy) * WQ + xx;
+        },
+        [&](int r, int xx) {
+          const int c = r / ((TZ + 3) * (TY + 3));
+          return c * XCS + (r - c * (TZ + 3) * (TY + 3)) * XRS + xx;
+        });
+    __syncthreads();
+#pragma unroll 1
+    for (int row = wave; row < TZ * TY; row += 4) {
+      const int zz = row / TY, yy = row % TY;
+      const float* pa = ldsG + laneA + row * GRS;
+      const float* pb = ldsX + laneB + (zz * (TY + 3) + yy) * XRS;
+      // operands of x-group xg+1 are fetched while the 16 MFMAs of group xg issue
+      float a_cur = pa[0], b_cur[16];
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) b_cur[t2] = pb[((t2 >> 2) * (TY + 3) + (t2 & 3)) * XRS];
+#pragma unroll
+      for (int xg = 0; xg < NG; ++xg) {
+        float a_nxt = 0.f, b_nxt[16];
+        if (xg + 1 < NG) {
+          a_nxt = pa[(xg + 1) * 4];
+#pragma unroll
+          for (int t2 = 0; t2 < 16; ++t2) b_nxt[t2] = pb[((t2 >> 2) * (TY + 3) + (t2 & 3)) * XRS + (xg + 1) * 4];
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 16; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t2], acc[t2], 0, 0, 0);
+        if (xg + 1 < NG) {
+          a_cur = a_nxt;
+#pragma unroll
+          for (int t2 = 0; t2 < 16; ++t2) b_cur[t2] = b_nxt[t2];
+        }
+      }
+    }
+  }
+  // cross-wave sum through LDS (reusing the staging area), then one slab per workgroup
+  __syncthreads();
+  const int nn = lane & 15, ci = nn & 7, sB = nn >> 3;
+#pragma unroll 1
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * (lane >> 4) + r, co = m & 7, sA = m >> 3;
+          const int o = (co * 8 + ci) * 64 + (t2 >> 2) * 16 + (t2 & 3) * 4 + sA + 2 * sB;
+          lds[o] = wv == 0 ? acc[t2][r] : lds[o] + acc[t2][r];
+        }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (size_t)blockIdx.x * 4096;
+  for (int o = tid; o < 4096; o += 256) slab[o] = lds[o];
+}
+
+template <class C>
+static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* slabs, WgDims d, int accumulate,
+                             hipStream_t s) {
+  d.items = d.batch * (C::W / C::TY) * (C::W / C::TZ);
+  int nslab = d.items < kMaxSlabs ? d.items : kMaxSlabs;
+  d.items_per_wg = (d.items + nslab - 1) / nslab;
+  nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+  wgrad_k4_mfma<C><<<nslab, 256, 0, s>>>(g, x, slabs, d);
+  wgrad_reduce<<<(4096 + 63) / 64, 256, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
+  return NVF_OK;
+}
+
 // dw[j] (+)= sum_g slabs[g][j], g ascending inside each of 4 interleaved slices, slices added 0..3
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab,
                                                     int jtotal, int accumulate) {
@@ -163,8 +309,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
     dw[j] = accumulate ? dw[j] + t : t;
   }
 }
-
-static const int kMaxSlabs = 512;
 
 extern "C" size_t nvf_wgrad_workspace(int batch, int a, int b, int k, int dp, int hp, int wp) {
   (void)batch; (void)dp; (void)hp; (void)wp;
@@ -189,7 +333,7 @@ static int launch_wgrad(const float* p, const float* q, float* dw, float* slabs,
 
 extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch,
                          int a, int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq,
-                         int out_mode, int accumulate, int naive, void* stream) {
+                         int out_mode, int accumulate, int variant, void* stream) {
   if (!p || !q || !dw || batch <= 0 || a <= 0 || b <= 0 || k <= 0 || stride <= 0) return NVF_EINVAL;
   if (dp <= 0 || hp <= 0 || wp <= 0 || dq <= 0 || hq <= 0 || wq <= 0) return NVF_EINVAL;
   if (out_mode != 0 && out_mode != 1) return NVF_EINVAL;
@@ -198,28 +342,51 @@ extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* worksp
   d.out_mode = out_mode; d.jtotal = a * b * k * k * k;
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
-  if (!naive && workspace) {
+  if (variant != 1 && workspace) {
     if (workspace_bytes < nvf_wgrad_workspace(batch, a, b, k, dp, hp, wp)) return NVF_EWORKSPACE;
     float* slabs = (float*)workspace;
-#define NVF_W(AA, KS, ST, WP, NB, TX, TY, TZ)                                                          \
-  if (rc == 1 && a == AA && k == KS && stride == ST && wp == WP && hp % TY == 0 && dp % TZ == 0)        \
-    rc = launch_wgrad<WCfg<AA, KS, ST, NB, TX, TY, TZ>>(p, q, dw, slabs, d, accumulate, s);
-    if (b % 8 == 0) {
-      NVF_W(8, 4, 1, 32, 8, 32, 8, 2)    // conv2 narrow: p = dY [8,32^3], q = X [8,35^3]
-      NVF_W(8, 4, 1, 16, 8, 16, 8, 2)    // conv1 narrow
-      NVF_W(8, 5, 2, 16, 4, 16, 4, 2)    // up2 narrow: p = X [8,16^3], q = dY [8,35^3]
-      NVF_W(16, 5, 2, 8, 4, 8, 4, 2)     // up1 narrow: p = X [16,8^3], q = dY [8,19^3]
-      NVF_W(16, 4, 1, 32, 8, 32, 8, 2)   // conv2 wide
-      NVF_W(16, 4, 1, 16, 8, 16, 8, 2)   // conv1 wide
-      NVF_W(16, 5, 2, 16, 4, 16, 4, 2)   // up2 wide
-      NVF_W(32, 5, 2, 8, 4, 8, 4, 2)     // up1 wide
-    }
-    if (b == 1) {
-      NVF_W(8, 3, 1, 32, 1, 32, 8, 4)    // conv2_cls: p = X [8,32^3], q = dlogit [1,32^3] (out_mode 1)
-      NVF_W(8, 3, 1, 16, 1, 16, 8, 4)    // conv1_cls
-      NVF_W(16, 3, 1, 32, 1, 32, 8, 4)   // wide heads
-      NVF_W(16, 3, 1, 16, 1, 16, 8, 4)
-    }
+#define NVF_W(VAR, AA, KS, ST, WP, NB, TX, TY, TZ, IXU)                                                          \
+  if (rc == 1 && variant == VAR && a == AA && k == KS && stride == ST && wp == WP && hp % TY == 0 && dp % TZ == 0 && \
+      b % NB == 0)                                                                                                 \
+    rc = launch_wgrad<WCfg<AA, KS, ST, NB, TX, TY, TZ, IXU>>(p, q, dw, slabs, d, accumulate, s);
+    const bool cube_k4 = a == 8 && b == 8 && k == 4 && stride == 1 && pad == 0 && out_mode == 0 && dp == wp &&
+                         hp == wp && dq == wp + 3 && hq == wp + 3 && wq == wp + 3;
+    if (rc == 1 && variant == 0 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 4, 4>>(p, q, dw, slabs, d, accumulate, s);
+    if (rc == 1 && variant == 0 && cube_k4 && wp == 16) rc = launch_wgrad_mfma<MCfg<16, 2, 8>>(p, q, dw, slabs, d, accumulate, s);
+    if (rc == 1 && variant == 7 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 8>>(p, q, dw, slabs, d, accumulate, s);
+    if (rc == 1 && variant == 8 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 4>>(p, q, dw, slabs, d, accumulate, s);
+    NVF_W(9, 8, 4, 1, 32, 8, 32, 8, 2, 0)    // conv2 narrow, VALU form: p = dY [8,32^3], q = X [8,35^3]
+    NVF_W(9, 8, 4, 1, 16, 8, 16, 8, 2, 0)    // conv1 narrow, VALU form
+    NVF_W(0, 8, 5, 2, 16, 4, 16, 4, 2, 0)    // up2 narrow: p = X [8,16^3], q = dY [8,35^3]
+    NVF_W(0, 16, 5, 2, 8, 4, 8, 4, 2, 0)     // up1 narrow: p = X [16,8^3], q = dY [8,19^3]
+    NVF_W(0, 8, 5, 2, 4, 4, 4, 4, 4, 0)      // conv0 narrow: p = X [8,4^3], q = dY [16,8^3]
+    NVF_W(0, 16, 4, 1, 32, 8, 32, 8, 2, 0)   // conv2 wide
+    NVF_W(0, 16, 4, 1, 16, 8, 16, 8, 2, 0)   // conv1 wide
+    NVF_W(0, 16, 5, 2, 16, 4, 16, 4, 2, 0)   // up2 wide
+    NVF_W(0, 32, 5, 2, 8, 4, 8, 4, 2, 0)     // up1 wide
+    NVF_W(0, 16, 5, 2, 4, 4, 4, 4, 4, 0)     // conv0 wide
+    NVF_W(0, 8, 3, 1, 32, 1, 32, 8, 4, 0)    // conv2_cls: p = X [8,32^3], q = dlogit [1,32^3] (out_mode 1)
+    NVF_W(0, 8, 3, 1, 16, 1, 16, 8, 4, 0)    // conv1_cls
+    NVF_W(0, 16, 3, 1, 8, 1, 8, 8, 8, 0)     // conv0_cls narrow
+    NVF_W(0, 16, 3, 1, 32, 1, 32, 8, 4, 0)   // wide heads
+    NVF_W(0, 16, 3, 1, 16, 1, 16, 8, 4, 0)
+    NVF_W(0, 32, 3, 1, 8, 1, 8, 8, 8, 0)
+    NVF_W(0, 1, 3, 1, 32, 8, 32, 8, 4, 8)    // heads in the plain orientation: p = dlogit [1,32^3], q = X [8,32^3]
+    NVF_W(0, 1, 3, 1, 16, 8, 16, 8, 4, 4)
+    NVF_W(0, 1, 3, 1, 8, 8, 8, 8, 8, 2)
+    // tuning alternatives
+    NVF_W(2, 1, 3, 1, 32, 8, 32, 8, 2, 8)
+    NVF_W(3, 1, 3, 1, 32, 4, 32, 8, 4, 8)
+    NVF_W(2, 8, 4, 1, 32, 8, 32, 8, 2, 1)
+    NVF_W(3, 8, 4, 1, 32, 8, 32, 8, 2, 8)
+    NVF_W(4, 8, 4, 1, 32, 8, 32, 4, 2, 2)
+    NVF_W(5, 8, 4, 1, 32, 4, 32, 8, 4, 2)
+    NVF_W(6, 8, 4, 1, 32, 8, 32, 8, 4, 2)
+    NVF_W(2, 8, 3, 1, 32, 1, 32, 8, 4, 1)
+    NVF_W(3, 8, 3, 1, 32, 1, 32, 4, 2, 2)
+    NVF_W(2, 8, 5, 2, 16, 4, 16, 4, 2, 1)
+    NVF_W(3, 8, 5, 2, 16, 8, 16, 4, 2, 2)
+    NVF_W(4, 8, 5, 2, 16, 4, 16, 2, 2, 2)
 #undef NVF_W
   }
   if (rc == 1) {

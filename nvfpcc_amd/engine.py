@@ -159,10 +159,7 @@ class TrainEngine:
     def _bwd_conv(self, L, g_out, x_in, mask, want_w, addend=None, need_dx=True):
         """g_out: gradient w.r.t. the layer's pre-activation output.  Returns d x_in (masked by `mask`)."""
         if want_w:
-            if L.cout == 1:
-                ops.wgrad(x_in, g_out, L.k, 1, L.k - 1 - L.pad, out_mode=1, out=L.gk)
-            else:
-                ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
+            ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
             ops.channel_sum(g_out, out=L.gb)
         if not need_dx:
             return None

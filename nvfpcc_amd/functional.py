@@ -56,10 +56,7 @@ class Conv3d(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d_gather(gp, wb, None, cin, k, 1, k - 1 - pad, tuple(x.shape[2:]))
         if ctx.needs_input_grad[1]:
-            if cout == 1 and k > 1:   # one-channel heads: taps on the lanes, input channels in registers
-                dw = ops.wgrad(x, gp, k, 1, k - 1 - pad, out_mode=1)
-            else:
-                dw = ops.wgrad(gp, x, k, 1, pad, out_mode=0)
+            dw = ops.wgrad(gp, x, k, 1, pad, out_mode=0)
         if ctx.needs_input_grad[2]:
             db = ops.channel_sum(gp)
         return dx, dw, db, None, None

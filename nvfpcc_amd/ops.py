@@ -11,12 +11,19 @@ import torch
 from ._lib import lib, check
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-_NAIVE = int(os.environ.get("NVF_NAIVE", "0"))  # debug: route convs through the one-thread-per-output kernels
+# kernel variant passed to the conv / wgrad entry points: 0 = tuned LDS-tiled kernels, 1 = the
+# one-thread-per-output kernels (debug cross-check), >= 2 = alternates kept for tuning (tools/kbench.py)
+_NAIVE = int(os.environ.get("NVF_VARIANT", "0"))
 
 
 def set_naive(flag):
     global _NAIVE
     _NAIVE = int(bool(flag))
+
+
+def set_variant(v):
+    global _NAIVE
+    _NAIVE = int(v)
 
 
 def _ptr(t):

@@ -118,20 +118,17 @@ def test_conv_weight_gradient(ops, cin, cout, k, pad, n):
     y = F.conv3d(x, w, None, 1, pad)
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
-    if cout == 1:   # heads: p = X, q = dlogit, flipped output
-        dw = ops.wgrad(dev(x), dev(gy), k, 1, pad, out_mode=1)
-        ops.set_naive(True)
-        dwn = ops.wgrad(dev(x), dev(gy), k, 1, pad, out_mode=1)
-    else:
-        dw = ops.wgrad(dev(gy), dev(x), k, 1, pad, out_mode=0)
-        ops.set_naive(True)
-        dwn = ops.wgrad(dev(gy), dev(x), k, 1, pad, out_mode=0)
+    dw = ops.wgrad(dev(gy), dev(x), k, 1, pad, out_mode=0)
+    ops.set_naive(True)
+    dwn = ops.wgrad(dev(gy), dev(x), k, 1, pad, out_mode=0)
     ops.set_naive(False)
+    if cout == 1:   # the transposed orientation (p = X, q = dlogit, flipped taps) gives the same tensor
+        dwf = ops.wgrad(dev(x), dev(gy), k, 1, k - 1 - pad, out_mode=1)
+        assert rel_err(dwf, w.grad) < 2e-5
     assert tuple(dw.shape) == tuple(w.shape)
     assert rel_err(dwn, w.grad) < 2e-5
     assert rel_err(dw, w.grad) < 2e-5
-    acc = ops.wgrad(dev(x), dev(gy), k, 1, pad, out_mode=1, out=dw.clone(), accumulate=True) if cout == 1 else \
-        ops.wgrad(dev(gy), dev(x), k, 1, pad, out_mode=0, out=dw.clone(), accumulate=True)
+    acc = ops.wgrad(dev(gy), dev(x), k, 1, pad, out_mode=0, out=dw.clone(), accumulate=True)
     assert rel_err(acc, 2 * w.grad) < 2e-5
 
 
