@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""NVFPCC command line on MI355X: `train`, `encode`, `decode` with the reference's flags, defaults,
+checkpoint files and pack.pk layout (/root/reference/NVFPCC.py:654-755), driven by the gfx950 step
+engine (nvfpcc_amd/engine.py) instead of a DataLoader + autograd loop.
+
+    python NVFPCC.py train longdress_vox10_1300.ply --checkpoint_dir ckpts --batchsize 16 --lambda 200 \
+        --lr 1e-3 --w1 10 --w2 57 --wemb 5 --shuffle True --chanstr 8,16,8,8 --ch 3
+    python NVFPCC.py encode longdress_vox10_1300.ply --batchsize 1 --chanstr 8,16,8,8 --ch 3 \
+        --load_weights 0500_quantized_q4.ckpt --load_emb ckpts/0500_emb.ckpt --thh 0.65 --pack_fn pack.pk
+    python NVFPCC.py decode pack.pk --batchsize 1 --chanstr 8,16,8,8 --ch 3 --thh 0.64
+
+Additions over the reference (all optional): --device, --epochs, --seed; multi-GPU training when launched
+through torch.distributed.run (one process per GPU, leaf blocks sharded, one RCCL all-reduce per step).
+Headless: no GUI window, no IPython shell.
+"""
+import argparse
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+param_model = 'Gaussian'
+prob_model = 'Gaussian'
+main_loss = 'wfocal'   # distance-weighted focal loss (NVFPCC.py:27)
+focal_alpha = 0.9
+
+
+def _banner():
+    print(f'[Info] Using {param_model} for network parameters.')
+    print(f'[Info] Using {prob_model} for latent repr.')
+    print(f'[Info] Using {main_loss} as main loss function, alpha={focal_alpha}')
+
+
+def lr_at_epoch(base_lr, epoch):
+    """Both MultiStepLR([300,400,450], 0.1) objects of the reference are bound to the DECODER optimiser
+    (NVFPCC.py:117,126,253-254): x0.01 per milestone for the decoder, the latent LR never decays."""
+    return base_lr * (0.01 ** sum(epoch >= m for m in (300, 400, 450)))
+
+
+def _device(args):
+    if not torch.cuda.is_available():
+        raise RuntimeError("NVFPCC.py needs a HIP device: the NVF hot path has no CPU fallback "
+                           "(the CPU oracle lives in oracle/ and is test infrastructure)")
+    from nvfpcc_amd import dist as nd
+    rank, local_rank, world = nd.init()
+    dev = torch.device(args.device if args.device != 'cuda' else f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+    return dev, rank, world
+
+
+def _build_net(args, dev):
+    from nvfpcc_amd import network
+    from nvfpcc_amd.model import Net
+    network.reset_seed()                     # SEED3.npy from the CWD if present, else the build's stand-in
+    network.set_noise_seed(args.seed)
+    return Net(args, param_model, args.ch, channel_str=args.chanstr).to(dev)
+
+
+def _psnr1(sse, denom):
+    mse1 = sse / max(denom, 1e-30)
+    return mse1, 20 * np.log10(1023 / np.sqrt(mse1 / 3)) if mse1 > 0 else float('inf')
+
+
+def train(args):
+    from nvfpcc_amd import dist as nd, ops
+    from nvfpcc_amd.dataloader import LoadedVoxelDataset
+    from nvfpcc_amd.engine import TrainEngine
+    dev, rank, world = _device(args)
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say(f'Rate loss = {args.w1} * b1 + b2 + {args.w2} * b3')
+    fid = args.input[:-4]
+    data = LoadedVoxelDataset(f'{fid}_l5_origins.npy', f'{fid}_l5_gt_grid.npy', f'{fid}_l5_dist.npy')
+    say('Using lambda: ', args.lmbda)
+    net = _build_net(args, dev)
+    gt, dist = data.to_device(dev)
+    eng = TrainEngine(net, gt, dist, n_points_total=float(data.N), lmbda=args.lmbda, w1=args.w1, w2=args.w2,
+                      lr=args.lr, wemb=args.wemb, seed=args.seed)
+    nd.attach(eng, world)
+    say('Embedding learning rate: %f x %f = %f' % (args.lr, args.wemb, args.lr * args.wemb))
+    B, N = args.batchsize, data.N_leaf
+    lo, hi = nd.shard_range(N, rank, world)
+    q = 1
+    for epoch in range(0, args.epochs):
+        t0 = time.time()
+        if epoch == args.phase_change:
+            q = 2
+        eng.lr = lr_at_epoch(args.lr, epoch)
+        order = data.epoch_order(epoch, bool(args.shuffle), seed=args.seed)
+        nsteps = (N + B - 1) // B
+        acc = torch.zeros(6, device=dev)          # tp, ap, tn, an (thh .5); sse, denom (thh .6) over the epoch
+        loss_sum = torch.zeros(3, device=dev)
+        bits_sum = torch.zeros(2, device=dev)
+        for s in range(nsteps):
+            ids, whole = nd.shard_minibatch(order, s, B, rank, world)
+            if len(ids) == 0:                     # short last batch: this rank idles but still joins the all-reduce
+                eng.flat_g.zero_()
+                nd.allreduce_sum_(eng.flat_g)
+                eng.opt_step += 1
+                ops.adam_step(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, eng.lr, eng.opt_step)
+                continue
+            n_pts = float(eng.counts[whole].sum())
+            a = eng.train_step(ids, q, n_pts=n_pts)
+            idd = torch.from_numpy(np.asarray(ids)).to(dev)
+            ops.metrics(a["p2"], ops.gather_rows(eng.gt, idd), ops.gather_rows(eng.dist, idd), 0.5, 0.6, out=acc,
+                        accumulate=True)
+            loss_sum += eng.last["loss_terms"][:3]
+            bits_sum[0] += eng.last["latent_bits"][0] / n_pts
+            bits_sum[1] += eng.last["net_bits"].sum() / eng.n_points_total
+        # latent update on this rank's shard, then re-synchronise the replicated table
+        if hi > lo:
+            eng.latent_step(q, lo, hi)
+        nd.allgather_rows_(eng.emb, rank, world)
+        if world > 1:
+            for t in (acc, loss_sum, bits_sum):
+                nd.allreduce_sum_(t)
+        m = acc.cpu().numpy()
+        ls = loss_sum.cpu().numpy() / nsteps
+        bs = bits_sum.cpu().numpy() / nsteps
+        mse1, psnr1 = _psnr1(m[4], m[5])
+        total = ls.sum() + args.lmbda * (bs[0] * args.w1 + bs[1] * args.w2)
+        say('[Epoch %04d TRAIN %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f '
+            'S1 Loss: %.4f S2 Loss: %.4f bpp: %.4f b_latent: %.4f  b_net: %.4f MSE1: %.4f PSNR1: %.4f' % (
+                epoch, time.time() - t0, total, 0.0, 0.0, m[0] / max(m[1], 1), m[2] / max(m[3], 1), ls[1], ls[2],
+                bs[0] + bs[1], bs[0], bs[1], mse1, psnr1))
+        if epoch % 10 == 0 and rank == 0:
+            print('[INFO] Saving')
+            os.makedirs(args.checkpoint_dir, exist_ok=True)
+            sd = OrderedDict((k, v.detach().clone()) for k, v in net.state_dict().items())
+            torch.save(sd, './%s/%04d.ckpt' % (args.checkpoint_dir, epoch))
+            torch.save(eng.emb.detach().clone(), './%s/%04d_emb.ckpt' % (args.checkpoint_dir, epoch))
+            t1 = time.time()
+            a = eng.eval_forward(q=2)
+            mt = ops.metrics(a["p2"], eng.gt, eng.dist, 0.5, 0.6).cpu().numpy()
+            lat_bits = a["lbits"].item()
+            net_bits = net.get_network_bits()
+            mse1, psnr1 = _psnr1(mt[4], mt[5])
+            print('[Epoch %04d TEST %.1f seconds] Pacc: %.4f Nacc: %.4f b_latent: %.4f b_all: %.4f MSE1: %.4f '
+                  'PSNR1: %.4f' % (epoch, time.time() - t1, mt[0] / max(mt[1], 1), mt[2] / max(mt[3], 1),
+                                   lat_bits / data.N, (lat_bits + net_bits) / data.N, mse1, psnr1))
+
+
+def encode(args):
+    """Pack everything the decoder needs (NVFPCC.py:395-554)."""
+    from nvfpcc_amd import ops, weight_codec, latent_codec
+    from nvfpcc_amd.dataloader import LoadedVoxelDataset
+    from nvfpcc_amd.recon import reconstruct_points, write_ply_ascii
+    dev, rank, world = _device(args)
+    fid = args.input[:-4]
+    data = LoadedVoxelDataset(f'{fid}_l5_origins.npy', f'{fid}_l5_gt_grid.npy', f'{fid}_l5_dist.npy', shuffle=False)
+    net = _build_net(args, dev)
+    net_weight_pack = weight_codec.enc_dec_from_file(args.load_weights, qp=int(args.qp))
+    net_bits = len(net_weight_pack['bit_stream']) * 8
+    d = torch.load(args.load_weights, map_location=dev)
+    net.load_state_dict({k: v for k, v in d.items() if 'init_coords' not in k}, strict=False)
+    emb = torch.load(args.load_emb, map_location=dev).to(dev).float().contiguous()
+    np_origins = np.array([data.origins[i] for i in range(len(data))], dtype=np.int16)
+    with torch.no_grad():
+        info = net.get_latent_code(emb)
+    print('Estimated bit rate: ', info['latent_likelihood'].sum())
+    latent_pack = latent_codec.arithmetic_enc(info['quantized_latent'], info['sigma'], info['mu'])
+    with open(args.pack_fn, 'wb') as f:
+        pickle.dump({'net_weight_pack': net_weight_pack, 'origins': np_origins, 'latent_pack': latent_pack}, f)
+    print('Start to reconstruct')
+    pts, counts = reconstruct_points(net, info['quantized_latent'].detach(), np_origins, args.thh,
+                                     batch=max(int(args.batchsize), 1))
+    gt, dist = data.to_device(dev)
+    with torch.no_grad():
+        out = torch.cat([net.reconstruct(info['quantized_latent'][i:i + 64].contiguous(), 2)
+                         for i in range(0, len(data), 64)], 0)
+    m = ops.metrics(out, gt, dist, args.thh, args.thh).cpu().numpy()
+    latent_bits = len(latent_pack['latent_byte_stream']) * 8
+    print('[Latent code] Gross bpp: %.4f' % ((latent_bits + net_bits) / data.N))
+    print('[Recon] Pacc: %.4f Nacc: %.4f MSE1: %.4f PSNR1: %.4f' % (
+        m[0] / max(m[1], 1), m[2] / max(m[3], 1), *_psnr1(m[4], m[5])))
+    write_ply_ascii('rc_enc.ply', pts)
+
+
+def decode(args):
+    """Decode from a pack (NVFPCC.py:557-652)."""
+    from nvfpcc_amd import weight_codec, latent_codec
+    from nvfpcc_amd.recon import reconstruct_points, write_ply_ascii
+    dev, rank, world = _device(args)
+    net = _build_net(args, torch.device('cpu'))
+    with open(args.input, 'rb') as f:
+        total_pack = pickle.load(f)
+    wp = total_pack['net_weight_pack']
+    dec_pool = weight_codec.entropy_decode(wp['bit_stream'], wp['inv_codebook'], wp['element_length'], wp['shape_list'])
+    nd_ = {}
+    for k, v in zip(wp['keys_quantize'], dec_pool):
+        nd_[k] = torch.from_numpy(v).float() / args.qp
+    for k, v in zip(wp['keys_code_as_is'], wp['as_is_pool']):
+        nd_[k] = torch.from_numpy(np.asarray(v)).float()
+    net.load_state_dict(nd_, strict=False)
+    net = net.to(dev)
+    latents = latent_codec.arithmetic_dec(total_pack['latent_pack']).to(dev)
+    n = int(args.N)
+    print('Start to reconstruct')
+    pts, counts = reconstruct_points(net, latents[:n].contiguous(), total_pack['origins'][:n], args.thh,
+                                     batch=max(int(args.batchsize), 1))
+    write_ply_ascii('rc_dec.ply', pts)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("command", choices=["train", "encode", "decode"], help="What to do?")
+    p.add_argument("input", nargs="?", help="Input filename.")
+    p.add_argument("--checkpoint_dir", default="train", help="Directory where to save/load model checkpoints.")
+    p.add_argument("--batchsize", type=int, default=2, help="Batch size for training.")
+    p.add_argument("--lambda", type=float, default=0.01, dest="lmbda", help="Lambda for rate-distortion tradeoff.")
+    p.add_argument("--load_weights", default="", help="Weights to load")
+    p.add_argument("--load_extern", default="", help="Load external weights")
+    p.add_argument("--lr", type=float, default=1e-4, help="Learning rate.")
+    p.add_argument("--alpha", type=float, default=200, help="Alpha.")
+    # type=bool as in the reference: any non-empty string is True (NVFPCC.py:684-692, 710)
+    p.add_argument("--use_coords", type=bool, default=False, help="Use coords?")
+    p.add_argument("--real", type=bool, default=False, help="Real compression?")
+    p.add_argument("--dsep", type=bool, default=False, help="Use depth-separable conv?")
+    p.add_argument("--stat_latent", type=bool, default=False, help="(unused)")
+    p.add_argument("--stat_net", type=bool, default=False, help="(unused)")
+    p.add_argument("--w1", type=float, default=1, dest="w1", help="W1 for rate-distortion tradeoff.")
+    p.add_argument("--w2", type=float, default=1, dest="w2", help="W2 for rate-distortion tradeoff.")
+    p.add_argument("--notes", type=str, default="Hello", dest="notes", help="Leave a note?")
+    p.add_argument("--load_meta", type=str, default="", dest="load_meta", help="Load a meta init")
+    p.add_argument('--shuffle', type=bool, default=False, dest="shuffle", help="Shuffle the dataset randomly?")
+    p.add_argument("--phase_change", type=int, default=100, dest="phase_change", help="Phase change epoch.")
+    p.add_argument("--wemb", type=float, default=5, dest="wemb", help="Weight for emb lr.")
+    p.add_argument('--ch', type=int, default=8, dest="ch", help="# channels in latent")
+    p.add_argument("--load_emb", type=str, default="", dest="load_emb", help="Load an emb")
+    p.add_argument("--chanstr", type=str, default="8,16,8,8", dest="chanstr", help="Control channels in the compnet")
+    p.add_argument("--thh", type=float, default=0.6, dest="thh", help="Threshold.")
+    p.add_argument('--pack_fn', default='pack.pk', help='package filename.')
+    p.add_argument('--N', default=917, help='Number of leaves nodes.')
+    p.add_argument('--qp', type=float, default=16, help='Quantization parameter used for net weights.')
+    # additions
+    p.add_argument('--device', default='cuda', help='HIP device (the reference hard-codes cuda).')
+    p.add_argument('--epochs', type=int, default=501, help='Number of epochs (the reference hard-codes 501).')
+    p.add_argument('--seed', type=int, default=0, help='Seed of the counter RNG behind the q=1 / latent noise.')
+    return p
+
+
+if __name__ == "__main__":
+    _banner()
+    args = build_parser().parse_args()
+    {"train": train, "encode": encode, "decode": decode}[args.command](args)

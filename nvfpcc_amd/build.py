@@ -7,18 +7,34 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnvf_hip.so")
+CODEC_LIB = os.path.join(HERE, "libnvf_codec.so")
 SOURCES = ["conv_direct.hip", "wgrad.hip", "pointwise.hip"]
 
 
-def _stale():
-    if not os.path.isfile(LIB):
+def _stale(lib=LIB):
+    if not os.path.isfile(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "nvf_hip.h")]
+    t = os.path.getmtime(lib)
+    inc = os.path.join(HERE, "..", "include")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    deps += [os.path.join(inc, f) for f in os.listdir(inc)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_codec(force=False):
+    """Host-side range coder (g++, no GPU code): libnvf_codec.so, C ABI in include/nvf_codec.h."""
+    if not force and not _stale(CODEC_LIB):
+        return CODEC_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-shared", "-std=c++17",
+           os.path.join(CSRC, "range_coder.cpp"), "-o", CODEC_LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on range_coder.cpp:\n{r.stdout}")
+    return CODEC_LIB
+
+
 def build(force=False, verbose=False):
+    build_codec(force)
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

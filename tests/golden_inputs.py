@@ -95,3 +95,29 @@ def gdn_case_inputs():
     gy = torch.randn(2, c, 2, 2, 2, generator=g)
     cases["below_bound"] = (x, beta, gamma, gy)
     return cases
+
+
+def codec_cases():
+    """(symbols int16 in [0,1023], mu f32, sigma f32) triples for the latent arithmetic coder."""
+    rng = np.random.default_rng(4242)
+    cases = {}
+    # a latent table like longdress l5: 917 blocks x 3 channels x 8 positions, symbols = round(latent) + 512
+    n_blk, ch = 917, 3
+    mu_c = np.array([0.21, -0.4, 0.05], np.float32)
+    sg_c = np.array([1.7, 2.9, 0.8], np.float32)
+    lat = np.round(rng.normal(mu_c[None, :, None], sg_c[None, :, None], (n_blk, ch, 8)))
+    mu = np.broadcast_to(mu_c[None, :, None], lat.shape).reshape(-1).astype(np.float32) + 512
+    sg = np.broadcast_to(sg_c[None, :, None], lat.shape).reshape(-1).astype(np.float32)
+    cases["latents917"] = ((lat.reshape(-1) + 512).astype(np.int16), mu, sg)
+    # five symbols
+    cases["tiny"] = (np.array([512, 511, 515, 512, 509], np.int16), np.full(5, 512.3, np.float32),
+                     np.full(5, 1.25, np.float32))
+    # wide model, symbols across the alphabet, per-symbol parameters
+    n = 1000
+    sg2 = rng.uniform(20, 200, n).astype(np.float32)
+    mu2 = rng.uniform(300, 700, n).astype(np.float32)
+    sym2 = np.clip(np.round(rng.normal(mu2, sg2)), 0, 1023).astype(np.int16)
+    cases["wide"] = (sym2, mu2, sg2)
+    # empty message: only the terminator is coded
+    cases["empty"] = (np.zeros(0, np.int16), np.zeros(0, np.float32), np.zeros(0, np.float32))
+    return cases

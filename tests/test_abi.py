@@ -10,8 +10,8 @@ from nvfpcc_amd.build import build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "nvf_hip.h")).read()
+def declared_symbols(header="nvf_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nvf_[a-zA-Z0-9_]+)\s*\(", text)))
 
@@ -45,3 +45,12 @@ def test_ops_refuse_cpu_tensors():
     from nvfpcc_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.maxpool2(torch.zeros(1, 1, 4, 4, 4))
+
+
+def test_codec_library_exports_its_header():
+    from nvfpcc_amd.build import build_codec
+    h = ctypes.CDLL(build_codec())
+    names = declared_symbols("nvf_codec.h")
+    assert names == ["nvf_ac_decode", "nvf_ac_encode", "nvf_codec_version"]
+    for n in names:
+        assert hasattr(h, n)
