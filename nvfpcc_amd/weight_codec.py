@@ -78,15 +78,18 @@ def entropy_encode(tensor_list, codebook):
         for v in t.reshape(-1):
             assert abs(int(v) - v) < 1e-3
             words.append(codebook[int(v)])
-    bits = np.concatenate(words, 0)
+    bits = np.concatenate(words, 0) if words else np.zeros(0, bool)
     print("Length of the bit string: ", bits.shape)
     return np.packbits(bits.astype(np.uint8)).tobytes(), shape_list    # MSB first, zero-padded to a byte
 
 
 def entropy_decode(byte_str, inv_codebook, nsymbol, shape_list):
     bits = np.unpackbits(np.frombuffer(byte_str, np.uint8))
-    table = {(len(k), int(k, 2)): v for k, v in inv_codebook.items()}
     symbols, length, value = [], 0, 0
+    if '' in inv_codebook:      # one distinct value: the empty codeword, zero bits per symbol
+        symbols = [inv_codebook['']] * nsymbol
+        bits = bits[:0]
+    table = {(len(k), int(k, 2)): v for k, v in inv_codebook.items() if k}
     for b in bits:
         length += 1
         value = (value << 1) | int(b)

@@ -126,3 +126,14 @@ def test_non_discrete_checkpoint_is_rejected(tmp_path):
     torch.save(ws, fn)
     with pytest.raises(ValueError):
         weight_codec.enc_dec_from_file(fn)
+
+
+def test_single_valued_kernels_use_the_empty_codeword(tmp_path):
+    fn, ws = _fake_ckpt(tmp_path)
+    for k in weight_codec.keys_quantize:
+        ws[k] = torch.zeros_like(ws[k])
+    torch.save(ws, fn)
+    pack = weight_codec.enc_dec_from_file(fn)
+    assert pack['bit_stream'] == b'' and list(pack['inv_codebook']) == ['']
+    dec = weight_codec.entropy_decode(pack['bit_stream'], pack['inv_codebook'], pack['element_length'], pack['shape_list'])
+    assert all(not t.any() for t in dec)
