@@ -106,6 +106,11 @@ size_t nvf_channel_sum_workspace(int c);
 int nvf_channel_sum(const float* x, float* out, void* workspace, size_t workspace_bytes, int batch, int c,
                     int spatial, int accumulate, void* stream);
 
+/* several bias gradients at once (<= 12 tensors of the same batch): outs[i][c] = sum xs[i][b,c,:]; two launches */
+size_t nvf_multi_channel_sum_workspace(int total_channels);
+int nvf_multi_channel_sum(const float* const* xs, float* const* outs, const int* channels, const int* spatials,
+                          int ntensors, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- GDN / IGDN (gdn_3d.py:72-95, 137-159; LowerBound gdn_3d.py:13-29) ----------
  * beta = max(beta_hat, beta_bound)^2 - 2^-36, gamma = max(gamma_hat, 2^-18)^2 - 2^-36;
  * norm[c] = sqrt(beta[c] + sum_j gamma[c][j] x[j]^2); y = x / norm (GDN) or x * norm (IGDN).
@@ -121,7 +126,7 @@ int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* gamma_hat, c
 /* ---- latent quantisation + Gaussian rate (network.py:4514-4539, 145-161) --------
  * x_rounded = round(x) (half-to-even); v = x + (U-.5) (mode 0 = train) or x_rounded (mode 1 = eval);
  * bits[0] = sum -log2(max(Phi((v-mu+.5)/|s|) - Phi((v-mu-.5)/|s|), 1e-8)).
- * U comes from `u` if non-NULL, else Philox keyed by (seed, block_ids[b], step): one stream per
+ * U comes from `u` if non-NULL, else Philox keyed by (seed, block_ids[b], step + *step_dev): one stream per
  * leaf block, so the noise does not depend on how blocks are sharded over GPUs; block_ids NULL
  * means 0..B-1.  Gradients (each optional, overwritten) are already multiplied by the upstream
  * gradient g = g_host * (g_dev ? *g_dev : 1): dx = dx_addend + g dbits/dx (identity through the
@@ -130,13 +135,20 @@ int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* gamma_hat, c
 int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma, const float* mu,
                     float* x_rounded, float* bits, float* dx, const float* dx_addend, float* dsigma, float* dmu,
                     const float* g_dev, float g_host, int batch, int c, int spatial, int mode, uint64_t seed,
-                    uint64_t step, void* stream);
+                    uint64_t step, const uint64_t* step_dev, void* stream);
 
 /* ---- weight rate (network.py:4777-4778, 301-305): one quantised kernel ---------
  * bits[0] = sum -log2(max(Phi((w-mu+1/32)/|s|) - Phi((w-mu-1/32)/|s|), 1e-8)), w = round(16 k)/16.
  * dk[i], dsigma[0], dmu[0] (optional) get g * d bits / d(.), overwritten or accumulated. */
 int nvf_weight_rate(const float* kernel, int n, const float* sigma, const float* mu, float* bits, float* dk,
                     float* dsigma, float* dmu, const float* g_dev, float g_host, int accumulate, void* stream);
+
+/* all (<= 8) quantised kernels in two launches: bits[l] per layer; dks[l][i] += g dbits/dk (dks or entries may be
+ * NULL); dsigma[0], dmu[0] overwritten with the sum over layers (network.py:4777-4778). */
+size_t nvf_weight_rate_batch_workspace(void);
+int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const int* ns, int nlayers,
+                          const float* sigma, const float* mu, float* bits, float* dsigma, float* dmu,
+                          const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, void* stream);
 
 /* workspace (bytes) for the two-stage reductions of nvf_focal_loss / nvf_metrics */
 size_t nvf_reduce_workspace(void);

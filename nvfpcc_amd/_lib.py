@@ -30,11 +30,15 @@ PROTOTYPES = {
     "nvf_wgrad": (I, [P, P, P, P, Z] + [I] * 15 + [P]),
     "nvf_channel_sum_workspace": (Z, [I]),
     "nvf_channel_sum": (I, [P, P, P, Z, I, I, I, I, P]),
+    "nvf_multi_channel_sum_workspace": (Z, [I]),
+    "nvf_multi_channel_sum": (I, [P, P, P, P, I, I, P, Z, P]),
     "nvf_gdn_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "nvf_gdn_bwd_workspace": (Z, [I]),
     "nvf_gdn_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
-    "nvf_latent_rate": (I, [P] * 12 + [F, I, I, I, I, U, U, P]),
+    "nvf_latent_rate": (I, [P] * 12 + [F, I, I, I, I, U, U, P, P]),
     "nvf_weight_rate": (I, [P, I, P, P, P, P, P, P, P, F, I, P]),
+    "nvf_weight_rate_batch_workspace": (Z, []),
+    "nvf_weight_rate_batch": (I, [P, P, P, I, P, P, P, P, P, P, F, P, Z, P]),
     "nvf_reduce_workspace": (Z, []),
     "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, I, P]),
     "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P]),

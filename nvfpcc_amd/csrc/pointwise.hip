@@ -319,8 +319,10 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
                                                            const float* __restrict__ dx_addend,
                                                            float* __restrict__ dsigma, float* __restrict__ dmu,
                                                            const float* __restrict__ g_dev, float g_host, int batch,
-                                                           int c, int spatial, int mode, uint64_t seed, uint64_t step) {
+                                                           int c, int spatial, int mode, uint64_t seed, uint64_t step_in,
+                                                           const uint64_t* __restrict__ step_dev) {
   __shared__ float red[16];
+  const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
   const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
   float total_bits = 0.f;
@@ -368,12 +370,12 @@ extern "C" int nvf_latent_rate(const float* x, const float* u, const int64_t* bl
                                const float* mu, float* x_rounded, float* bits, float* dx, const float* dx_addend,
                                float* dsigma, float* dmu, const float* g_dev, float g_host, int batch, int c,
                                int spatial, int mode,
-                               uint64_t seed, uint64_t step, void* stream) {
+                               uint64_t seed, uint64_t step, const uint64_t* step_dev, void* stream) {
   if (!x || !sigma || !mu || batch <= 0 || c <= 0 || spatial <= 0) return NVF_EINVAL;
   if (mode != 0 && mode != 1) return NVF_EINVAL;
   latent_rate_kernel<<<1, 1024, 0, nvf_stream(stream)>>>(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dx_addend,
                                                          dsigma, dmu, g_dev, g_host, batch, c, spatial, mode, seed,
-                                                         step);
+                                                         step, step_dev);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -415,6 +417,107 @@ extern "C" int nvf_weight_rate(const float* kernel, int n, const float* sigma, c
   if (!kernel || !sigma || !mu || n <= 0) return NVF_EINVAL;
   weight_rate_kernel<<<1, 1024, 0, nvf_stream(stream)>>>(kernel, n, sigma, mu, bits, dk, dsigma, dmu, g_dev, g_host,
                                                          accumulate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// all quantised kernels of the decoder in two launches: workgroups own fixed chunks of one layer each and
+// write (bits, dsigma, dmu) partials; one workgroup then adds the partials in chunk order (reproducible).
+// dk is ADDED to the weight gradients already in place.
+struct WeightRateBatch {
+  const float* kernel[8];
+  float* dk[8];
+  int32_t n[8];
+  int32_t first_wg[9];   // workgroups [first_wg[l], first_wg[l+1]) belong to layer l
+  int32_t nlayers, chunk;
+};
+
+__global__ __launch_bounds__(256) void weight_rate_batch_kernel(WeightRateBatch b, const float* __restrict__ sigma,
+                                                                const float* __restrict__ mu,
+                                                                float* __restrict__ part,
+                                                                const float* __restrict__ g_dev, float g_host) {
+  __shared__ float red[16];
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+  const float sabs = fabsf(sigma[0]), m = mu[0];
+  int l = 0;
+  while (l + 1 < b.nlayers && (int)blockIdx.x >= b.first_wg[l + 1]) ++l;
+  const int lo = ((int)blockIdx.x - b.first_wg[l]) * b.chunk;
+  const int hi = min(lo + b.chunk, b.n[l]);
+  const float* k = b.kernel[l];
+  float* dk = b.dk[l];
+  float sb = 0.f, ss = 0.f, sm_ = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    float v = rintf(k[i] * 16.f) / 16.f;
+    RateTerm r = rate_term(v, m, sabs, 0.03125f, gsign);
+    sb += r.bits;
+    ss += r.dsig;
+    sm_ += r.dmu;
+    if (dk) dk[i] += g * r.dv;
+  }
+  float tb = nvf_block_sum(sb, red);
+  float tsg = nvf_block_sum(ss, red);
+  float tm = nvf_block_sum(sm_, red);
+  if (threadIdx.x == 0) {
+    part[3 * blockIdx.x] = tb;
+    part[3 * blockIdx.x + 1] = tsg;
+    part[3 * blockIdx.x + 2] = tm;
+  }
+}
+
+__global__ void weight_rate_batch_final(WeightRateBatch b, const float* __restrict__ part,
+                                        const float* __restrict__ sigma, float* __restrict__ bits,
+                                        float* __restrict__ dsigma, float* __restrict__ dmu,
+                                        const float* __restrict__ g_dev, float g_host) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  float acc_s = 0.f, acc_m = 0.f;
+  for (int l = 0; l < b.nlayers; ++l) {
+    float tb = 0.f;
+    for (int wg = b.first_wg[l]; wg < b.first_wg[l + 1]; ++wg) {
+      tb += part[3 * wg];
+      acc_s += part[3 * wg + 1];
+      acc_m += part[3 * wg + 2];
+    }
+    bits[l] = tb;
+  }
+  const float sraw = sigma[0];
+  const float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
+  if (dsigma) dsigma[0] = g * acc_s * sgn;
+  if (dmu) dmu[0] = g * acc_m;
+}
+
+extern "C" size_t nvf_weight_rate_batch_workspace(void) { return (size_t)3 * 512 * sizeof(float); }
+
+extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const int* ns, int nlayers,
+                                     const float* sigma, const float* mu, float* bits, float* dsigma, float* dmu,
+                                     const float* g_dev, float g_host, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (!kernels || !ns || nlayers <= 0 || nlayers > 8 || !sigma || !mu || !bits || !workspace) return NVF_EINVAL;
+  if (workspace_bytes < nvf_weight_rate_batch_workspace()) return NVF_EWORKSPACE;
+  WeightRateBatch b{};
+  long total = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    if (!kernels[i] || ns[i] <= 0) return NVF_EINVAL;
+    b.kernel[i] = kernels[i];
+    b.dk[i] = dks ? dks[i] : nullptr;
+    b.n[i] = ns[i];
+    total += ns[i];
+  }
+  b.nlayers = nlayers;
+  long chunk = (total + 255) / 256;          // <= ~256 + nlayers workgroups
+  if (chunk < 1024) chunk = 1024;
+  b.chunk = (int)chunk;
+  int wg = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    b.first_wg[i] = wg;
+    wg += (int)((ns[i] + chunk - 1) / chunk);
+  }
+  b.first_wg[nlayers] = wg;
+  if (wg > 512) return NVF_EINVAL;
+  hipStream_t s = nvf_stream(stream);
+  weight_rate_batch_kernel<<<wg, 256, 0, s>>>(b, sigma, mu, (float*)workspace, g_dev, g_host);
+  weight_rate_batch_final<<<1, 64, 0, s>>>(b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -289,23 +289,26 @@ static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* s
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
   wgrad_k4_mfma<C><<<nslab, 256, 0, s>>>(g, x, slabs, d);
-  wgrad_reduce<<<(4096 + 63) / 64, 256, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
+  wgrad_reduce<<<(4096 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
   return NVF_OK;
 }
 
-// dw[j] (+)= sum_g slabs[g][j], g ascending inside each of 4 interleaved slices, slices added 0..3
-__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab,
-                                                    int jtotal, int accumulate) {
-  __shared__ float part[4][64];
+// dw[j] (+)= sum_g slabs[g][j]: 16 interleaved slices of g per output (each summed in ascending g), then the
+// slices added in order 0..15 -- a fixed order, so the result is reproducible
+__global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                     int nslab, int jtotal, int accumulate) {
+  __shared__ float part[16][64];
   const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jl;
   float s = 0.f;
   if (j < jtotal)
-    for (int g = sl; g < nslab; g += 4) s += slabs[(size_t)g * jtotal + j];
+    for (int g = sl; g < nslab; g += 16) s += slabs[(size_t)g * jtotal + j];
   part[sl][jl] = s;
   __syncthreads();
   if (sl == 0 && j < jtotal) {
-    float t = ((part[0][jl] + part[1][jl]) + part[2][jl]) + part[3][jl];
+    float t = part[0][jl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][jl];
     dw[j] = accumulate ? dw[j] + t : t;
   }
 }
@@ -327,7 +330,7 @@ static int launch_wgrad(const float* p, const float* q, float* dw, float* slabs,
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
   wgrad_tiled<C><<<dim3(nslab, ygroups), C::NT, 0, s>>>(p, q, slabs, d);
-  wgrad_reduce<<<(d.jtotal + 63) / 64, 256, 0, s>>>(slabs, dw, nslab, d.jtotal, accumulate);
+  wgrad_reduce<<<(d.jtotal + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, d.jtotal, accumulate);
   return NVF_OK;
 }
 
@@ -442,6 +445,78 @@ extern "C" int nvf_channel_sum(const float* x, float* out, void* workspace, size
   hipStream_t s = nvf_stream(stream);
   channel_sum_partial<<<dim3(c, nchunk), 256, 0, s>>>(x, (float*)workspace, batch, c, spatial, (int)chunk);
   channel_sum_final<<<(c + 63) / 64, 64, 0, s>>>((const float*)workspace, out, c, nchunk, accumulate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// all bias gradients of a backward pass in two launches: out_i[c] = sum_{n,s} x_i[n,c,s] for up to 12 tensors
+// ---------------------------------------------------------------------------
+struct MultiSumDesc {
+  const float* x[12];
+  float* out[12];
+  int32_t c[12], spatial[12], chan_base[12];
+  int32_t ntensors, batch, total_channels, nchunk;
+};
+
+__global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
+  __shared__ float red[16];
+  const int gch = blockIdx.x, g = blockIdx.y;
+  int t = 0;
+  while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
+  const int ch = gch - d.chan_base[t], c = d.c[t], spatial = d.spatial[t];
+  const long total = (long)d.batch * spatial;
+  const long chunk = (total + d.nchunk - 1) / d.nchunk;
+  const long lo = (long)g * chunk;
+  long hi = lo + chunk;
+  if (hi > total) hi = total;
+  const float* x = d.x[t];
+  float s = 0.f;
+  for (long e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+    const long n = e / spatial, sp = e % spatial;
+    s += x[((size_t)n * c + ch) * spatial + sp];
+  }
+  s = nvf_block_sum(s, red);
+  if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
+}
+
+__global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part) {
+  const int gch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gch >= d.total_channels) return;
+  int t = 0;
+  while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
+  float s = 0.f;
+  for (int g = 0; g < d.nchunk; ++g) s += part[(size_t)g * d.total_channels + gch];
+  d.out[t][gch - d.chan_base[t]] = s;
+}
+
+extern "C" size_t nvf_multi_channel_sum_workspace(int total_channels) {
+  return (size_t)kSumChunks * total_channels * sizeof(float);
+}
+
+extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs, const int* channels,
+                                     const int* spatials, int ntensors, int batch, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (!xs || !outs || !channels || !spatials || ntensors <= 0 || ntensors > 12 || batch <= 0 || !workspace)
+    return NVF_EINVAL;
+  MultiSumDesc d{};
+  int base = 0;
+  long biggest = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    if (!xs[i] || !outs[i] || channels[i] <= 0 || spatials[i] <= 0) return NVF_EINVAL;
+    d.x[i] = xs[i]; d.out[i] = outs[i]; d.c[i] = channels[i]; d.spatial[i] = spatials[i]; d.chan_base[i] = base;
+    base += channels[i];
+    if ((long)batch * spatials[i] > biggest) biggest = (long)batch * spatials[i];
+  }
+  d.ntensors = ntensors; d.batch = batch; d.total_channels = base;
+  long nchunk = (biggest + 32767) / 32768;
+  if (nchunk > kSumChunks) nchunk = kSumChunks;
+  if (nchunk < 1) nchunk = 1;
+  d.nchunk = (int)nchunk;
+  if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
+  hipStream_t s = nvf_stream(stream);
+  multi_channel_sum_partial<<<dim3(base, d.nchunk), 256, 0, s>>>(d, (float*)workspace);
+  multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -66,6 +66,9 @@ class TrainEngine:
         self._flatten_parameters()
         self._build_layers()
         self.last = {}
+        # per-step scalars live in device memory while a captured HIP graph replays (see GraphedTrainStep)
+        self._step_dev = None     # uint64 noise-step offset
+        self._g_lat_dev = None    # lambda * w1 / n_pts
 
     # ------------------------------------------------------------------ parameters
     def _flatten_parameters(self):
@@ -121,7 +124,9 @@ class TrainEngine:
         self.nlayers = len(mods)
 
     def prepare_weights(self, q):
-        check(lib().nvf_prepare_weights(self.table.data_ptr(), self.nlayers, int(q), self.seed, self.noise_step, None,
+        sd = self._step_dev
+        check(lib().nvf_prepare_weights(self.table.data_ptr(), self.nlayers, int(q), self.seed,
+                                        0 if sd is not None else self.noise_step, None if sd is None else sd.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights")
 
     # ------------------------------------------------------------------ forward
@@ -140,8 +145,10 @@ class TrainEngine:
         g2 = net.latent_gen.gdn_2
         a["lat"] = ops.gdn_fwd(a["h"], g2.beta, g2.gamma, False)
         ec = net.entropy_coder
+        sd = self._step_dev
         a["x0"], a["lbits"], _, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
-                                                       block_ids=block_ids, seed=self.seed, step=self.noise_step)
+                                                       block_ids=block_ids, seed=self.seed,
+                                                       step=0 if sd is not None else self.noise_step, step_dev=sd)
         a["a0"] = self._convT(Ls["up0"], a["x0"], NONE)
         ig = net.reconstructor.activation
         a["h0"] = ops.gdn_fwd(a["a0"], ig.beta, ig.gamma, True)
@@ -160,7 +167,7 @@ class TrainEngine:
         """g_out: gradient w.r.t. the layer's pre-activation output.  Returns d x_in (masked by `mask`)."""
         if want_w:
             ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
-            ops.channel_sum(g_out, out=L.gb)
+            self._bias_jobs.append((g_out, L.gb))
         if not need_dx:
             return None
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
@@ -169,7 +176,7 @@ class TrainEngine:
     def _bwd_convT(self, L, g_out, x_in, mask, want_w, addend=None, need_dx=True):
         if want_w:
             ops.wgrad(x_in, g_out, 5, 2, L.pad, out_mode=0, out=L.gk)
-            ops.channel_sum(g_out, out=L.gb)
+            self._bias_jobs.append((g_out, L.gb))
         if not need_dx:
             return None
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
@@ -178,6 +185,7 @@ class TrainEngine:
     def backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
         """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g."""
         net, Ls = self.net, self.layers
+        self._bias_jobs = []
         loss = torch.zeros(4, device=self.dev)   # [main, head0, head1, unused]
         _, dl2 = ops.focal_loss(a["p2"], gt, dist, 0.9, 1.0, want_grad=True, loss_out=loss[0:1], chain_sigmoid=True)
         _, dl0 = ops.focal_loss(a["p0"], gt8, None, 0.85, want_grad=True, loss_out=loss[1:2], chain_sigmoid=True)
@@ -191,39 +199,36 @@ class TrainEngine:
         g1 = self._bwd_convT(Ls["up1"], g2, a["y1"], a["y1"], want_w, addend=t0)
         dh0 = self._bwd_convT(Ls["conv0"], g1, a["h0"], None, want_w)
         ig = net.reconstructor.activation
-        da0, dbeta, dgamma = ops.gdn_bwd(a["a0"], ig.beta, ig.gamma, dh0, True)
+        gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
+        da0, _, _ = ops.gdn_bwd(a["a0"], ig.beta, ig.gamma, dh0, True, gview("reconstructor.activation.beta"),
+                                None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape))
         dx0 = self._bwd_convT(Ls["up0"], da0, a["x0"], None, want_w)
         # latent rate (+ the decoder's gradient through the straight-through round)
         ec = net.entropy_coder
-        g_lat = self.lmbda * self.w1 / n_pts
-        _, _, dlat, dsig, dmu = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
-                                                block_ids=block_ids, want_grad=True, g_host=g_lat, seed=self.seed,
-                                                step=self.noise_step, dx_addend=dx0)
+        sd = self._step_dev
+        g_lat = self.lmbda * self.w1 / n_pts if self._g_lat_dev is None else 1.0
+        _, _, dlat, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
+                                           block_ids=block_ids, want_grad=True, g_host=g_lat, g_dev=self._g_lat_dev,
+                                           seed=self.seed, step=0 if sd is not None else self.noise_step, step_dev=sd,
+                                           dx_addend=dx0,
+                                           dsigma_out=gview("entropy_coder.sigma"), dmu_out=gview("entropy_coder.mu"))
         g2m = net.latent_gen.gdn_2
-        dh, dbeta_l, dgamma_l = ops.gdn_bwd(a["h"], g2m.beta, g2m.gamma, dlat, False)
+        dh, _, _ = ops.gdn_bwd(a["h"], g2m.beta, g2m.gamma, dlat, False, gview("latent_gen.gdn_2.beta"),
+                               None if not want_w else self._g("latent_gen.gdn_2.gamma").view(g2m.gamma.shape))
         de = self._bwd_conv(Ls["latent"], dh, a["e"], None, want_w, need_dx=want_emb)
-        if want_w:
-            self._g("reconstructor.activation.beta").copy_(dbeta)
-            self._g("reconstructor.activation.gamma").copy_(dgamma.reshape(-1))
-            self._g("latent_gen.gdn_2.beta").copy_(dbeta_l)
-            self._g("latent_gen.gdn_2.gamma").copy_(dgamma_l.reshape(-1))
-            self._g("entropy_coder.sigma").copy_(dsig)
-            self._g("entropy_coder.mu").copy_(dmu)
+        if want_w:   # every bias gradient of the pass in one two-launch reduction
+            ops.multi_channel_sum([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients
         lm = net.reconstructor.likelihood_model
         nbits = torch.empty(7, device=self.dev)
         g_net = self.lmbda * self.w2 / self.n_points_total
         gs, gm = self._g("reconstructor.likelihood_model.sigma"), self._g("reconstructor.likelihood_model.mu")
-        if want_w:
-            gs.zero_()
-            gm.zero_()
-        for i, n in enumerate(TRUNK):
-            L = Ls[n]
-            if want_w:   # dk is ADDED to the conv weight gradient wgrad already wrote; dsigma/dmu add up over layers
-                ops.weight_rate(L.mod.kernel, lm.sigma, lm.mu, bits_out=nbits[i:i + 1], dk=L.gk.view(-1), dsigma=gs,
-                                dmu=gm, g_host=g_net * self.rate_grad_scale, accumulate=True)
-            else:
-                ops.weight_rate(L.mod.kernel, lm.sigma, lm.mu, bits_out=nbits[i:i + 1])
+        kernels = [Ls[n].mod.kernel for n in TRUNK]
+        if want_w:   # dk is ADDED to the conv weight gradient wgrad already wrote; dsigma / dmu sum over the layers
+            ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
+                                  g_host=g_net * self.rate_grad_scale)
+        else:
+            ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
         self.last = {"loss_terms": loss, "latent_bits": a["lbits"], "net_bits": nbits, "n_pts": n_pts}
         return de
 
@@ -286,3 +291,62 @@ class TrainEngine:
         b_latent = t["latent_bits"].item() / t["n_pts"]
         b_net = t["net_bits"].sum().item() / self.n_points_total
         return float(terms[0] + terms[1] + terms[2] + self.lmbda * (b_latent * self.w1 + b_net * self.w2))
+
+
+class GraphedTrainStep:
+    """The mini-batch step body captured once into a HIP graph and replayed: removes ~90 host-side launches
+    per step (the reference pays ~1 500 aten dispatches).  Everything that changes from step to step comes
+    from device memory: block ids, the rate coefficient lambda*w1/n_pts and the noise-step counter.
+    Adam stays outside the graph (its bias correction depends on the step number)."""
+
+    def __init__(self, eng, batch, q):
+        self.eng, self.batch, self.q = eng, batch, q
+        dev = eng.dev
+        self.idx = torch.zeros(batch, dtype=torch.int64, device=dev)
+        self.idx_pin = torch.zeros(batch, dtype=torch.int64).pin_memory()
+        self.scal_pin = torch.zeros(2, dtype=torch.float64).pin_memory()
+        self.g_lat = torch.zeros(1, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int64, device=dev)
+        eng._step_dev, eng._g_lat_dev = self.step, self.g_lat
+        self.idx.copy_(torch.arange(batch) % eng.N_leaf)
+        self.g_lat.fill_(1.0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up: allocates the grow-only workspaces outside the graph
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        eng._step_dev, eng._g_lat_dev = None, None
+
+    def _body(self):
+        eng = self.eng
+        gt, dist, gt16, gt8 = eng._batch(self.idx)
+        eng.prepare_weights(self.q)
+        e = ops.gather_rows(eng.emb, self.idx)
+        a = eng.forward(e, "train", self.idx)
+        eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False)
+        self.out = a
+
+    def __call__(self, idx_host, n_pts=None):
+        eng = self.eng
+        idx_host = np.asarray(idx_host, np.int64)
+        assert idx_host.shape[0] == self.batch
+        if self.q == 1:
+            eng.noise_step += 1
+        if n_pts is None:
+            n_pts = float(eng.counts[idx_host].sum())
+        self.idx_pin.copy_(torch.from_numpy(idx_host))
+        self.idx.copy_(self.idx_pin, non_blocking=True)
+        self.g_lat.fill_(eng.lmbda * eng.w1 / n_pts)
+        self.step.fill_(eng.noise_step)
+        self.graph.replay()
+        eng.last["n_pts"] = n_pts
+        if eng.grad_hook is not None:
+            eng.grad_hook(eng.flat_g)
+        eng.opt_step += 1
+        ops.adam_step(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, eng.lr, eng.opt_step)
+        return self.out

@@ -154,6 +154,22 @@ def channel_sum(x, out=None, accumulate=False):
     return o
 
 
+def multi_channel_sum(tensors, outs):
+    """outs[i][c] = sum over batch and space of tensors[i][:, c]; all tensors share the batch size."""
+    import ctypes
+    _f32(*tensors)
+    _f32(*outs)
+    n = len(tensors)
+    B = tensors[0].shape[0]
+    xs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    os_ = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    cs = (ctypes.c_int * n)(*[t.shape[1] for t in tensors])
+    sp = (ctypes.c_int * n)(*[t[0, 0].numel() for t in tensors])
+    total = sum(t.shape[1] for t in tensors)
+    ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum")
+    check(lib().nvf_multi_channel_sum(xs, os_, cs, sp, n, B, _ptr(ws), ws.numel(), _stream()), "nvf_multi_channel_sum")
+
+
 # ---------------------------------------------------------------- GDN
 def gdn_fwd(x, beta_hat, gamma_hat, inverse):
     _f32(x, beta_hat, gamma_hat)
@@ -164,12 +180,12 @@ def gdn_fwd(x, beta_hat, gamma_hat, inverse):
     return y
 
 
-def gdn_bwd(x, beta_hat, gamma_hat, dy, inverse):
-    _f32(x, beta_hat, gamma_hat, dy)
+def gdn_bwd(x, beta_hat, gamma_hat, dy, inverse, dbeta_out=None, dgamma_out=None):
+    _f32(x, beta_hat, gamma_hat, dy, dbeta_out, dgamma_out)
     B, c = x.shape[0], x.shape[1]
     dx = torch.empty_like(x)
-    dbeta = torch.empty_like(beta_hat)
-    dgamma = torch.empty_like(gamma_hat)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty_like(beta_hat)
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty_like(gamma_hat)
     ws = workspace(lib().nvf_gdn_bwd_workspace(c), x.device, "gdn")
     check(lib().nvf_gdn_bwd(_ptr(x), _ptr(beta_hat), _ptr(gamma_hat), _ptr(dy), _ptr(dx), _ptr(dbeta), _ptr(dgamma),
                             _ptr(ws), ws.numel(), B, c, x[0, 0].numel(), int(inverse), _stream()), "nvf_gdn_bwd")
@@ -178,7 +194,7 @@ def gdn_bwd(x, beta_hat, gamma_hat, dy, inverse):
 
 # ---------------------------------------------------------------- rates
 def latent_rate(x, sigma, mu, mode, u=None, block_ids=None, want_grad=False, g_dev=None, g_host=1.0, seed=0,
-                step=0, dx_addend=None):
+                step=0, dx_addend=None, dsigma_out=None, dmu_out=None, step_dev=None):
     """Returns (x_rounded, bits[1], dx, dsigma, dmu); the gradient outputs are None unless want_grad."""
     _f32(x, sigma, mu, u, g_dev, dx_addend)
     _chk(block_ids)
@@ -186,12 +202,13 @@ def latent_rate(x, sigma, mu, mode, u=None, block_ids=None, want_grad=False, g_d
     xr = torch.empty_like(x)
     bits = torch.empty(1, device=x.device)
     dx = torch.empty_like(x) if want_grad else None
-    ds = torch.empty(c, device=x.device) if want_grad else None
-    dm = torch.empty(c, device=x.device) if want_grad else None
+    ds = dsigma_out if dsigma_out is not None else (torch.empty(c, device=x.device) if want_grad else None)
+    dm = dmu_out if dmu_out is not None else (torch.empty(c, device=x.device) if want_grad else None)
     check(lib().nvf_latent_rate(_ptr(x), _ptr(u), _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(xr), _ptr(bits),
                                 _ptr(dx), _ptr(dx_addend), _ptr(ds), _ptr(dm), _ptr(g_dev), float(g_host), B, c,
                                 x[0, 0].numel(),
-                                0 if mode == "train" else 1, int(seed), int(step), _stream()), "nvf_latent_rate")
+                                0 if mode == "train" else 1, int(seed), int(step), _ptr(step_dev), _stream()),
+          "nvf_latent_rate")
     return xr, bits, dx, ds, dm
 
 
@@ -202,6 +219,21 @@ def weight_rate(kernel, sigma, mu, bits_out=None, dk=None, dsigma=None, dmu=None
     check(lib().nvf_weight_rate(_ptr(kernel), kernel.numel(), _ptr(sigma), _ptr(mu), _ptr(bits), _ptr(dk),
                                 _ptr(dsigma), _ptr(dmu), _ptr(g_dev), float(g_host), int(accumulate), _stream()),
           "nvf_weight_rate")
+    return bits
+
+
+def weight_rate_batch(kernels, dks, sigma, mu, bits, dsigma=None, dmu=None, g_dev=None, g_host=1.0):
+    """bits[l] for every kernel; dks[l] (or None) += g dbits/dk; dsigma/dmu overwritten with the layer sum."""
+    import ctypes
+    _f32(*kernels)
+    n = len(kernels)
+    ks = (ctypes.c_void_p * n)(*[k.data_ptr() for k in kernels])
+    ds = (ctypes.c_void_p * n)(*[(d.data_ptr() if d is not None else None) for d in dks]) if dks is not None else None
+    ns = (ctypes.c_int * n)(*[k.numel() for k in kernels])
+    ws = workspace(lib().nvf_weight_rate_batch_workspace(), kernels[0].device, "wrate")
+    check(lib().nvf_weight_rate_batch(ks, ds, ns, n, _ptr(sigma), _ptr(mu), _ptr(bits), _ptr(dsigma), _ptr(dmu),
+                                      _ptr(g_dev), float(g_host), _ptr(ws), ws.numel(), _stream()),
+          "nvf_weight_rate_batch")
     return bits
 
 
