@@ -238,8 +238,12 @@ extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bi
   // variant 0: the tuned configuration; 1: one-thread-per-output kernel; >= 2: alternatives kept for tuning runs.
   // Small batches cannot fill 256 CUs with whole-Cout tiles, so they take the Cout-split (COG) instantiations.
   if (variant == 0 && batch <= 64) {
-    if (cin == 8 && cout == 8 && k == 5 && stride == 2 && wout >= 9 && wout <= 16) variant = 5;   // up2 backward-data
-    if (cin == 8 && cout == 16 && k == 5 && stride == 2 && wout >= 5 && wout <= 8) variant = 5;   // up1 backward-data
+    if (cin == 8 && cout == 8 && k == 5 && stride == 2 && wout >= 9 && wout <= 16) variant = 9;   // up2 backward-data
+    if (cin == 8 && cout == 16 && k == 5 && stride == 2 && wout >= 5 && wout <= 8) variant = 9;   // up1 backward-data
+    if (cin == 16 && cout == 8 && k == 5 && stride == 2 && wout >= 3 && wout <= 4) variant = 9;   // conv0 backward-data
+    if (cin == 8 && cout == 8 && k == 4 && stride == 1 && wout >= 9 && wout <= 16) variant = 9;   // conv1 forward
+    if (cin == 8 && cout == 8 && k == 4 && stride == 1 && wout >= 17 && wout <= 20) variant = 10; // conv1 backward-data
+    if (cin == 1 && cout == 16 && k == 3 && wout <= 8) variant = 1;                               // conv0_cls backward-data
   }
   if (variant != 1) {
 #define NVF_GC(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU, COG)                                        \
@@ -281,6 +285,24 @@ extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bi
     NVF_G(2, 8, 16, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0)
     NVF_G(3, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 4, 0)
     NVF_G(4, 8, 16, 5, 2, 5, 8, 4, 2, 8, 4, 4, 0)
+    NVF_GC(9, 8, 8, 4, 1, 21, 32, 4, 8, 8, 8, 2, 0, 4)
+    NVF_GC(10, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 4)
+    NVF_GC(11, 8, 8, 4, 1, 21, 32, 8, 4, 8, 8, 2, 0, 4)
+    NVF_GC(9, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0, 4)
+    NVF_GC(10, 8, 8, 4, 1, 33, 40, 4, 9, 7, 8, 2, 0, 4)
+    NVF_GC(9, 8, 8, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 4)
+    NVF_GC(10, 8, 8, 4, 1, 9, 16, 4, 4, 16, 4, 2, 0, 4)
+    NVF_GC(9, 8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0, 4)
+    NVF_GC(10, 8, 8, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0, 4)
+    NVF_GC(7, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 4)
+    NVF_GC(8, 8, 16, 5, 2, 5, 8, 2, 4, 8, 2, 2, 0, 4)
+    NVF_GC(9, 8, 16, 5, 2, 5, 8, 2, 4, 4, 4, 4, 0, 2)
+    NVF_GC(7, 8, 8, 5, 2, 9, 16, 2, 8, 8, 2, 2, 0, 4)
+    NVF_GC(8, 8, 8, 5, 2, 9, 16, 4, 4, 8, 2, 2, 0, 4)
+    NVF_GC(9, 8, 8, 5, 2, 9, 16, 2, 8, 4, 4, 2, 0, 4)
+    NVF_GC(7, 16, 8, 5, 2, 3, 4, 2, 2, 4, 2, 4, 0, 1)
+    NVF_GC(8, 16, 8, 5, 2, 3, 4, 2, 2, 4, 4, 8, 0, 1)
+    NVF_GC(9, 16, 8, 5, 2, 3, 4, 2, 2, 2, 2, 4, 0, 1)
     NVF_GC(5, 8, 16, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0, 4)
     NVF_GC(6, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 4, 0, 4)
     NVF_GC(5, 8, 8, 5, 2, 9, 16, 2, 8, 8, 4, 2, 0, 4)
@@ -490,7 +512,11 @@ extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float*
   ConvDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0};
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
-  if (variant == 0 && batch <= 64 && cin == 16 && cout == 8 && win == 8) variant = 6;   // up1 forward, small batch
+  if (variant == 0 && batch <= 64) {
+    if (cin == 16 && cout == 8 && win == 8) variant = 7;    // up1 forward
+    if (cin == 8 && cout == 8 && win == 16) variant = 7;    // up2 forward
+    if (cin == 8 && cout == 16 && win == 4) variant = 8;    // conv0 forward
+  }
   if (variant != 1) {
 #define NVF_T(VAR, CI, CO, WIN, VX, NCX, TY, TZ, COG)                      \
   if (rc == 1 && variant == VAR && cin == CI && cout == CO && win == WIN) \
@@ -502,6 +528,14 @@ extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float*
     NVF_T(0, 16, 16, 16, 4, 5, 6, 6, 0)   // up2 wide
     NVF_T(0, 32, 16, 8, 4, 3, 5, 5, 0)    // up1 wide
     NVF_T(0, 16, 32, 4, 2, 2, 4, 4, 4)    // conv0 wide
+    NVF_T(7, 16, 8, 8, 2, 5, 5, 2, 2)
+    NVF_T(8, 16, 8, 8, 2, 5, 5, 1, 4)
+    NVF_T(9, 16, 8, 8, 2, 5, 10, 1, 4)
+    NVF_T(7, 8, 8, 16, 2, 9, 6, 2, 4)
+    NVF_T(8, 8, 8, 16, 2, 9, 3, 3, 4)
+    NVF_T(9, 8, 8, 16, 2, 9, 6, 3, 2)
+    NVF_T(7, 8, 16, 4, 2, 2, 4, 2, 2)
+    NVF_T(8, 8, 16, 4, 2, 2, 4, 4, 1)
     NVF_T(2, 8, 8, 16, 4, 5, 6, 3, 0)
     NVF_T(3, 8, 8, 16, 2, 9, 6, 3, 0)
     NVF_T(4, 8, 8, 16, 2, 9, 6, 3, 4)

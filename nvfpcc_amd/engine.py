@@ -32,6 +32,14 @@ _DESC = np.dtype([("kernel", "<u8"), ("kernel_init", "<u8"), ("b", "<u8"), ("b_i
                   ("kind", "<i4"), ("quantised", "<i4"), ("layer_id", "<i4"), ("nbias", "<i4"), ("pad", "<i4")])
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad")
 
@@ -68,6 +76,11 @@ class TrainEngine:
         self.last = {}
         # per-step scalars live in device memory while a captured HIP graph replays (see GraphedTrainStep)
         self._step_dev = None     # uint64 noise-step offset
+        # second HIP stream: weight gradients, head backward-data, bias sums and the weight-rate term do not sit on
+        # the backward-data chain, so they overlap with it (at batch 16 one kernel cannot fill 256 CUs by itself)
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.allow_overlap = True
+        self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
 
     # ------------------------------------------------------------------ parameters
@@ -163,46 +176,88 @@ class TrainEngine:
         return a
 
     # ------------------------------------------------------------------ backward
-    def _bwd_conv(self, L, g_out, x_in, mask, want_w, addend=None, need_dx=True):
-        """g_out: gradient w.r.t. the layer's pre-activation output.  Returns d x_in (masked by `mask`)."""
-        if want_w:
-            ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
-            self._bias_jobs.append((g_out, L.gb))
-        if not need_dx:
-            return None
+    def _fork(self):
+        """Side stream waits for everything issued so far on the current (main) stream."""
+        if self.overlap:
+            self.side.wait_stream(torch.cuda.current_stream())
+
+    def _on_side(self):
+        return torch.cuda.stream(self.side) if self.overlap else _NullCtx()
+
+    def _wgrad_conv(self, L, g_out, x_in):
+        ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
+        self._bias_jobs.append((g_out, L.gb))
+
+    def _wgrad_convT(self, L, g_out, x_in):
+        ops.wgrad(x_in, g_out, 5, 2, L.pad, out_mode=0, out=L.gk)
+        self._bias_jobs.append((g_out, L.gb))
+
+    def _dx_conv(self, L, g_out, x_in, mask=None, addend=None):
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
                                  addend=addend, mask=mask)
 
-    def _bwd_convT(self, L, g_out, x_in, mask, want_w, addend=None, need_dx=True):
-        if want_w:
-            ops.wgrad(x_in, g_out, 5, 2, L.pad, out_mode=0, out=L.gk)
-            self._bias_jobs.append((g_out, L.gb))
-        if not need_dx:
-            return None
+    def _dx_convT(self, L, g_out, x_in, mask=None, addend=None):
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)
 
     def backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
-        """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g."""
+        """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g.
+
+        Main stream: the backward-data chain.  Side stream: head backward-data (t0, t1), every weight gradient,
+        the bias sums and the weight-rate term; each side job waits for the chain tensor it consumes."""
         net, Ls = self.net, self.layers
+        main = torch.cuda.current_stream()
+        self.overlap = self.allow_overlap and a["e"].shape[0] <= 64   # large batches fill the chip by themselves
         self._bias_jobs = []
         loss = torch.zeros(4, device=self.dev)   # [main, head0, head1, unused]
+        nbits = torch.empty(7, device=self.dev)
         _, dl2 = ops.focal_loss(a["p2"], gt, dist, 0.9, 1.0, want_grad=True, loss_out=loss[0:1], chain_sigmoid=True)
         _, dl0 = ops.focal_loss(a["p0"], gt8, None, 0.85, want_grad=True, loss_out=loss[1:2], chain_sigmoid=True)
         _, dl1 = ops.focal_loss(a["p1"], gt16, None, 0.85, want_grad=True, loss_out=loss[2:3], chain_sigmoid=True)
-        g5 = self._bwd_conv(Ls["conv2_cls"], dl2, a["y5"], a["y5"], want_w)
-        g4 = self._bwd_conv(Ls["conv2"], g5, a["y4"], a["y4"], want_w)
-        t1 = self._bwd_conv(Ls["conv1_cls"], dl1, a["y3"], None, want_w)
-        g3 = self._bwd_convT(Ls["up2"], g4, a["y3"], a["y3"], want_w, addend=t1)
-        g2 = self._bwd_conv(Ls["conv1"], g3, a["y2"], a["y2"], want_w)
-        t0 = self._bwd_conv(Ls["conv0_cls"], dl0, a["y1"], None, want_w)
-        g1 = self._bwd_convT(Ls["up1"], g2, a["y1"], a["y1"], want_w, addend=t0)
-        dh0 = self._bwd_convT(Ls["conv0"], g1, a["h0"], None, want_w)
+        ev_t1 = ev_t0 = None
+        self._fork()
+        with self._on_side():
+            t1 = self._dx_conv(Ls["conv1_cls"], dl1, a["y3"])
+            ev_t1 = torch.cuda.Event() if self.overlap else None
+            if ev_t1 is not None:
+                ev_t1.record()
+            t0 = self._dx_conv(Ls["conv0_cls"], dl0, a["y1"])
+            ev_t0 = torch.cuda.Event() if self.overlap else None
+            if ev_t0 is not None:
+                ev_t0.record()
+            if want_w:
+                self._wgrad_conv(Ls["conv2_cls"], dl2, a["y5"])
+                self._wgrad_conv(Ls["conv1_cls"], dl1, a["y3"])
+                self._wgrad_conv(Ls["conv0_cls"], dl0, a["y1"])
+
+        def side_wgrad(fn, L, g, x):
+            if not want_w:
+                return
+            self._fork()
+            with self._on_side():
+                fn(L, g, x)
+
+        g5 = self._dx_conv(Ls["conv2_cls"], dl2, a["y5"], mask=a["y5"])
+        side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
+        g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])
+        side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"])
+        if ev_t1 is not None:
+            main.wait_event(ev_t1)
+        g3 = self._dx_convT(Ls["up2"], g4, a["y3"], mask=a["y3"], addend=t1)
+        side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
+        g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
+        side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"])
+        if ev_t0 is not None:
+            main.wait_event(ev_t0)
+        g1 = self._dx_convT(Ls["up1"], g2, a["y1"], mask=a["y1"], addend=t0)
+        side_wgrad(self._wgrad_convT, Ls["conv0"], g1, a["h0"])
+        dh0 = self._dx_convT(Ls["conv0"], g1, a["h0"])
         ig = net.reconstructor.activation
         gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
         da0, _, _ = ops.gdn_bwd(a["a0"], ig.beta, ig.gamma, dh0, True, gview("reconstructor.activation.beta"),
                                 None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape))
-        dx0 = self._bwd_convT(Ls["up0"], da0, a["x0"], None, want_w)
+        side_wgrad(self._wgrad_convT, Ls["up0"], da0, a["x0"])
+        dx0 = self._dx_convT(Ls["up0"], da0, a["x0"])
         # latent rate (+ the decoder's gradient through the straight-through round)
         ec = net.entropy_coder
         sd = self._step_dev
@@ -215,20 +270,24 @@ class TrainEngine:
         g2m = net.latent_gen.gdn_2
         dh, _, _ = ops.gdn_bwd(a["h"], g2m.beta, g2m.gamma, dlat, False, gview("latent_gen.gdn_2.beta"),
                                None if not want_w else self._g("latent_gen.gdn_2.gamma").view(g2m.gamma.shape))
-        de = self._bwd_conv(Ls["latent"], dh, a["e"], None, want_w, need_dx=want_emb)
-        if want_w:   # every bias gradient of the pass in one two-launch reduction
-            ops.multi_channel_sum([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
-        # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients
+        side_wgrad(self._wgrad_conv, Ls["latent"], dh, a["e"])
+        de = self._dx_conv(Ls["latent"], dh, a["e"]) if want_emb else None
+        # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
+        # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model
-        nbits = torch.empty(7, device=self.dev)
         g_net = self.lmbda * self.w2 / self.n_points_total
         gs, gm = self._g("reconstructor.likelihood_model.sigma"), self._g("reconstructor.likelihood_model.mu")
         kernels = [Ls[n].mod.kernel for n in TRUNK]
-        if want_w:   # dk is ADDED to the conv weight gradient wgrad already wrote; dsigma / dmu sum over the layers
-            ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
-                                  g_host=g_net * self.rate_grad_scale)
-        else:
-            ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
+        self._fork()
+        with self._on_side():
+            if want_w:
+                ops.multi_channel_sum([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
+                ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
+                                      g_host=g_net * self.rate_grad_scale)
+            else:
+                ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
+        if self.overlap:
+            main.wait_stream(self.side)      # join: nothing below (Adam, frees) may pass the side work
         self.last = {"loss_terms": loss, "latent_bits": a["lbits"], "net_bits": nbits, "n_pts": n_pts}
         return de
 
