@@ -162,6 +162,12 @@ int nvf_focal_loss(const float* p, const float* gt, const float* dist, float alp
                    float* dp, const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, int64_t n,
                    int accumulate, int chain_sigmoid, void* stream);
 
+/* up to 3 focal terms (the objective's main output + two heads, NVFPCC.py:166-184) in one launch pair;
+ * loss[t] overwritten; dps[t] (optional) = d loss_t / d p_t, times p(1-p) with chain_sigmoid. */
+int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const float* const* dists,
+                         float* const* dps, const float* alphas, const float* betas, const int64_t* ns, int nterm,
+                         float* loss, int chain_sigmoid, void* workspace, size_t workspace_bytes, void* stream);
+
 /* metrics (utils/loss.py:74-84, 113-121): out[0..5] (+)= tp, ap, tn, an at thh_acc; sse, denom at thh_sse */
 int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
                 void* workspace, size_t workspace_bytes, int64_t n, int accumulate, void* stream);
@@ -188,6 +194,10 @@ int nvf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * dst[idx[r],:] += src[r,:] (indices unique within a call) */
 int nvf_gather_rows(const float* src, const int64_t* idx, float* dst, int rows, int width, void* stream);
 int nvf_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int width, void* stream);
+
+/* up to 6 gathers sharing one index vector: dsts[t][r,:] = srcs[t][idx[r],:] */
+int nvf_gather_rows_multi(const float* const* srcs, float* const* dsts, const int* widths, int n,
+                          const int64_t* idx, int rows, void* stream);
 
 /* U[0,1) floats, Philox4x32-10 keyed by (seed, stream_id), counter = element index */
 int nvf_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "nvf_weight_rate_batch": (I, [P, P, P, I, P, P, P, P, P, P, F, P, Z, P]),
     "nvf_reduce_workspace": (Z, []),
     "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, I, P]),
+    "nvf_focal_loss_multi": (I, [P, P, P, P, P, P, P, I, P, I, P, Z, P]),
     "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P]),
     "nvf_sigmoid_bwd": (I, [P, P, P, L, P]),
     "nvf_relu_bwd": (I, [P, P, P, L, P]),
@@ -49,6 +50,7 @@ PROTOTYPES = {
     "nvf_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
+    "nvf_gather_rows_multi": (I, [P, P, P, I, P, I, P]),
     "nvf_uniform": (I, [P, L, U, U, P]),
     "nvf_threshold_count": (I, [P, F, P, I, I, P]),
     "nvf_threshold_compact": (I, [P, F, P, P, P, I, I, P]),

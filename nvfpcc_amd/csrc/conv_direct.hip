@@ -524,6 +524,8 @@ extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float*
     NVF_T(0, 8, 8, 16, 2, 9, 6, 3, 4)     // up2 narrow: 16^3 -> 35^3 (18 cells / axis), Cout split 2 ways
     NVF_T(0, 16, 8, 8, 2, 5, 5, 5, 0)     // up1 narrow: 8^3 -> 19^3 (10 cells / axis)
     NVF_T(6, 16, 8, 8, 2, 5, 5, 5, 4)     // up1 narrow, small batch
+    NVF_T(0, 3, 8, 2, 2, 1, 2, 2, 2)      // up0 narrow (ch = 3): 2^3 -> 4^3 (2 cells / axis)
+    NVF_T(0, 8, 16, 2, 2, 1, 2, 2, 4)     // up0 wide (ch = 8)
     NVF_T(0, 8, 16, 4, 2, 2, 4, 4, 2)     // conv0 narrow: 4^3 -> 8^3 (4 cells / axis), Cout split 8 ways
     NVF_T(0, 16, 16, 16, 4, 5, 6, 6, 0)   // up2 wide
     NVF_T(0, 32, 16, 8, 4, 3, 5, 5, 0)    // up1 wide

@@ -575,6 +575,81 @@ extern "C" int nvf_focal_loss(const float* p, const float* gt, const float* dist
   return NVF_OK;
 }
 
+// the three focal terms of the objective (main output + two heads, NVFPCC.py:166-184) in one launch pair
+struct FocalMulti {
+  const float* p[3];
+  const float* gt[3];
+  const float* dist[3];
+  float* dp[3];
+  float alpha[3], beta[3];
+  long n[3];
+  int nwg[3];
+};
+
+__global__ __launch_bounds__(256) void focal_multi_kernel(FocalMulti m, float* __restrict__ part, int chain_sigmoid) {
+  __shared__ float red[16];
+  const int t = blockIdx.y;
+  if ((int)blockIdx.x >= m.nwg[t]) return;
+  const float* p = m.p[t];
+  const float* gt = m.gt[t];
+  const float* dist = m.dist[t];
+  float* dp = m.dp[t];
+  const float a1 = m.alpha[t], a0 = 1.f - m.alpha[t], beta = m.beta[t];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m.n[t]; i += (long)m.nwg[t] * blockDim.x) {
+    float pv = p[i], gv = gt[i];
+    bool occ = gv != 0.f;
+    float F = occ ? pv : 1.f - pv;
+    float at = occ ? a1 : a0;
+    float w = 1.f;
+    if (dist) w = dist[i] + (occ ? beta : 0.f);
+    float Fc = fmaxf(F, 1e-9f);
+    float om = 1.f - Fc;
+    float lg = logf(Fc);
+    s += -1.f * at * (om * om) * w * lg;
+    if (dp) {
+      float d = 0.f;
+      if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
+      float dd = occ ? d : -d;
+      dp[i] = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
+    }
+  }
+  float tot = nvf_block_sum(s, red);
+  if (threadIdx.x == 0) part[t * kLossMaxWG + blockIdx.x] = tot;
+}
+
+__global__ void focal_multi_final(FocalMulti m, const float* __restrict__ part, float* __restrict__ loss, int nterm) {
+  int t = threadIdx.x;
+  if (t >= nterm) return;
+  float s = 0.f;
+  for (int g = 0; g < m.nwg[t]; ++g) s += part[t * kLossMaxWG + g];
+  loss[t] = s;
+}
+
+extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const float* const* dists,
+                                    float* const* dps, const float* alphas, const float* betas, const int64_t* ns,
+                                    int nterm, float* loss, int chain_sigmoid, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!ps || !gts || !alphas || !ns || !loss || !workspace || nterm <= 0 || nterm > 3) return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  FocalMulti m{};
+  int maxwg = 1;
+  for (int t = 0; t < nterm; ++t) {
+    if (!ps[t] || !gts[t] || ns[t] <= 0) return NVF_EINVAL;
+    m.p[t] = ps[t]; m.gt[t] = gts[t]; m.dist[t] = dists ? dists[t] : nullptr; m.dp[t] = dps ? dps[t] : nullptr;
+    m.alpha[t] = alphas[t]; m.beta[t] = betas ? betas[t] : 0.f; m.n[t] = (long)ns[t];
+    int nwg = (int)((ns[t] + 256 * 8 - 1) / (256 * 8));
+    if (nwg > kLossMaxWG) nwg = kLossMaxWG;
+    m.nwg[t] = nwg;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  hipStream_t s = nvf_stream(stream);
+  focal_multi_kernel<<<dim3(maxwg, nterm), 256, 0, s>>>(m, (float*)workspace, chain_sigmoid);
+  focal_multi_final<<<1, 64, 0, s>>>(m, (const float*)workspace, loss, nterm);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 // metrics (utils/loss.py:74-84, 113-121): tp, ap, tn, an at thh_acc; sse, denom at thh_sse
 __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ p, const float* __restrict__ gt,
                                                       const float* __restrict__ dist, float thh_acc, float thh_sse,
@@ -748,6 +823,56 @@ extern "C" int nvf_scatter_add_rows(const float* src, const int64_t* idx, float*
   if (!src || !idx || !dst || rows <= 0 || width <= 0) return NVF_EINVAL;
   scatter_add_rows_kernel<<<NVF_GRID((long)rows * width, 256), 256, 0, nvf_stream(stream)>>>(src, idx, dst, rows,
                                                                                             width);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// up to 6 row gathers that share one index vector (the mini-batch's grids, pyramid and latents) in one launch
+struct GatherMulti {
+  const float* src[6];
+  float* dst[6];
+  int32_t width[6];
+  int32_t n;
+};
+
+__global__ void gather_rows_multi_kernel(GatherMulti g, const int64_t* __restrict__ idx, int rows) {
+  const int t = blockIdx.y;
+  if (t >= g.n) return;
+  const int width = g.width[t];
+  const long total = (long)rows * width;
+  const float* src = g.src[t];
+  float* dst = g.dst[t];
+  if ((width & 3) == 0) {
+    const long total4 = total >> 2;
+    const int w4 = width >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+      const long r = i / w4;
+      const int c = (int)(i - r * w4);
+      ((float4*)dst)[i] = ((const float4*)src)[idx[r] * w4 + c];
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const long r = i / width;
+      dst[i] = src[idx[r] * width + (i - r * width)];
+    }
+  }
+}
+
+extern "C" int nvf_gather_rows_multi(const float* const* srcs, float* const* dsts, const int* widths, int n,
+                                     const int64_t* idx, int rows, void* stream) {
+  if (!srcs || !dsts || !widths || !idx || n <= 0 || n > 6 || rows <= 0) return NVF_EINVAL;
+  GatherMulti g{};
+  long biggest = 0;
+  for (int t = 0; t < n; ++t) {
+    if (!srcs[t] || !dsts[t] || widths[t] <= 0) return NVF_EINVAL;
+    g.src[t] = srcs[t]; g.dst[t] = dsts[t]; g.width[t] = widths[t];
+    if ((long)rows * widths[t] > biggest) biggest = (long)rows * widths[t];
+  }
+  g.n = n;
+  long wg = (biggest / 4 + 255) / 256;
+  if (wg > 1024) wg = 1024;
+  if (wg < 1) wg = 1;
+  gather_rows_multi_kernel<<<dim3((unsigned)wg, n), 256, 0, nvf_stream(stream)>>>(g, idx, rows);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

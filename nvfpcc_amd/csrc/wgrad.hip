@@ -461,22 +461,26 @@ struct MultiSumDesc {
 
 __global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
   __shared__ float red[16];
-  const int gch = blockIdx.x, g = blockIdx.y;
+  const int gch = blockIdx.x, g = blockIdx.y;       // g: group of consecutive batch entries
   int t = 0;
   while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
   const int ch = gch - d.chan_base[t], c = d.c[t], spatial = d.spatial[t];
-  const long total = (long)d.batch * spatial;
-  const long chunk = (total + d.nchunk - 1) / d.nchunk;
-  const long lo = (long)g * chunk;
-  long hi = lo + chunk;
-  if (hi > total) hi = total;
+  const int per = (d.batch + d.nchunk - 1) / d.nchunk;
+  const int n_lo = g * per, n_hi = min(n_lo + per, d.batch);
   const float* x = d.x[t];
-  float s = 0.f;
-  for (long e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-    const long n = e / spatial, sp = e % spatial;
-    s += x[((size_t)n * c + ch) * spatial + sp];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int n = n_lo; n < n_hi; ++n) {
+    const float* row = x + ((size_t)n * c + ch) * spatial;     // one contiguous row per (n, channel)
+    if ((spatial & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < spatial; i += blockDim.x * 4) {
+        const float4 v = *(const float4*)(row + i);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+      }
+    } else {
+      for (int i = threadIdx.x; i < spatial; i += blockDim.x) s0 += row[i];
+    }
   }
-  s = nvf_block_sum(s, red);
+  const float s = nvf_block_sum((s0 + s1) + (s2 + s3), red);
   if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
 }
 
@@ -509,9 +513,8 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
     if ((long)batch * spatials[i] > biggest) biggest = (long)batch * spatials[i];
   }
   d.ntensors = ntensors; d.batch = batch; d.total_channels = base;
-  long nchunk = (biggest + 32767) / 32768;
-  if (nchunk > kSumChunks) nchunk = kSumChunks;
-  if (nchunk < 1) nchunk = 1;
+  (void)biggest;
+  long nchunk = batch < kSumChunks ? batch : kSumChunks;   // groups of consecutive batch entries
   d.nchunk = (int)nchunk;
   if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);

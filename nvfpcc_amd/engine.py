@@ -165,14 +165,21 @@ class TrainEngine:
         a["a0"] = self._convT(Ls["up0"], a["x0"], NONE)
         ig = net.reconstructor.activation
         a["h0"] = ops.gdn_fwd(a["a0"], ig.beta, ig.gamma, True)
+        self.overlap = self.allow_overlap and e.shape[0] <= 64   # large batches fill the chip by themselves
         a["y1"] = self._convT(Ls["conv0"], a["h0"], R)
-        a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
+        self._fork()
+        with self._on_side():                       # the two coarse heads run beside the trunk
+            a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
         a["y2"] = self._convT(Ls["up1"], a["y1"], R)
         a["y3"] = self._conv(Ls["conv1"], a["y2"], R)
-        a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
+        self._fork()
+        with self._on_side():
+            a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
         a["y4"] = self._convT(Ls["up2"], a["y3"], R)
         a["y5"] = self._conv(Ls["conv2"], a["y4"], R)
         a["p2"] = self._conv(Ls["conv2_cls"], a["y5"], S)
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.side)
         return a
 
     # ------------------------------------------------------------------ backward
@@ -207,13 +214,12 @@ class TrainEngine:
         the bias sums and the weight-rate term; each side job waits for the chain tensor it consumes."""
         net, Ls = self.net, self.layers
         main = torch.cuda.current_stream()
-        self.overlap = self.allow_overlap and a["e"].shape[0] <= 64   # large batches fill the chip by themselves
+        self.overlap = self.allow_overlap and a["e"].shape[0] <= 64
         self._bias_jobs = []
-        loss = torch.zeros(4, device=self.dev)   # [main, head0, head1, unused]
+        loss = torch.empty(4, device=self.dev)   # [main, head0, head1, unused]
         nbits = torch.empty(7, device=self.dev)
-        _, dl2 = ops.focal_loss(a["p2"], gt, dist, 0.9, 1.0, want_grad=True, loss_out=loss[0:1], chain_sigmoid=True)
-        _, dl0 = ops.focal_loss(a["p0"], gt8, None, 0.85, want_grad=True, loss_out=loss[1:2], chain_sigmoid=True)
-        _, dl1 = ops.focal_loss(a["p1"], gt16, None, 0.85, want_grad=True, loss_out=loss[2:3], chain_sigmoid=True)
+        dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
+                                              (a["p1"], gt16, None, 0.85, 0.0)], loss)
         ev_t1 = ev_t0 = None
         self._fork()
         with self._on_side():
@@ -293,8 +299,8 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ steps
     def _batch(self, idx_dev):
-        return (ops.gather_rows(self.gt, idx_dev), ops.gather_rows(self.dist, idx_dev),
-                ops.gather_rows(self.gt16, idx_dev), ops.gather_rows(self.gt8, idx_dev))
+        """(gt, dist, gt16, gt8, emb) rows of the mini-batch: one fused gather."""
+        return ops.gather_rows_multi([self.gt, self.dist, self.gt16, self.gt8, self.emb], idx_dev)
 
     def train_step(self, idx_host, q, idx_dev=None, update=True, n_pts=None):
         """One mini-batch decoder update (NVFPCC.py:149-223, minus logging).  Under data parallelism
@@ -307,9 +313,8 @@ class TrainEngine:
             self.noise_step += 1
         if n_pts is None:
             n_pts = float(self.counts[idx_host].sum())
-        gt, dist, gt16, gt8 = self._batch(idx_dev)
+        gt, dist, gt16, gt8, e = self._batch(idx_dev)
         self.prepare_weights(q)
-        e = ops.gather_rows(self.emb, idx_dev)
         a = self.forward(e, "train", idx_dev)
         self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False)
         if self.grad_hook is not None:
@@ -361,14 +366,18 @@ class GraphedTrainStep:
     def __init__(self, eng, batch, q):
         self.eng, self.batch, self.q = eng, batch, q
         dev = eng.dev
-        self.idx = torch.zeros(batch, dtype=torch.int64, device=dev)
-        self.idx_pin = torch.zeros(batch, dtype=torch.int64).pin_memory()
-        self.scal_pin = torch.zeros(2, dtype=torch.float64).pin_memory()
-        self.g_lat = torch.zeros(1, device=dev)
-        self.step = torch.zeros(1, dtype=torch.int64, device=dev)
+        # one device buffer [idx (B x i64) | noise step (u64) | lambda*w1/n_pts (f32 in the low half)] refreshed by a
+        # single pinned-memory copy per step
+        self.buf = torch.zeros(batch + 2, dtype=torch.int64, device=dev)
+        self.pin = torch.zeros(batch + 2, dtype=torch.int64).pin_memory()
+        self.idx = self.buf[:batch]
+        self.step = self.buf[batch:batch + 1]
+        self.g_lat = self.buf[batch + 1:batch + 2].view(torch.float32)[0:1]
+        self.pin_g = self.pin[batch + 1:batch + 2].view(torch.float32)
         eng._step_dev, eng._g_lat_dev = self.step, self.g_lat
-        self.idx.copy_(torch.arange(batch) % eng.N_leaf)
-        self.g_lat.fill_(1.0)
+        self.pin[:batch] = torch.arange(batch) % eng.N_leaf
+        self.pin_g[0] = 1.0
+        self.buf.copy_(self.pin)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up: allocates the grow-only workspaces outside the graph
@@ -383,9 +392,8 @@ class GraphedTrainStep:
 
     def _body(self):
         eng = self.eng
-        gt, dist, gt16, gt8 = eng._batch(self.idx)
+        gt, dist, gt16, gt8, e = eng._batch(self.idx)
         eng.prepare_weights(self.q)
-        e = ops.gather_rows(eng.emb, self.idx)
         a = eng.forward(e, "train", self.idx)
         eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False)
         self.out = a
@@ -398,10 +406,10 @@ class GraphedTrainStep:
             eng.noise_step += 1
         if n_pts is None:
             n_pts = float(eng.counts[idx_host].sum())
-        self.idx_pin.copy_(torch.from_numpy(idx_host))
-        self.idx.copy_(self.idx_pin, non_blocking=True)
-        self.g_lat.fill_(eng.lmbda * eng.w1 / n_pts)
-        self.step.fill_(eng.noise_step)
+        self.pin[:self.batch] = torch.from_numpy(idx_host)
+        self.pin[self.batch] = eng.noise_step
+        self.pin_g[0] = eng.lmbda * eng.w1 / n_pts
+        self.buf.copy_(self.pin, non_blocking=True)
         self.graph.replay()
         eng.last["n_pts"] = n_pts
         if eng.grad_hook is not None:

@@ -250,6 +250,25 @@ def focal_loss(p, gt, dist, alpha, beta=0.0, want_grad=False, g_dev=None, g_host
     return loss, dp
 
 
+def focal_loss_multi(terms, loss_out, chain_sigmoid=True):
+    """terms: list of (p, gt, dist-or-None, alpha, beta); returns the list of gradients w.r.t. p (or the logits)."""
+    import ctypes
+    n = len(terms)
+    for p, gt, dist, _, _ in terms:
+        _f32(p, gt, dist)
+    _f32(loss_out)
+    dps = [torch.empty_like(t[0]) for t in terms]
+    arr = lambda xs: (ctypes.c_void_p * n)(*[(x.data_ptr() if x is not None else None) for x in xs])
+    al = (ctypes.c_float * n)(*[float(t[3]) for t in terms])
+    be = (ctypes.c_float * n)(*[float(t[4]) for t in terms])
+    ns = (ctypes.c_int64 * n)(*[t[0].numel() for t in terms])
+    ws = workspace(lib().nvf_reduce_workspace(), terms[0][0].device, "reduce")
+    check(lib().nvf_focal_loss_multi(arr([t[0] for t in terms]), arr([t[1] for t in terms]),
+                                     arr([t[2] for t in terms]), arr(dps), al, be, ns, n, _ptr(loss_out),
+                                     int(chain_sigmoid), _ptr(ws), ws.numel(), _stream()), "nvf_focal_loss_multi")
+    return dps
+
+
 def metrics(p, gt, dist, thh_acc, thh_sse, out=None, accumulate=False):
     _f32(p, gt, dist, out)
     o = out if out is not None else torch.empty(6, device=p.device)
@@ -307,6 +326,20 @@ def gather_rows(src, idx):
     dst = torch.empty((idx.numel(),) + tuple(src.shape[1:]), device=src.device)
     check(lib().nvf_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), idx.numel(), width, _stream()), "nvf_gather_rows")
     return dst
+
+
+def gather_rows_multi(srcs, idx):
+    """[src[idx] for src in srcs] in one launch (all sources indexed by the same int64 vector)."""
+    import ctypes
+    _f32(*srcs)
+    _chk(idx)
+    n, rows = len(srcs), idx.numel()
+    dsts = [torch.empty((rows,) + tuple(s.shape[1:]), device=s.device) for s in srcs]
+    sp = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    wd = (ctypes.c_int * n)(*[s[0].numel() for s in srcs])
+    check(lib().nvf_gather_rows_multi(sp, dp, wd, n, _ptr(idx), rows, _stream()), "nvf_gather_rows_multi")
+    return dsts
 
 
 def scatter_add_rows(src, idx, dst):
