@@ -86,6 +86,21 @@ int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, floa
                          int pad, int din, int hin, int win, int dout, int hout, int wout, int act, int variant,
                          void* stream);
 
+/* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
+ * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
+ * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when
+ *           dbeta_hat, dgamma_hat and dw_up0 are all non-NULL also the IGDN parameter gradients and up0's weight
+ *           gradient [ch][8][5][5][5] (overwritten).  One workgroup per block, intermediates in LDS.
+ * Weights are the packed layouts: *_w_fwd = [cin][125][cout], *_w_bwd = [cout][125][cin]. */
+int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
+                 const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
+                 float* y1, int batch, int ch, int c0, int c1, void* stream);
+size_t nvf_stem_bwd_workspace(int ch);
+int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
+                 const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
+                 float* dbeta_hat, float* dgamma_hat, float* dw_up0, void* workspace, size_t workspace_bytes,
+                 int batch, int ch, int c0, int c1, void* stream);
+
 /* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
  * dw[a][b][k] (+)= sum_{n,i} p[n,a,i] * q[n,b, stride*i - pad + k]      (out_mode 0)
  * dw[b][a][K^3-1-k] (+)= same sum                                        (out_mode 1)

@@ -80,6 +80,7 @@ class TrainEngine:
         # the backward-data chain, so they overlap with it (at batch 16 one kernel cannot fill 256 CUs by itself)
         self.side = torch.cuda.Stream(device=self.dev)
         self.allow_overlap = True
+        self.fused_stem = tuple(net.reconstructor.channels[:2]) == (8, 16) and net.entropy_coder.sigma.shape[1] <= 8
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
 
@@ -162,11 +163,15 @@ class TrainEngine:
         a["x0"], a["lbits"], _, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
                                                        block_ids=block_ids, seed=self.seed,
                                                        step=0 if sd is not None else self.noise_step, step_dev=sd)
-        a["a0"] = self._convT(Ls["up0"], a["x0"], NONE)
         ig = net.reconstructor.activation
-        a["h0"] = ops.gdn_fwd(a["a0"], ig.beta, ig.gamma, True)
         self.overlap = self.allow_overlap and e.shape[0] <= 64   # large batches fill the chip by themselves
-        a["y1"] = self._convT(Ls["conv0"], a["h0"], R)
+        if self.fused_stem:
+            a["a0"], a["h0"], a["y1"] = ops.stem_fwd(a["x0"], Ls["up0"].w_fwd, Ls["up0"].b_eff, ig.beta, ig.gamma,
+                                                     Ls["conv0"].w_fwd, Ls["conv0"].b_eff)
+        else:
+            a["a0"] = self._convT(Ls["up0"], a["x0"], NONE)
+            a["h0"] = ops.gdn_fwd(a["a0"], ig.beta, ig.gamma, True)
+            a["y1"] = self._convT(Ls["conv0"], a["h0"], R)
         self._fork()
         with self._on_side():                       # the two coarse heads run beside the trunk
             a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
@@ -257,13 +262,21 @@ class TrainEngine:
             main.wait_event(ev_t0)
         g1 = self._dx_convT(Ls["up1"], g2, a["y1"], mask=a["y1"], addend=t0)
         side_wgrad(self._wgrad_convT, Ls["conv0"], g1, a["h0"])
-        dh0 = self._dx_convT(Ls["conv0"], g1, a["h0"])
         ig = net.reconstructor.activation
         gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
-        da0, _, _ = ops.gdn_bwd(a["a0"], ig.beta, ig.gamma, dh0, True, gview("reconstructor.activation.beta"),
-                                None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape))
-        side_wgrad(self._wgrad_convT, Ls["up0"], da0, a["x0"])
-        dx0 = self._dx_convT(Ls["up0"], da0, a["x0"])
+        gamma_view = None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape)
+        if self.fused_stem:
+            da0, dx0 = ops.stem_bwd(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta, ig.gamma,
+                                    gview("reconstructor.activation.beta"), gamma_view,
+                                    Ls["up0"].gk if want_w else None)
+            if want_w:
+                self._bias_jobs.append((da0, Ls["up0"].gb))
+        else:
+            dh0 = self._dx_convT(Ls["conv0"], g1, a["h0"])
+            da0, _, _ = ops.gdn_bwd(a["a0"], ig.beta, ig.gamma, dh0, True, gview("reconstructor.activation.beta"),
+                                    gamma_view)
+            side_wgrad(self._wgrad_convT, Ls["up0"], da0, a["x0"])
+            dx0 = self._dx_convT(Ls["up0"], da0, a["x0"])
         # latent rate (+ the decoder's gradient through the straight-through round)
         ec = net.entropy_coder
         sd = self._step_dev

@@ -129,6 +129,33 @@ def convT3d_k5s2_fwd(x, w_fwd, bias, cout, pad, act=ACT_NONE, out=None):
     return y
 
 
+def stem_fwd(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b):
+    """Fused up0 -> IGDN -> conv0 + ReLU for chanstr (8, 16, ...): returns (a0, h0, y1)."""
+    _f32(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b)
+    B, ch = x0.shape[0], x0.shape[1]
+    a0 = torch.empty((B, 8, 4, 4, 4), device=x0.device)
+    h0 = torch.empty((B, 8, 4, 4, 4), device=x0.device)
+    y1 = torch.empty((B, 16, 8, 8, 8), device=x0.device)
+    check(lib().nvf_stem_fwd(_ptr(x0), _ptr(up0_w_fwd), _ptr(up0_b), _ptr(beta_hat), _ptr(gamma_hat),
+                             _ptr(conv0_w_fwd), _ptr(conv0_b), _ptr(a0), _ptr(h0), _ptr(y1), B, ch, 8, 16,
+                             _stream()), "nvf_stem_fwd")
+    return a0, h0, y1
+
+
+def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=None, dgamma_out=None, dw_up0=None):
+    """Fused conv0 backward-data -> IGDN backward -> up0 backward-data (+ IGDN / up0 parameter gradients when
+    the three outputs are given).  Returns (da0, dx0)."""
+    _f32(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0)
+    B, ch = x0.shape[0], x0.shape[1]
+    da0 = torch.empty_like(a0)
+    dx0 = torch.empty_like(x0)
+    ws = workspace(lib().nvf_stem_bwd_workspace(ch), x0.device, "stem")
+    check(lib().nvf_stem_bwd(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
+                             _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
+                             _ptr(dw_up0), _ptr(ws), ws.numel(), B, ch, 8, 16, _stream()), "nvf_stem_bwd")
+    return da0, dx0
+
+
 def wgrad(p, q, k, stride, pad, out_mode=0, out=None, accumulate=False):
     """dw[a][b][k] (out_mode 0) or dw[b][a][flip k] (out_mode 1) = sum p[n,a,i] q[n,b,stride*i-pad+k]."""
     _f32(p, q)

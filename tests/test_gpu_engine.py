@@ -135,3 +135,22 @@ def test_weight_noise_and_latent_noise_are_reproducible(gpu):
     assert torch.equal(eng.flat_g, g1)
     eng.train_step([0, 1, 2], 1, update=False)      # next step: different noise
     assert not torch.equal(eng.flat_g, g1)
+
+
+def test_fused_stem_equals_the_per_layer_kernels(gpu):
+    """Forward bit-identical (same accumulation order); gradients to rounding."""
+    net, eng, gt, dist, emb = make("S", gpu)
+    assert eng.fused_stem
+    idx = [0, 2, 5, 1]
+    a = eng.train_step(idx, 2, update=False)
+    g_fused, y1, h0 = eng.flat_g.clone(), a["y1"].clone(), a["h0"].clone()
+    eng.fused_stem = False
+    a = eng.train_step(idx, 2, update=False)
+    assert torch.equal(a["y1"], y1) and torch.equal(a["h0"], h0)
+    for name, (off, n) in eng.slices.items():
+        close(g_fused[off:off + n], eng.flat_g[off:off + n], tol=1e-5)
+    eng.fused_stem = True
+    _, de = eng.latent_step(2, update=False)
+    eng.fused_stem = False
+    _, de2 = eng.latent_step(2, update=False)
+    close(de, de2, tol=1e-5)
