@@ -226,6 +226,13 @@ int nvf_threshold_count(const float* p, float thh, int32_t* counts, int batch, i
 int nvf_threshold_compact(const float* p, float thh, const int32_t* offsets, const int32_t* origins,
                           int32_t* coords, int batch, int dim, void* stream);
 
+/* ---- pre-processing: exact squared distance of every voxel of every 32^3 leaf block to the nearest input
+ * point (util_get_grids.py:19-46; gt_grid = (d2 == 0), dist = sqrt(d2)).  pts int32 [P,3] sorted by block,
+ * blk_off [N+1] their ranges, origins int32 [N,3], (nb_off, nb_idx) a CSR list of candidate blocks per block
+ * (the block itself first, then occupied blocks within +-2 block steps).  d2out int32 [N,32,32,32], axes (x,y,z). */
+int nvf_nearest_dist2(const int32_t* pts, const int32_t* blk_off, const int32_t* origins, const int32_t* nb_off,
+                      const int32_t* nb_idx, int32_t* d2out, int nblocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,3 +121,20 @@ def codec_cases():
     # empty message: only the terminator is coded
     cases["empty"] = (np.zeros(0, np.int16), np.zeros(0, np.float32), np.zeros(0, np.float32))
     return cases
+
+
+def synthetic_cloud(seed=99, n_dir=40000, radius=70.0, center=(500.0, 530.0, 470.0)):
+    """A 10-bit voxelised ellipsoid shell (~30 k points, ~100 level-5 cubes) for the pre-processing tests."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n_dir, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = np.asarray(center) + d * np.array([radius, 0.8 * radius, 1.3 * radius])
+    return np.unique(np.round(p).astype(np.int64), axis=0)
+
+
+def write_cloud_ply(path, pts):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % len(pts))
+        for x, y, z in pts.tolist():
+            f.write(f"{x} {y} {z} 128 128 128\n")
