@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Rate-distortion sweep of the whole codec on a synthetic 10-bit surface (README
+steps 1-3 of the reference end to end): pre-process -> train -> 4-bit weight quantisation -> encode -> decode,
+for several lambda.  Reports bpp from the REAL stream lengths (NVFPCC.py:542-547), the reference's one-sided
+PSNR1 (NVFPCC.py:259-260) and a symmetric D1 PSNR (point-to-point, peak 1023) computed with a KD-tree.
+
+    python tools/rd_sweep.py --lambdas 50,200,800 --epochs 301 --out profiles/r01_rd_sweep.md
+"""
+import argparse
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_cloud(seed, radius, n_dir):
+    """Bumpy ellipsoid shell, 10-bit coordinates."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n_dir, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    bump = 1.0 + 0.08 * np.sin(5 * d[:, 0]) * np.cos(4 * d[:, 1]) + 0.05 * np.sin(9 * d[:, 2])
+    p = np.array([512.0, 512.0, 512.0]) + d * bump[:, None] * np.array([radius, 0.85 * radius, 1.2 * radius])
+    return np.unique(np.clip(np.round(p), 0, 1023).astype(np.int64), axis=0)
+
+
+def d1_psnr(a, b, peak=1023.0):
+    da, _ = cKDTree(b).query(a)
+    db, _ = cKDTree(a).query(b)
+    mse = max(np.mean(da ** 2), np.mean(db ** 2))
+    return 10 * np.log10(3 * peak ** 2 / max(mse, 1e-12))
+
+
+def run(cmd, cwd, log):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable] + cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    log.write(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout[-2000:])
+    return r.stdout
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lambdas", default="50,200,800")
+    ap.add_argument("--epochs", type=int, default=301)
+    ap.add_argument("--phase_change", type=int, default=100)
+    ap.add_argument("--radius", type=float, default=150.0)
+    ap.add_argument("--n_dir", type=int, default=1500000)
+    ap.add_argument("--chanstr", default="8,16,8,8")
+    ap.add_argument("--ch", type=int, default=3)
+    ap.add_argument("--thh", type=float, default=0.6)
+    ap.add_argument("--wemb", type=float, default=5.0)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--workdir", default="")
+    a = ap.parse_args()
+    from nvfpcc_amd.preprocess import preprocess
+    from nvfpcc_amd.recon import read_ply_ascii
+    from tests.golden_inputs import write_cloud_ply
+    wd = a.workdir or tempfile.mkdtemp(prefix="nvf_rd_")
+    os.makedirs(wd, exist_ok=True)
+    os.chdir(wd)
+    log = open("rd_sweep.log", "w")
+    pts = make_cloud(7, a.radius, a.n_dir)
+    write_cloud_ply("cloud.ply", pts)
+    t0 = time.time()
+    origins, gt, dist = preprocess("cloud.ply")
+    t_pre = time.time() - t0
+    n_pts, n_blk = len(pts), len(origins)
+    print(f"cloud: {n_pts} points, {n_blk} level-5 cubes, occupancy {100 * n_pts / (n_blk * 32768):.2f} %, "
+          f"pre-processing {t_pre:.1f} s")
+    cli = os.path.join(ROOT, "NVFPCC.py")
+    common = ["--chanstr", a.chanstr, "--ch", str(a.ch)]
+    rows = []
+    for lam in [float(v) for v in a.lambdas.split(",")]:
+        ck = f"ckpt_{lam:g}"
+        t0 = time.time()
+        run([cli, "train", "cloud.ply", "--checkpoint_dir", ck, "--batchsize", "16", "--lambda", str(lam), "--lr", "1e-3",
+             "--w1", "10", "--w2", "57", "--wemb", str(a.wemb), "--shuffle", "True", "--epochs", str(a.epochs), "--phase_change",
+             str(a.phase_change)] + common, wd, log)
+        t_train = time.time() - t0
+        last = (a.epochs - 1) // 10 * 10
+        run([os.path.join(ROOT, "manipulate_weights.py"), f"{ck}/{last:04d}.ckpt", f"q4_{lam:g}.ckpt", "16"], wd, log)
+        out = run([cli, "encode", "cloud.ply", "--batchsize", "64", "--load_weights", f"q4_{lam:g}.ckpt", "--load_emb",
+                   f"{ck}/{last:04d}_emb.ckpt", "--thh", str(a.thh), "--pack_fn", f"pack_{lam:g}.pk"] + common, wd, log)
+        psnr1 = float(out.split("PSNR1: ")[-1].split()[0])
+        run([cli, "decode", f"pack_{lam:g}.pk", "--batchsize", "64", "--thh", str(a.thh), "--N", str(n_blk)] + common, wd, log)
+        enc, dec = read_ply_ascii("rc_enc.ply"), read_ply_ascii("rc_dec.ply")
+        same = enc.shape == dec.shape and np.array_equal(enc, dec)
+        pack = pickle.load(open(f"pack_{lam:g}.pk", "rb"))
+        bits_lat = 8 * len(pack["latent_pack"]["latent_byte_stream"])
+        bits_net = 8 * len(pack["net_weight_pack"]["bit_stream"])
+        rows.append((lam, (bits_lat + bits_net) / n_pts, bits_lat / n_pts, bits_net / n_pts, psnr1, d1_psnr(pts, dec),
+                     len(dec), same, t_train))
+        print(rows[-1])
+    lines = ["| lambda | bpp | bpp latents | bpp weights | PSNR1 (dB) | D1 PSNR sym. (dB) | decoded points | rc_enc == rc_dec | train s |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        lines.append(f"| {r[0]:g} | {r[1]:.4f} | {r[2]:.4f} | {r[3]:.4f} | {r[4]:.2f} | {r[5]:.2f} | {r[6]} | {r[7]} | {r[8]:.0f} |")
+    table = "\n".join(lines)
+    head = (f"RD sweep on a synthetic 10-bit surface: {n_pts} points, {n_blk} level-5 cubes; ch={a.ch}, chanstr={a.chanstr}, "
+            f"{a.epochs} epochs (phase change {a.phase_change}), batch 16, lr 1e-3, w1 10, w2 57, wemb {a.wemb:g}, 4-bit weights, "
+            f"thh {a.thh}; 1 x MI355X.\n\n")
+    print(head + table)
+    if a.out:
+        with open(os.path.join(ROOT, a.out) if not os.path.isabs(a.out) else a.out, "w") as f:
+            f.write(head + table + "\n")
+
+
+if __name__ == "__main__":
+    main()
