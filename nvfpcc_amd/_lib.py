@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvf_hip.so")
+LIB_PATH = os.environ.get("NVF_LIB", os.path.join(_HERE, "libnvf_hip.so"))   # NVF_LIB: A/B a second build
 
 P = C.c_void_p
 I = C.c_int
