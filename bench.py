@@ -140,7 +140,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", int(os.environ.get("NVF_DEVICE_OVERRIDE", local_rank)))   # override: test hook
     torch.cuda.set_device(device)
     ops.set_naive(args.naive)
     eng = build_engine(args, device, world)
@@ -174,6 +174,7 @@ def main():
                lambda p_, q_, k, s, pad, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -197,7 +198,8 @@ def main():
         torch.cuda.synchronize()
         probe.enabled = False
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device=device if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss = eng.loss_value()

@@ -33,7 +33,8 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # NVF_DIST_BACKEND=gloo is a test hook (several ranks sharing one GPU); production is RCCL
+            backend = os.environ.get("NVF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -56,7 +57,12 @@ def shard_range(n, rank, world):
 
 def allreduce_sum_(flat):
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and flat.is_cuda:     # test hook: gloo reduces on the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
@@ -71,7 +77,13 @@ def allgather_rows_(table, rank, world):
     lo, hi = shard_range(n, rank, world)
     mine = torch.zeros(per, width, device=table.device, dtype=table.dtype)
     mine[:hi - lo] = table[lo:hi].reshape(hi - lo, width)
-    dist.all_gather_into_tensor(pad, mine) if hasattr(dist, "all_gather_into_tensor") else \
+    if dist.get_backend() == "gloo" and table.is_cuda:        # test hook: gloo gathers on the host
+        parts = [torch.zeros(per, width) for _ in range(world)]
+        dist.all_gather(parts, mine.cpu())
+        pad.copy_(torch.cat(parts, 0))
+    elif hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(pad, mine)
+    else:
         dist.all_gather(list(pad.chunk(world)), mine)
     table.copy_(pad[:n].reshape(table.shape))
     return table
