@@ -133,6 +133,59 @@ struct GCfg {
   static_assert(LDSF * 4 <= 160 * 1024, "LDS");
 };
 
+// One (ci,kz,ky) step of a thread's register tile: acc[co][v] += in[v*S+kx] * w[kx][co], kx ascending (the
+// canonical per-output order).  For even COG the FMAs are written on channel PAIRS: the weight pair is an aligned
+// SGPR pair straight out of s_load_dwordx16 and the input is one half of a VGPR pair picked by op_sel, so
+// v_pk_fma_f32 needs no operand shuffling (packing over x pairs instead costs an s_mov/v_mov per odd operand).
+typedef float nvf_f2 __attribute__((ext_vector_type(2)));
+template <int COG, int VX>
+struct NvfAcc {
+  static constexpr bool PAIR = COG % 2 == 0;
+  nvf_f2 p[PAIR ? COG / 2 : 1][VX];
+  float s[PAIR ? 1 : COG][VX];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < (PAIR ? COG / 2 : 1); ++i)
+#pragma unroll
+      for (int j = 0; j < VX; ++j) p[i][j] = (nvf_f2){0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (PAIR ? 1 : COG); ++i)
+#pragma unroll
+      for (int j = 0; j < VX; ++j) s[i][j] = 0.f;
+  }
+  __device__ __forceinline__ float get(int co, int v) const {
+    if constexpr (PAIR) return (co & 1) ? p[co / 2][v].y : p[co / 2][v].x;
+    else return s[co][v];
+  }
+};
+
+template <int COG, int VX, int KS, int S, int COUT, int NIN>
+__device__ __forceinline__ void nvf_mac_row(const float (&in)[NIN], const float* __restrict__ wr,
+                                            NvfAcc<COG, VX>& acc) {
+  if constexpr (COG % 2 == 0) {
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+      for (int co = 0; co < COG; co += 2) {
+        const nvf_f2 wv = {wr[kx * COUT + co], wr[kx * COUT + co + 1]};
+#pragma unroll
+        for (int v = 0; v < VX; ++v) {
+          const float xv = in[v * S + kx];
+          acc.p[co / 2][v] = __builtin_elementwise_fma((nvf_f2){xv, xv}, wv, acc.p[co / 2][v]);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+      for (int co = 0; co < COG; ++co) {
+        const float wv = wr[kx * COUT + co];
+#pragma unroll
+        for (int v = 0; v < VX; ++v) acc.s[co][v] = fmaf(in[v * S + kx], wv, acc.s[co][v]);
+      }
+  }
+}
+
 template <class C>
 __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
@@ -151,11 +204,8 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
   const int tid = threadIdx.x;
   const int cx = tid % NCX, ty = (tid / NCX) % TY, tz = tid / (NCX * TY);
   const bool active = tid < C::NACT;
-  float acc[COG][VX];
-#pragma unroll
-  for (int i = 0; i < COG; ++i)
-#pragma unroll
-    for (int j = 0; j < VX; ++j) acc[i][j] = 0.f;
+  NvfAcc<COG, VX> acc;
+  acc.zero();
   const float* xb = x + (size_t)b * CIN * d.din * d.hin * d.win;
   const int gz0 = oz0 * S - d.pad, gy0 = oy0 * S - d.pad, gx0 = ox0 * S - d.pad;
   const int plane = d.hin * d.win;
@@ -183,14 +233,7 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
             float in[NIN4];
             nvf_lds_row<NIN4, LV>(rowp, in);
             const float* wr = w + (size_t)((((c0 + c) * KS + kz) * KS + ky) * KS) * COUT + co0;  // wave-uniform
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-              for (int co = 0; co < COG; ++co) {
-                const float wv = wr[kx * COUT + co];
-#pragma unroll
-                for (int v = 0; v < VX; ++v) acc[co][v] = fmaf(in[v * S + kx], wv, acc[co][v]);
-              }
+            nvf_mac_row<COG, VX, KS, S, COUT>(in, wr, acc);
           }
         }
       }
@@ -207,13 +250,163 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
     for (int v = 0; v < VX; ++v) {
       const int ox = ox0 + cx * VX + v;
       if (ox < d.wout) {
-        float o = nvf_act(acc[co][v] + bv, d.act);
+        float o = nvf_act(acc.get(co, v) + bv, d.act);
         if (addend) o += addend[base + ox];
         if (mask) o = mask[base + ox] > 0.f ? o : 0.f;
         y[base + ox] = o;
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Same tile / register / accumulation scheme, but the input tile is filled by LDS-DMA
+// (global_load_lds_dword: HBM/L2 -> LDS with no VGPR destination) into TWO tile buffers:
+// the loads of channel chunk c+1 are in flight while chunk c is being multiplied, so a
+// workgroup that is alone on its CU (batch 16: 1-2 waves per SIMD) no longer idles through
+// every staging phase.  One wave-instruction moves whole rows (lane = x): the row base is
+// scalar (SALU), the only per-lane quantity is the constant x offset, and halo / padding
+// elements are simply never written -- both buffers are zeroed once, and the out-of-range
+// pattern of a tile is the same for every channel chunk.  The DMA is issued from inline
+// asm, so hipcc does not count it: the explicit vmcnt(0) before the barrier is the wait.
+// Results are bit-identical to conv_gather_tiled (same LDS image, same fmaf chain).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void nvf_glds_row(const float* row_base, unsigned voff_bytes, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_bytes), "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "s"(row_base)
+      : "memory");
+}
+__device__ __forceinline__ void nvf_glds_lane(const float* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
+      : "memory");
+}
+
+template <class C>
+__device__ __forceinline__ void conv_glds_issue(const float* __restrict__ xc, unsigned lds_byte, int wave, int lane,
+                                                int gz0, int gy0, int gx0, const ConvDims& d) {
+  constexpr int RS = C::RS, IX = C::IX, IY = C::IY, IZ = C::IZ, R = C::CC * C::IZ * C::IY, NW = C::NT / 64;
+  constexpr int RPI = RS <= 32 ? 64 / RS : 1;                    // LDS rows are contiguous: several per instruction
+  const int sub = RPI > 1 ? lane / RS : 0;
+  const int xx = lane - sub * RS;
+  const int gx = gx0 + xx;
+  const bool xok = sub < RPI && xx < IX && gx >= 0 && gx < d.win;
+#pragma unroll 1
+  for (int r0 = wave * RPI; r0 < R; r0 += NW * RPI) {            // wave-uniform
+    if constexpr (RPI == 1) {
+      const int yy = r0 % IY, t = r0 / IY, zz = t % IZ, c = t / IZ;
+      const int gy = gy0 + yy, gz = gz0 + zz;
+      if (gy < 0 || gy >= d.hin || gz < 0 || gz >= d.din) continue;
+      const float* rb = xc + ((c * d.din + gz) * d.hin + gy) * d.win;   // < 2^31 elements per batch item
+      if (xok) nvf_glds_row(rb, (unsigned)gx * 4u, lds_byte + (unsigned)r0 * RS * 4u);
+    } else {
+      int off = 0;
+      bool ok = false;
+#pragma unroll
+      for (int u = 0; u < RPI; ++u) {
+        const int r = r0 + u;
+        const int yy = r % IY, t = r / IY, zz = t % IZ, c = t / IZ;
+        const int gy = gy0 + yy, gz = gz0 + zz;
+        const bool rok = r < R && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din;
+        const int o = ((c * d.din + gz) * d.hin + gy) * d.win;
+        if (sub == u) { off = o; ok = rok; }
+      }
+      if (xok && ok) nvf_glds_lane(xc + off + gx, lds_byte + (unsigned)r0 * RS * 4u);
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void conv_gather_glds(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          const float* __restrict__ addend,
+                                                          const float* __restrict__ mask, ConvDims d) {
+  constexpr int CIN = C::CIN, COUT = C::COUT, KS = C::KS, S = C::S, VX = C::VX, NCX = C::NCX, TY = C::TY, TZ = C::TZ,
+                CC = C::CC;
+  constexpr int RS = C::RS, IY = C::IY, IZ = C::IZ, NT = C::NT, NIN4 = C::NIN4, COG = C::COG, LV = C::LV;
+  constexpr int LDSF = (C::LDSF + 3) / 4 * 4;
+  static_assert(2 * LDSF * 4 <= 160 * 1024, "two tile buffers");
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDSF];
+  const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
+  const int co0 = (blockIdx.x % C::NCOG) * COG;            // wave-uniform
+  const int wg = blockIdx.x / C::NCOG;
+  const int tile = wg % ntile, b = wg / ntile;
+  const int tx_i = tile % d.tiles_x, ty_i = (tile / d.tiles_x) % d.tiles_y, tz_i = tile / (d.tiles_x * d.tiles_y);
+  const int ox0 = tx_i * C::TX, oy0 = ty_i * TY, oz0 = tz_i * TZ;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int cx = tid % NCX, ty = (tid / NCX) % TY, tz = tid / (NCX * TY);
+  const bool active = tid < C::NACT;
+  NvfAcc<COG, VX> acc;
+  acc.zero();
+  const size_t vol = (size_t)d.din * d.hin * d.win;
+  const float* xb = x + (size_t)b * CIN * vol;
+  const int gz0 = oz0 * S - d.pad, gy0 = oy0 * S - d.pad, gx0 = ox0 * S - d.pad;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  for (int i = tid * 4; i < 2 * LDSF; i += NT * 4) *(float4*)(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  conv_glds_issue<C>(xb, lds0, wave, lane, gz0, gy0, gx0, d);
+#pragma unroll 1
+  for (int c0 = 0; c0 < CIN; c0 += CC) {
+    const int buf = (c0 / CC) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA rows of chunk c0 have landed
+    __syncthreads();                                        // ... everyone's; and chunk c0-CC is no longer being read
+    if (c0 + CC < CIN)
+      conv_glds_issue<C>(xb + (size_t)(c0 + CC) * vol, lds0 + (unsigned)(buf ^ 1) * LDSF * 4u, wave, lane, gz0, gy0,
+                         gx0, d);
+    if (active) {
+      const float* tile_lds = lds + buf * LDSF;
+#pragma unroll 1
+      for (int c = 0; c < CC; ++c) {
+#pragma unroll 1
+        for (int kz = 0; kz < KS; ++kz) {
+#pragma unroll C::KYU
+          for (int ky = 0; ky < KS; ++ky) {
+            const float* rowp = tile_lds + ((c * IZ + tz * S + kz) * IY + ty * S + ky) * RS + cx * VX * S;
+            float in[NIN4];
+            nvf_lds_row<NIN4, LV>(rowp, in);
+            const float* wr = w + (size_t)((((c0 + c) * KS + kz) * KS + ky) * KS) * COUT + co0;  // wave-uniform
+            nvf_mac_row<COG, VX, KS, S, COUT>(in, wr, acc);
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const int oz = oz0 + tz, oy = oy0 + ty;
+  if (oz >= d.dout || oy >= d.hout) return;
+#pragma unroll
+  for (int co = 0; co < COG; ++co) {
+    const float bv = bias ? bias[co0 + co] : 0.f;
+    const size_t base = (((size_t)b * COUT + co0 + co) * d.dout + oz) * d.hout * d.wout + (size_t)oy * d.wout;
+#pragma unroll
+    for (int v = 0; v < VX; ++v) {
+      const int ox = ox0 + cx * VX + v;
+      if (ox < d.wout) {
+        float o = nvf_act(acc.get(co, v) + bv, d.act);
+        if (addend) o += addend[base + ox];
+        if (mask) o = mask[base + ox] > 0.f ? o : 0.f;
+        y[base + ox] = o;
+      }
+    }
+  }
+}
+
+template <class C>
+static int launch_gather_glds(const float* x, const float* w, const float* bias, float* y, const float* addend,
+                              const float* mask, int batch, ConvDims d, hipStream_t s) {
+  d.tiles_x = (d.wout + C::TX - 1) / C::TX;
+  d.tiles_y = (d.hout + C::TY - 1) / C::TY;
+  d.tiles_z = (d.dout + C::TZ - 1) / C::TZ;
+  dim3 grid((unsigned)(d.tiles_x * d.tiles_y * d.tiles_z) * batch * C::NCOG);
+  conv_gather_glds<C><<<grid, C::NT, 0, s>>>(x, w, bias, y, addend, mask, d);
+  return NVF_OK;
 }
 
 template <class C>
@@ -238,19 +431,78 @@ extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bi
   // variant 0: the tuned configuration; 1: one-thread-per-output kernel; >= 2: alternatives kept for tuning runs.
   // Small batches cannot fill 256 CUs with whole-Cout tiles, so they take the Cout-split (COG) instantiations.
   if (variant == 0 && batch <= 64) {
-    if (cin == 8 && cout == 8 && k == 5 && stride == 2 && wout >= 9 && wout <= 16) variant = 9;   // up2 backward-data
+    if (cin == 8 && cout == 8 && k == 5 && stride == 2 && wout >= 9 && wout <= 16) variant = 30;  // up2 backward-data
     if (cin == 8 && cout == 16 && k == 5 && stride == 2 && wout >= 5 && wout <= 8) variant = 9;   // up1 backward-data
     if (cin == 16 && cout == 8 && k == 5 && stride == 2 && wout >= 3 && wout <= 4) variant = 9;   // conv0 backward-data
-    if (cin == 8 && cout == 8 && k == 4 && stride == 1 && wout >= 9 && wout <= 16) variant = 9;   // conv1 forward
-    if (cin == 8 && cout == 8 && k == 4 && stride == 1 && wout >= 17 && wout <= 20) variant = 10; // conv1 backward-data
+    if (cin == 8 && cout == 8 && k == 4 && stride == 1 && wout >= 9 && wout <= 40) variant = 30;  // conv1, conv2: both
     if (cin == 1 && cout == 16 && k == 3 && wout <= 8) variant = 1;                               // conv0_cls backward-data
+  } else if (variant == 0) {
+    if (cin == 8 && cout == 8 && k == 4 && stride == 1 && wout >= 17 && wout <= 40) variant = 31; // conv1 bwd, conv2: both
+    if (cin == 8 && cout == 16 && k == 5 && stride == 2 && wout >= 5 && wout <= 8) variant = 31;  // up1 backward-data
+    if (cin == 16 && cout == 16 && k == 4 && stride == 1 && wout >= 21 && wout <= 36) variant = 31;  // wide conv2: both
   }
-  if (variant != 1) {
+  // a tuned id (>= 9) without an instantiation for this shape falls back to the variant-0 table
+  for (int pass = 0; pass < 2 && rc == 1 && variant != 1; ++pass, variant = 0) {
 #define NVF_GC(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU, COG)                                        \
   if (rc == 1 && variant == VAR && cin == CI && cout == CO && k == KS && stride == ST && wout >= WLO && wout <= WHI) \
     rc = launch_gather<GCfg<CI, CO, KS, ST, VX, NCX, TY, TZ, CC, KYU, COG>>(x, w, bias, y, addend, mask, batch, d, s);
 #define NVF_G(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU) \
   NVF_GC(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU, 0)
+#define NVF_GD(VAR, CI, CO, KS, ST, WLO, WHI, VX, NCX, TY, TZ, CC, KYU, COG)                                        \
+  if (rc == 1 && variant == VAR && cin == CI && cout == CO && k == KS && stride == ST && wout >= WLO && wout <= WHI) \
+    rc = launch_gather_glds<GCfg<CI, CO, KS, ST, VX, NCX, TY, TZ, CC, KYU, COG>>(x, w, bias, y, addend, mask, batch, \
+                                                                                 d, s);
+    // LDS-DMA double-buffered kernels: the tuned choice for batch <= 64 (30) and above (31)
+    NVF_GD(30, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 0)   // conv2 forward
+    NVF_GD(30, 8, 8, 4, 1, 33, 40, 4, 9, 5, 4, 2, 0, 0)   // conv2 backward-data
+    NVF_GD(30, 8, 8, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 4)    // conv1 forward
+    NVF_GD(30, 8, 8, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0, 4)   // conv1 backward-data
+    NVF_GD(30, 8, 8, 5, 2, 9, 16, 2, 8, 4, 4, 2, 0, 4)    // up2 backward-data
+    NVF_GD(31, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 0)   // conv2 forward
+    NVF_GD(31, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0, 0)   // conv2 backward-data
+    NVF_GD(31, 8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0, 0)  // conv1 backward-data
+    NVF_GD(31, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 0)    // up1 backward-data
+    NVF_GD(31, 16, 16, 4, 1, 33, 36, 4, 9, 7, 4, 2, 0, 0) // wide conv2 backward-data
+    NVF_GD(31, 16, 16, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 0) // wide conv2 forward
+    NVF_GD(20, 16, 16, 4, 1, 33, 36, 4, 9, 7, 4, 2, 0, 0)
+    NVF_GD(20, 16, 16, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 0)
+    // LDS-DMA candidates kept for tuning runs
+    NVF_GD(20, 8, 8, 4, 1, 21, 32, 4, 8, 8, 8, 2, 0, 0)
+    NVF_GD(21, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 0)
+    NVF_GD(22, 8, 8, 4, 1, 21, 32, 4, 8, 8, 8, 2, 0, 4)
+    NVF_GD(23, 8, 8, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0, 4)
+    NVF_GD(24, 8, 8, 4, 1, 21, 32, 4, 8, 4, 4, 2, 0, 0)
+    NVF_GD(25, 8, 8, 4, 1, 21, 32, 4, 8, 8, 2, 2, 0, 0)
+    NVF_GD(20, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0, 0)
+    NVF_GD(21, 8, 8, 4, 1, 33, 40, 4, 9, 7, 8, 2, 0, 0)
+    NVF_GD(22, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0, 4)
+    NVF_GD(23, 8, 8, 4, 1, 33, 40, 4, 9, 7, 8, 2, 0, 4)
+    NVF_GD(24, 8, 8, 4, 1, 33, 40, 4, 9, 5, 4, 2, 0, 0)
+    NVF_GD(25, 8, 8, 4, 1, 33, 40, 4, 9, 7, 2, 2, 0, 0)
+    NVF_GD(20, 8, 8, 4, 1, 9, 16, 4, 4, 16, 4, 2, 0, 0)
+    NVF_GD(21, 8, 8, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 0)
+    NVF_GD(22, 8, 8, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 4)
+    NVF_GD(23, 8, 8, 4, 1, 9, 16, 4, 4, 16, 4, 2, 0, 4)
+    NVF_GD(24, 8, 8, 4, 1, 9, 16, 4, 4, 8, 2, 2, 0, 4)
+    NVF_GD(25, 8, 8, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 2)
+    NVF_GD(20, 8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0, 0)
+    NVF_GD(21, 8, 8, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0, 0)
+    NVF_GD(22, 8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0, 4)
+    NVF_GD(23, 8, 8, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0, 4)
+    NVF_GD(24, 8, 8, 4, 1, 17, 20, 4, 5, 10, 2, 2, 0, 4)
+    NVF_GD(25, 8, 8, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0, 2)
+    NVF_GD(20, 8, 8, 5, 2, 9, 16, 4, 4, 16, 4, 1, 0, 0)
+    NVF_GD(21, 8, 8, 5, 2, 9, 16, 2, 8, 8, 4, 2, 0, 0)
+    NVF_GD(22, 8, 8, 5, 2, 9, 16, 2, 8, 8, 2, 2, 0, 4)
+    NVF_GD(23, 8, 8, 5, 2, 9, 16, 2, 8, 4, 4, 2, 0, 4)
+    NVF_GD(24, 8, 8, 5, 2, 9, 16, 4, 4, 8, 2, 2, 0, 4)
+    NVF_GD(25, 8, 8, 5, 2, 9, 16, 2, 8, 8, 2, 2, 0, 2)
+    NVF_GD(20, 8, 16, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0, 0)
+    NVF_GD(21, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 0)
+    NVF_GD(22, 8, 16, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 4)
+    NVF_GD(23, 8, 16, 5, 2, 5, 8, 2, 4, 4, 4, 4, 0, 2)
+    NVF_GD(24, 8, 16, 5, 2, 5, 8, 2, 4, 8, 2, 2, 0, 4)
+    NVF_GD(25, 8, 16, 5, 2, 5, 8, 2, 4, 4, 4, 2, 0, 4)
     // ---- narrow decoder (chanstr 8,16,8,8)
     NVF_G(0, 8, 8, 4, 1, 33, 40, 4, 9, 7, 4, 2, 0)    // conv2 backward-data (35^3)
     NVF_G(0, 8, 8, 4, 1, 21, 32, 4, 8, 8, 8, 2, 0)    // conv2 forward (32^3)
@@ -326,6 +578,7 @@ extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bi
     NVF_GC(0, 16, 8, 5, 2, 2, 2, 2, 1, 2, 2, 8, 0, 1) // up0 backward-data (ch = 8)
 #undef NVF_G
 #undef NVF_GC
+#undef NVF_GD
   }
   if (rc == 1) {
     long total = (long)batch * cout * dout * hout * wout;

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--chanstr", default="8,16,8,8")
     ap.add_argument("--ch", type=int, default=3)
     ap.add_argument("--only", default="")
+    ap.add_argument("--check", action="store_true", help="also compare every variant bit for bit with variant 1")
     a = ap.parse_args()
     B = a.batch
     c0, c1, c2, c3 = (int(v) for v in a.chanstr.split(","))
@@ -82,8 +83,17 @@ def main():
         if a.only and a.only not in name:
             continue
         row = f"{name:22s}"
+        ref = None
+        if a.check:
+            ops.set_variant(1)
+            ref = fn()
         for v in variants:
             ops.set_variant(v)
+            if ref is not None:
+                got = fn()
+                torch.cuda.synchronize()
+                if not torch.equal(got, ref):
+                    row += f" [v{v} MISMATCH max|d|={float((got - ref).abs().max()):.3e}]"
             us = timeit(fn, a.reps)
             total[v] += us
             row += f"{us:10.1f}us {2 * macs / us / 1e6:6.1f}TF  " if macs else f"{us:10.1f}us            "
