@@ -90,12 +90,13 @@ int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, floa
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when
  *           dbeta_hat, dgamma_hat and dw_up0 are all non-NULL also the IGDN parameter gradients and up0's weight
- *           gradient [ch][8][5][5][5] (overwritten).  One workgroup per block, intermediates in LDS.
+ *           gradient [ch][8][5][5][5] (overwritten).  Intermediates in LDS; the workspace (always required)
+ *           also holds conv0's backward-data partials, batch x 8 x 512 floats.
  * Weights are the packed layouts: *_w_fwd = [cin][125][cout], *_w_bwd = [cout][125][cin]. */
 int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
                  const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
                  float* y1, int batch, int ch, int c0, int c1, void* stream);
-size_t nvf_stem_bwd_workspace(int ch);
+size_t nvf_stem_bwd_workspace(int batch, int ch);
 int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                  const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
                  float* dbeta_hat, float* dgamma_hat, float* dw_up0, void* workspace, size_t workspace_bytes,
@@ -114,6 +115,15 @@ size_t nvf_wgrad_workspace(int batch, int a, int b, int k, int dp, int hp, int w
 int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch, int a,
               int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq, int out_mode,
               int accumulate, int variant, void* stream);
+/* The same gradient in two separate steps, so that a whole backward pass needs ONE reduction launch:
+ * nvf_wgrad_partial launches only the partial sums (slabs stay in `workspace`, which the caller must not reuse
+ * until the reduction; *nslab = number of slabs, 0 when dw was written directly), nvf_wgrad_reduce_multi adds the
+ * slabs of up to 16 gradients in the same fixed order as nvf_wgrad (results identical bit for bit). */
+int nvf_wgrad_partial(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch,
+                      int a, int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq,
+                      int out_mode, int variant, int* nslab, void* stream);
+int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const int* nslabs, const int* jtotals,
+                           int n, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */

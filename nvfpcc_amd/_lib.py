@@ -27,10 +27,12 @@ PROTOTYPES = {
     "nvf_conv3d_gather": (I, [P, P, P, P, P, P] + [I] * 14 + [P]),
     "nvf_convT3d_k5s2_fwd": (I, [P, P, P, P] + [I] * 12 + [P]),
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
-    "nvf_stem_bwd_workspace": (Z, [I]),
+    "nvf_stem_bwd_workspace": (Z, [I, I]),
     "nvf_stem_bwd": (I, [P] * 13 + [Z, I, I, I, I, P]),
     "nvf_wgrad_workspace": (Z, [I] * 7),
     "nvf_wgrad": (I, [P, P, P, P, Z] + [I] * 15 + [P]),
+    "nvf_wgrad_partial": (I, [P, P, P, P, Z] + [I] * 14 + [P, P]),
+    "nvf_wgrad_reduce_multi": (I, [P, P, P, P, I, P]),
     "nvf_channel_sum_workspace": (Z, [I]),
     "nvf_channel_sum": (I, [P, P, P, Z, I, I, I, I, P]),
     "nvf_multi_channel_sum_workspace": (Z, [I]),

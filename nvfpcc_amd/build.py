@@ -40,13 +40,19 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    inc = os.path.join(HERE, "..", "include")
+    hdr_t = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")] +
+                [os.path.getmtime(os.path.join(inc, f)) for f in os.listdir(inc)])
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force and os.path.isfile(obj) and
+                os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src)))):
+            continue          # object is newer than its source and every header
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

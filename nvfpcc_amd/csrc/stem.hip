@@ -5,10 +5,12 @@
 //              plus up0's weight gradient
 //
 // These layers are < 1 % of the step's FLOPs but, as separate launches over a
-// batch of 16 blocks, each is a latency chain on a handful of CUs.  Here one workgroup owns one block, keeps
-// every intermediate in LDS, and walks the reference's operator sequence (utils/network.py:4759-4760,
-// gdn_3d.py:137-159) in one launch.  Accumulation orders equal those of the per-layer kernels
-// (conv_direct.hip), so the forward is bit-identical to the unfused path.
+// batch of 16 blocks, each is a latency chain on a handful of CUs.  Here the reference's operator sequence
+// (utils/network.py:4759-4760, gdn_3d.py:137-159) runs with every intermediate in LDS: the forward is one launch
+// of (block, conv0 channel group) workgroups, the backward two (conv0's backward-data over (block, channel pair)
+// workgroups, then one workgroup per block for IGDN / up0).  Weights are copied to LDS with coalesced vector
+// loads before use.  Accumulation orders equal those of the per-layer kernels (conv_direct.hip), so the forward
+// is bit-identical to the unfused path.
 #include "nvf_common.h"
 
 #define NVF_PEDESTAL 1.4551915228366852e-11f
@@ -28,6 +30,39 @@ __device__ __forceinline__ float st_gamma(float gh) {
 }
 }  // namespace
 
+// conv0 for one output parity class (EZ,EY,EX): lane = cell, COG output channels in registers, taps unrolled so
+// the LDS reads of a whole input channel are in flight together.  Weights come from the LDS copy s_w[ci*125+tap][COG].
+template <int EZ, int EY, int EX, int COG>
+__device__ __forceinline__ void stem_conv0_class(const float* s_h, const float* s_w, const float* __restrict__ b1,
+                                                 float* __restrict__ y1, int b, int co0, int v) {
+  const int mz = (v >> 4) + 1, my = ((v >> 2) & 3) + 1, mx = (v & 3) + 1;   // cells 1..4 (pad 2)
+  float acc[COG];
+#pragma unroll
+  for (int co = 0; co < COG; ++co) acc[co] = 0.f;
+#pragma unroll 2
+  for (int ci = 0; ci < C0; ++ci) {
+#pragma unroll
+    for (int jz = 0; jz < 3 - EZ; ++jz)
+#pragma unroll
+      for (int jy = 0; jy < 3 - EY; ++jy)
+#pragma unroll
+        for (int jx = 0; jx < 3 - EX; ++jx) {
+          const float hv = s_h[ci * 216 + ((mz - jz + 1) * 6 + (my - jy + 1)) * 6 + (mx - jx + 1)];
+          const float* wr = s_w + (ci * 125 + ((EZ + 2 * jz) * 5 + (EY + 2 * jy)) * 5 + EX + 2 * jx) * COG;
+#pragma unroll
+          for (int co = 0; co < COG; ++co) acc[co] = fmaf(hv, wr[co], acc[co]);
+        }
+  }
+  const int qz = 2 * mz + EZ - 2, qy = 2 * my + EY - 2, qx = 2 * mx + EX - 2;   // in [0, 8)
+#pragma unroll
+  for (int co = 0; co < COG; ++co)
+    y1[((size_t)b * C1 + co0 + co) * 512 + (qz * 8 + qy) * 8 + qx] = fmaxf(acc[co] + b1[co0 + co], 0.f);
+}
+
+// grid = (batch, C1 / COG): every workgroup recomputes the (tiny) up0 + IGDN of its block and produces COG of
+// conv0's 16 output channels, so a batch of 16 blocks runs on 64 CUs instead of 16.  All weights are copied to
+// LDS with coalesced vector loads first: scalar loads in the tap loops were a chain of cache misses.
+template <int COG>
 __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w0,
                                                        const float* __restrict__ b0,
                                                        const float* __restrict__ beta_hat,
@@ -38,9 +73,13 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
   __shared__ float s_x[MAXCH * 8];
   __shared__ float s_a[C0 * 64];
   __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_w0[MAXCH * 125 * C0];
+  __shared__ __attribute__((aligned(16))) float s_w1[C0 * 125 * COG];
+  const int b = blockIdx.x, part = blockIdx.y, co0 = part * COG, tid = threadIdx.x;
   if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
   for (int e = tid; e < C0 * 216; e += 512) s_h[e] = 0.f;
+  for (int e = tid; e < ch * 125 * C0; e += 512) s_w0[e] = w0[e];
+  for (int e = tid; e < C0 * 125 * COG; e += 512) s_w1[e] = w1[(size_t)(e / COG) * C1 + co0 + e % COG];
   __syncthreads();
   const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
   {  // up0: a0[co = c, o] = b0 + sum_ci sum_{k : o + 2 - k = 2 i} x0[ci, i] w0[ci][k][co]
@@ -56,13 +95,13 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
             const int ux = ox + 2 - kx;
             if (ux < 0 || (ux & 1) || (ux >> 1) >= 2) continue;
             acc = fmaf(s_x[ci * 8 + (uz >> 1) * 4 + (uy >> 1) * 2 + (ux >> 1)],
-                       w0[(ci * 125 + (kz * 5 + ky) * 5 + kx) * C0 + c], acc);
+                       s_w0[(ci * 125 + (kz * 5 + ky) * 5 + kx) * C0 + c], acc);
           }
         }
       }
     const float val = acc + b0[c];
     s_a[tid] = val;
-    a0[(size_t)b * C0 * 64 + tid] = val;
+    if (part == 0) a0[(size_t)b * C0 * 64 + tid] = val;
   }
   __syncthreads();
   {  // IGDN: h0 = a0 * sqrt(beta_c + sum_j gamma_cj a0_j^2)
@@ -72,30 +111,20 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
       nrm = fmaf(st_gamma(gamma_hat[c * C0 + j]), xj * xj, nrm);
     }
     const float hv = s_a[tid] * sqrtf(nrm);
-    h0[(size_t)b * C0 * 64 + tid] = hv;
+    if (part == 0) h0[(size_t)b * C0 * 64 + tid] = hv;
     s_h[c * 216 + ((oz + 1) * 6 + (oy + 1)) * 6 + ox + 1] = hv;
   }
   __syncthreads();
-  {  // conv0: one wave per output parity class, one lane per cell, all 16 output channels in registers
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ez = wv >> 2, ey = (wv >> 1) & 1, ex = wv & 1;
-    const int mz = (v >> 4) + 1, my = ((v >> 2) & 3) + 1, mx = (v & 3) + 1;   // cells 1..4 (pad 2)
-    float acc[C1];
-#pragma unroll
-    for (int co = 0; co < C1; ++co) acc[co] = 0.f;
-    for (int ci = 0; ci < C0; ++ci)
-      for (int jz = 0; jz < 3 - ez; ++jz)
-        for (int jy = 0; jy < 3 - ey; ++jy)
-          for (int jx = 0; jx < 3 - ex; ++jx) {
-            const float hv = s_h[ci * 216 + ((mz - jz + 1) * 6 + (my - jy + 1)) * 6 + (mx - jx + 1)];
-            const float* wr = w1 + (size_t)(ci * 125 + ((ez + 2 * jz) * 5 + (ey + 2 * jy)) * 5 + ex + 2 * jx) * C1;
-#pragma unroll
-            for (int co = 0; co < C1; ++co) acc[co] = fmaf(hv, wr[co], acc[co]);
-          }
-    const int qz = 2 * mz + ez - 2, qy = 2 * my + ey - 2, qx = 2 * mx + ex - 2;   // in [0, 8)
-#pragma unroll
-    for (int co = 0; co < C1; ++co)
-      y1[((size_t)b * C1 + co) * 512 + (qz * 8 + qy) * 8 + qx] = fmaxf(acc[co] + b1[co], 0.f);
+  // conv0: one wave per output parity class, one lane per cell
+  switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+    case 0: stem_conv0_class<0, 0, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    case 1: stem_conv0_class<0, 0, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    case 2: stem_conv0_class<0, 1, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    case 3: stem_conv0_class<0, 1, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    case 4: stem_conv0_class<1, 0, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    case 5: stem_conv0_class<1, 0, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    case 6: stem_conv0_class<1, 1, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+    default: stem_conv0_class<1, 1, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
   }
 }
 
@@ -105,8 +134,9 @@ extern "C" int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float
   if (!x0 || !up0_w_fwd || !up0_b || !beta_hat || !gamma_hat || !conv0_w_fwd || !conv0_b || !a0 || !h0 || !y1)
     return NVF_EINVAL;
   if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
-  stem_fwd_kernel<<<batch, 512, 0, nvf_stream(stream)>>>(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd,
-                                                         conv0_b, a0, h0, y1, ch);
+  constexpr int COG = 4;
+  stem_fwd_kernel<COG><<<dim3(batch, C1 / COG), 512, 0, nvf_stream(stream)>>>(
+      x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -118,24 +148,64 @@ static const int kStemMaxSlabs = 256;
 static const int kStemNcol = C0 + C0 * C0;          // IGDN parameter partials
 static const int kStemWMax = MAXCH * C0 * 125;      // up0 weight-gradient slab
 
-__global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ x0,
+// conv0 backward-data, split over (block, output-channel pair): part[b][cp][ci][i] = sum over the pair's two co and
+// all 125 taps of g1[co, 2 i - 2 + k] w1[ci][co][k].  256 threads: wave = input-channel pair, lane = position i.
+// The pair's gradients (zero-padded) and weights sit in LDS; each lane runs the same fmaf chain (cc, kz, ky, kx
+// ascending) the single-workgroup version ran, so the partials and their fixed-order sum are unchanged bit for bit.
+__global__ __launch_bounds__(256) void stem_bwd_dh_kernel(const float* __restrict__ g1,
+                                                          const float* __restrict__ w1b /* [co16][125][ci8] */,
+                                                          float* __restrict__ part) {
+  __shared__ float s_g[2 * 1331];                                   // [cc][11][11][11], index q + 2
+  __shared__ __attribute__((aligned(16))) float s_w[2 * 125 * C0];  // [cc][k][ci]
+  const int b = blockIdx.x, cp = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < 2 * 1331; e += 256) s_g[e] = 0.f;
+  for (int e = tid; e < 2 * 125 * C0; e += 256) s_w[e] = w1b[(size_t)cp * 2 * 125 * C0 + e];
+  __syncthreads();
+  for (int e = tid; e < 2 * 512; e += 256) {
+    const int cc = e >> 9, q = e & 511;
+    s_g[cc * 1331 + (((q >> 6) + 2) * 11 + ((q >> 3) & 7) + 2) * 11 + (q & 7) + 2] =
+        g1[((size_t)b * C1 + 2 * cp) * 512 + e];
+  }
+  __syncthreads();
+  const int iz = lane >> 4, iy = (lane >> 2) & 3, ix = lane & 3;
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 1
+  for (int cc = 0; cc < 2; ++cc) {
+    const float* gp = s_g + cc * 1331 + ((2 * iz) * 11 + 2 * iy) * 11 + 2 * ix;   // q + 2 = 2 i + k
+    const float* wp = s_w + cc * 125 * C0 + 2 * wv;
+#pragma unroll 1
+    for (int kz = 0; kz < 5; ++kz)
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float gv = gp[(kz * 11 + ky) * 11 + kx];
+          const float2 w = *(const float2*)(wp + ((kz * 5 + ky) * 5 + kx) * C0);
+          acc0 = fmaf(gv, w.x, acc0);
+          acc1 = fmaf(gv, w.y, acc1);
+        }
+  }
+  float* o = part + (((size_t)b * 8 + cp) * C0 + 2 * wv) * 64 + lane;
+  o[0] = acc0;
+  o[64] = acc1;
+}
+
+__global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__ part, const float* __restrict__ x0,
                                                        const float* __restrict__ a0,
-                                                       const float* __restrict__ w1b /* [co16][125][ci8] */,
                                                        const float* __restrict__ w0b /* [co8][125][ch] */,
                                                        const float* __restrict__ beta_hat,
                                                        const float* __restrict__ gamma_hat, float* __restrict__ da0,
                                                        float* __restrict__ dx0, float* __restrict__ slab_gdn,
                                                        float* __restrict__ slab_w, int batch, int ch, int want_w) {
-  __shared__ float s_g[C1 * 1331];      // g1 with a two-voxel zero halo: [co][11][11][11], index q + 2
-  __shared__ float s_part[8][512];      // per-wave partial dh0
   __shared__ float s_dh[512], s_a[512], s_n[512], s_t[512];
   __shared__ float s_da[C0 * 343];      // da0 with a two-voxel halo: [co][7][7][7], index q + 2
   __shared__ float s_x[MAXCH * 8];
+  __shared__ float s_w0[C0 * 125 * MAXCH];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = tid >> 6, v = lane, iz = v >> 4, iy = (v >> 2) & 3, ix = v & 3;
-  for (int e = tid; e < C1 * 1331; e += 512) s_g[e] = 0.f;
   for (int e = tid; e < C0 * 343; e += 512) s_da[e] = 0.f;
+  for (int e = tid; e < C0 * 125 * ch; e += 512) s_w0[e] = w0b[e];
   float own_gdn = 0.f;                  // thread p < 72 owns IGDN partial p
   float own_w[(kStemWMax + 511) / 512]; // up0 weight-gradient outputs j = tid + 512 r
 #pragma unroll
@@ -144,43 +214,18 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
   __syncthreads();
 
   for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-    // ---- stage g1[b] (interior of the padded tile), a0[b], x0[b]
-    for (int e = tid; e < C1 * 512; e += 512) {
-      const int co = e >> 9, q = e & 511;
-      s_g[co * 1331 + (((q >> 6) + 2) * 11 + ((q >> 3) & 7) + 2) * 11 + (q & 7) + 2] = g1[(size_t)b * C1 * 512 + e];
-    }
     s_a[tid] = a0[(size_t)b * C0 * 64 + tid];
     if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
-    __syncthreads();
-    // ---- conv0 backward-data: dh0[ci, i] = sum_co sum_k g1[co, 2 i - 2 + k] w1[ci][co][k]; wave wv takes two co
     {
-      float acc[C0];
+      // dh0 = the eight channel-pair partials of conv0's backward-data, added in ascending order
+      float dh = 0.f;
 #pragma unroll
-      for (int ci = 0; ci < C0; ++ci) acc[ci] = 0.f;
-      for (int cc = 0; cc < 2; ++cc) {
-        const int co = 2 * wv + cc;
-        const float* gp = s_g + co * 1331 + ((2 * iz) * 11 + 2 * iy) * 11 + 2 * ix;   // q + 2 = 2 i + k
-#pragma unroll 1
-        for (int kz = 0; kz < 5; ++kz)
-#pragma unroll 1
-          for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-              const float gv = gp[(kz * 11 + ky) * 11 + kx];
-              const float* wr = w1b + (size_t)(co * 125 + (kz * 5 + ky) * 5 + kx) * C0;    // wave-uniform
-#pragma unroll
-              for (int ci = 0; ci < C0; ++ci) acc[ci] = fmaf(gv, wr[ci], acc[ci]);
-            }
-      }
-#pragma unroll
-      for (int ci = 0; ci < C0; ++ci) s_part[wv][ci * 64 + lane] = acc[ci];
+      for (int w = 0; w < 8; ++w) dh += part[((size_t)b * 8 + w) * 512 + tid];
+      s_dh[tid] = dh;
     }
     __syncthreads();
     {
-      float dh = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) dh += s_part[w][tid];
-      s_dh[tid] = dh;
+      const float dh = s_dh[tid];
       // IGDN forward quantities of this voxel/channel: n_c, t_c = dh_c a_c / n_c
       float nrm = st_beta(beta_hat[c]);
       for (int j = 0; j < C0; ++j) {
@@ -218,14 +263,15 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
       const int out = tid >> 3, co = tid & 7, ci = out >> 3, i = out & 7;
       const int jz = i >> 2, jy = (i >> 1) & 1, jx = i & 1;
       const float* dp = s_da + co * 343 + ((2 * jz) * 7 + 2 * jy) * 7 + 2 * jx;
+      const float* wp = s_w0 + co * 125 * ch + ci;
       float acc = 0.f;
 #pragma unroll 1
       for (int kz = 0; kz < 5; ++kz)
-#pragma unroll 1
+#pragma unroll
         for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 5; ++kx)
-            acc = fmaf(dp[(kz * 7 + ky) * 7 + kx], w0b[(size_t)(co * 125 + (kz * 5 + ky) * 5 + kx) * ch + ci], acc);
+            acc = fmaf(dp[(kz * 7 + ky) * 7 + kx], wp[((kz * 5 + ky) * 5 + kx) * ch], acc);
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
       acc += __shfl_xor(acc, 4, 64);
@@ -287,8 +333,9 @@ __global__ void stem_w_final(const float* __restrict__ slabs, float* __restrict_
   dw[j] = s;
 }
 
-extern "C" size_t nvf_stem_bwd_workspace(int ch) {
-  return (size_t)kStemMaxSlabs * (kStemNcol + (size_t)ch * C0 * 125) * sizeof(float);
+extern "C" size_t nvf_stem_bwd_workspace(int batch, int ch) {
+  return ((size_t)kStemMaxSlabs * (kStemNcol + (size_t)ch * C0 * 125) + (size_t)(batch > 0 ? batch : 0) * 8 * 512) *
+         sizeof(float);
 }
 
 extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
@@ -298,13 +345,15 @@ extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, c
   if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0) return NVF_EINVAL;
   if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
   const int want_w = dbeta_hat && dgamma_hat && dw_up0;
-  if (want_w && (!workspace || workspace_bytes < nvf_stem_bwd_workspace(ch))) return NVF_EWORKSPACE;
+  if (!workspace || workspace_bytes < nvf_stem_bwd_workspace(batch, ch)) return NVF_EWORKSPACE;
   const int nslab = batch < kStemMaxSlabs ? batch : kStemMaxSlabs;
   float* slab_gdn = (float*)workspace;
-  float* slab_w = slab_gdn ? slab_gdn + (size_t)kStemMaxSlabs * kStemNcol : nullptr;
+  float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * kStemNcol;
+  float* part = slab_w + (size_t)kStemMaxSlabs * ch * C0 * 125;
   hipStream_t s = nvf_stream(stream);
-  stem_bwd_kernel<<<nslab, 512, 0, s>>>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn,
-                                        slab_w, batch, ch, want_w);
+  stem_bwd_dh_kernel<<<dim3(batch, 8), 256, 0, s>>>(g1, conv0_w_bwd, part);
+  stem_bwd_kernel<<<nslab, 512, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn, slab_w,
+                                        batch, ch, want_w);
   if (want_w) {
     stem_gdn_final<<<(kStemNcol + 63) / 64, 64, 0, s>>>(slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab);
     const int jtotal = ch * C0 * 125;

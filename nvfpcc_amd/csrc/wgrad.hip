@@ -283,13 +283,14 @@ __global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g
 
 template <class C>
 static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* slabs, WgDims d, int accumulate,
-                             hipStream_t s) {
+                             hipStream_t s, int* defer_nslab) {
   d.items = d.batch * (C::W / C::TY) * (C::W / C::TZ);
   int nslab = d.items < kMaxSlabs ? d.items : kMaxSlabs;
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
   wgrad_k4_mfma<C><<<nslab, 256, 0, s>>>(g, x, slabs, d);
-  wgrad_reduce<<<(4096 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
+  if (defer_nslab) *defer_nslab = nslab;
+  else wgrad_reduce<<<(4096 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
   return NVF_OK;
 }
 
@@ -320,7 +321,7 @@ extern "C" size_t nvf_wgrad_workspace(int batch, int a, int b, int k, int dp, in
 
 template <class C>
 static int launch_wgrad(const float* p, const float* q, float* dw, float* slabs, WgDims d, int accumulate,
-                        hipStream_t s) {
+                        hipStream_t s, int* defer_nslab) {
   d.tiles_x = d.wp / C::TX;
   d.tiles_y = d.hp / C::TY;
   d.tiles_z = d.dp / C::TZ;
@@ -330,13 +331,14 @@ static int launch_wgrad(const float* p, const float* q, float* dw, float* slabs,
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
   wgrad_tiled<C><<<dim3(nslab, ygroups), C::NT, 0, s>>>(p, q, slabs, d);
-  wgrad_reduce<<<(d.jtotal + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, d.jtotal, accumulate);
+  if (defer_nslab) *defer_nslab = nslab;
+  else wgrad_reduce<<<(d.jtotal + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, d.jtotal, accumulate);
   return NVF_OK;
 }
 
-extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch,
-                         int a, int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq,
-                         int out_mode, int accumulate, int variant, void* stream) {
+static int wgrad_dispatch(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch,
+                          int a, int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq,
+                          int out_mode, int accumulate, int variant, void* stream, int* defer_nslab) {
   if (!p || !q || !dw || batch <= 0 || a <= 0 || b <= 0 || k <= 0 || stride <= 0) return NVF_EINVAL;
   if (dp <= 0 || hp <= 0 || wp <= 0 || dq <= 0 || hq <= 0 || wq <= 0) return NVF_EINVAL;
   if (out_mode != 0 && out_mode != 1) return NVF_EINVAL;
@@ -351,13 +353,13 @@ extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* worksp
 #define NVF_W(VAR, AA, KS, ST, WP, NB, TX, TY, TZ, IXU)                                                          \
   if (rc == 1 && variant == VAR && a == AA && k == KS && stride == ST && wp == WP && hp % TY == 0 && dp % TZ == 0 && \
       b % NB == 0)                                                                                                 \
-    rc = launch_wgrad<WCfg<AA, KS, ST, NB, TX, TY, TZ, IXU>>(p, q, dw, slabs, d, accumulate, s);
+    rc = launch_wgrad<WCfg<AA, KS, ST, NB, TX, TY, TZ, IXU>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
     const bool cube_k4 = a == 8 && b == 8 && k == 4 && stride == 1 && pad == 0 && out_mode == 0 && dp == wp &&
                          hp == wp && dq == wp + 3 && hq == wp + 3 && wq == wp + 3;
-    if (rc == 1 && variant == 0 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 4, 4>>(p, q, dw, slabs, d, accumulate, s);
-    if (rc == 1 && variant == 0 && cube_k4 && wp == 16) rc = launch_wgrad_mfma<MCfg<16, 2, 8>>(p, q, dw, slabs, d, accumulate, s);
-    if (rc == 1 && variant == 7 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 8>>(p, q, dw, slabs, d, accumulate, s);
-    if (rc == 1 && variant == 8 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 4>>(p, q, dw, slabs, d, accumulate, s);
+    if (rc == 1 && variant == 0 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 4, 4>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
+    if (rc == 1 && variant == 0 && cube_k4 && wp == 16) rc = launch_wgrad_mfma<MCfg<16, 2, 8>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
+    if (rc == 1 && variant == 7 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 8>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
+    if (rc == 1 && variant == 8 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 4>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
     NVF_W(9, 8, 4, 1, 32, 8, 32, 8, 2, 0)    // conv2 narrow, VALU form: p = dY [8,32^3], q = X [8,35^3]
     NVF_W(9, 8, 4, 1, 16, 8, 16, 8, 2, 0)    // conv1 narrow, VALU form
     NVF_W(0, 8, 5, 2, 16, 4, 16, 4, 2, 0)    // up2 narrow: p = X [8,16^3], q = dY [8,35^3]
@@ -394,10 +396,79 @@ extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* worksp
   }
   if (rc == 1) {
     wgrad_naive<<<(d.jtotal + 63) / 64, 64, 0, s>>>(p, q, dw, a, k, stride, d, accumulate);
+    if (defer_nslab) *defer_nslab = 0;   // dw is already final
     rc = NVF_OK;
   }
   NVF_LAUNCH_CHECK();
   return rc;
+}
+
+extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch,
+                         int a, int b, int k, int stride, int pad, int dp, int hp, int wp, int dq, int hq, int wq,
+                         int out_mode, int accumulate, int variant, void* stream) {
+  return wgrad_dispatch(p, q, dw, workspace, workspace_bytes, batch, a, b, k, stride, pad, dp, hp, wp, dq, hq, wq,
+                        out_mode, accumulate, variant, stream, nullptr);
+}
+
+// The partial-sum launch only: slabs land in `workspace` (which must stay untouched until the reduction), *nslab
+// tells how many (0: no slabs, dw was written directly).  nvf_wgrad_reduce_multi then finishes up to 16 such
+// gradients in ONE launch -- a backward pass has ten, and ten tiny reductions were ten launch gaps.
+extern "C" int nvf_wgrad_partial(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes,
+                                 int batch, int a, int b, int k, int stride, int pad, int dp, int hp, int wp, int dq,
+                                 int hq, int wq, int out_mode, int variant, int* nslab, void* stream) {
+  if (!nslab) return NVF_EINVAL;
+  return wgrad_dispatch(p, q, dw, workspace, workspace_bytes, batch, a, b, k, stride, pad, dp, hp, wp, dq, hq, wq,
+                        out_mode, 0, variant, stream, nslab);
+}
+
+struct WgReduceMulti {
+  const float* slabs[16];
+  float* dw[16];
+  int32_t nslab[16], jtotal[16], blk_base[17];
+  int32_t n;
+};
+
+// same arithmetic as wgrad_reduce (16 interleaved slices in ascending slab order, then slices 0..15)
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi(WgReduceMulti d) {
+  __shared__ float part[16][64];
+  int t = 0;
+  while (t + 1 < d.n && (int)blockIdx.x >= d.blk_base[t + 1]) ++t;
+  const float* slabs = d.slabs[t];
+  const int nslab = d.nslab[t], jtotal = d.jtotal[t];
+  const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int j = ((int)blockIdx.x - d.blk_base[t]) * 64 + jl;
+  float s = 0.f;
+  if (j < jtotal)
+    for (int g = sl; g < nslab; g += 16) s += slabs[(size_t)g * jtotal + j];
+  part[sl][jl] = s;
+  __syncthreads();
+  if (sl == 0 && j < jtotal) {
+    float v = part[0][jl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += part[k][jl];
+    d.dw[t][j] = v;
+  }
+}
+
+extern "C" int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const int* nslabs,
+                                      const int* jtotals, int n, void* stream) {
+  if (!slabs || !dws || !nslabs || !jtotals || n <= 0 || n > 16) return NVF_EINVAL;
+  WgReduceMulti d{};
+  int base = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (nslabs[i] == 0) continue;     // written directly by the partial launch
+    if (!slabs[i] || !dws[i] || nslabs[i] < 0 || jtotals[i] <= 0) return NVF_EINVAL;
+    d.slabs[m] = slabs[i]; d.dw[m] = dws[i]; d.nslab[m] = nslabs[i]; d.jtotal[m] = jtotals[i];
+    d.blk_base[m] = base;
+    base += (jtotals[i] + 63) / 64;
+    ++m;
+  }
+  d.blk_base[m] = base;
+  d.n = m;
+  if (m == 0) return NVF_OK;
+  wgrad_reduce_multi<<<base, 1024, 0, nvf_stream(stream)>>>(d);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 // ---------------------------------------------------------------------------

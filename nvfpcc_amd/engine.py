@@ -83,6 +83,7 @@ class TrainEngine:
         self.fused_stem = tuple(net.reconstructor.channels[:2]) == (8, 16) and net.entropy_coder.sigma.shape[1] <= 8
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
+        self._wg = None
 
     # ------------------------------------------------------------------ parameters
     def _flatten_parameters(self):
@@ -197,11 +198,11 @@ class TrainEngine:
         return torch.cuda.stream(self.side) if self.overlap else _NullCtx()
 
     def _wgrad_conv(self, L, g_out, x_in):
-        ops.wgrad(g_out, x_in, L.k, 1, L.pad, out_mode=0, out=L.gk)
+        self._wg.add(g_out, x_in, L.k, 1, L.pad, 0, L.gk)
         self._bias_jobs.append((g_out, L.gb))
 
     def _wgrad_convT(self, L, g_out, x_in):
-        ops.wgrad(x_in, g_out, 5, 2, L.pad, out_mode=0, out=L.gk)
+        self._wg.add(x_in, g_out, 5, 2, L.pad, 0, L.gk)
         self._bias_jobs.append((g_out, L.gb))
 
     def _dx_conv(self, L, g_out, x_in, mask=None, addend=None):
@@ -221,6 +222,8 @@ class TrainEngine:
         main = torch.cuda.current_stream()
         self.overlap = self.allow_overlap and a["e"].shape[0] <= 64
         self._bias_jobs = []
+        if self._wg is None:
+            self._wg = ops.WgradBatch(self.dev)    # partial sums now, ONE reduction launch for all ten gradients
         loss = torch.empty(4, device=self.dev)   # [main, head0, head1, unused]
         nbits = torch.empty(7, device=self.dev)
         dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
@@ -300,6 +303,7 @@ class TrainEngine:
         self._fork()
         with self._on_side():
             if want_w:
+                self._wg.finish()
                 ops.multi_channel_sum([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
                 ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
                                       g_host=g_net * self.rate_grad_scale)

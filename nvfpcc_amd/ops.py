@@ -149,7 +149,7 @@ def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=
     B, ch = x0.shape[0], x0.shape[1]
     da0 = torch.empty_like(a0)
     dx0 = torch.empty_like(x0)
-    ws = workspace(lib().nvf_stem_bwd_workspace(ch), x0.device, "stem")
+    ws = workspace(lib().nvf_stem_bwd_workspace(B, ch), x0.device, "stem")
     check(lib().nvf_stem_bwd(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
                              _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
                              _ptr(dw_up0), _ptr(ws), ws.numel(), B, ch, 8, 16, _stream()), "nvf_stem_bwd")
@@ -168,6 +168,47 @@ def wgrad(p, q, k, stride, pad, out_mode=0, out=None, accumulate=False):
     check(lib().nvf_wgrad(_ptr(p), _ptr(q), _ptr(dw), _ptr(ws), ws.numel(), B, a, b, k, stride, pad, dp, hp, wp, dq,
                           hq, wq, out_mode, int(accumulate), _NAIVE, _stream()), "nvf_wgrad")
     return dw
+
+
+class WgradBatch:
+    """Weight gradients of one backward pass with a single reduction launch: ``add`` launches only the partial
+    sums (each gradient keeps its own slab region until ``finish``), ``finish`` adds all slabs in one kernel."""
+
+    def __init__(self, device, nbytes=128 << 20):
+        self.device, self.jobs, self.offset = device, [], 0
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._retired = []      # outgrown buffers stay alive: kernels on another stream may still read them
+
+    def add(self, p, q, k, stride, pad, out_mode, out):
+        import ctypes
+        _f32(p, q, out)
+        B, a, dp, hp, wp = p.shape
+        b, dq, hq, wq = q.shape[1], q.shape[2], q.shape[3], q.shape[4]
+        nbytes = int(lib().nvf_wgrad_workspace(B, a, b, k, dp, hp, wp))
+        if self.offset + nbytes > self.ws.numel():
+            if self.jobs:    # cannot move slabs that are already in flight: finish them first
+                self.finish()
+            self._retired.append(self.ws)
+            self.ws = torch.empty(max(nbytes, 2 * self.ws.numel()), dtype=torch.uint8, device=self.device)
+        base = self.ws.data_ptr() + self.offset
+        nslab = ctypes.c_int(0)
+        check(lib().nvf_wgrad_partial(_ptr(p), _ptr(q), _ptr(out), base, nbytes, B, a, b, k, stride, pad, dp, hp, wp,
+                                      dq, hq, wq, out_mode, _NAIVE, ctypes.byref(nslab), _stream()),
+              "nvf_wgrad_partial")
+        self.jobs.append((base, out.data_ptr(), nslab.value, a * b * k ** 3))
+        self.offset += (nbytes + 255) // 256 * 256
+
+    def finish(self):
+        import ctypes
+        jobs, self.jobs, self.offset = self.jobs, [], 0
+        for i in range(0, len(jobs), 16):
+            chunk = jobs[i:i + 16]
+            n = len(chunk)
+            check(lib().nvf_wgrad_reduce_multi((ctypes.c_void_p * n)(*[j[0] for j in chunk]),
+                                               (ctypes.c_void_p * n)(*[j[1] for j in chunk]),
+                                               (ctypes.c_int * n)(*[j[2] for j in chunk]),
+                                               (ctypes.c_int * n)(*[j[3] for j in chunk]), n, _stream()),
+                  "nvf_wgrad_reduce_multi")
 
 
 def channel_sum(x, out=None, accumulate=False):
