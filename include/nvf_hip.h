@@ -86,6 +86,23 @@ int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float* bias, floa
                          int pad, int din, int hin, int win, int dout, int hout, int wout, int act, int variant,
                          void* stream);
 
+/* ---- matrix-core (v_mfma_f32_16x16x4_f32, exact fp32) form of the 4^3 convolutions with 8 output channels
+ * (conv1 / conv2 of chanstr 8,16,8,8: F.conv3d network.py:687 and its autograd backward-data).  Same contract
+ * as nvf_conv3d_gather with k = 4, stride 1, but the weights are pre-packed MFMA A-fragments:
+ *   nvf_pack_mfma_k4(gather_w [cin][64][8] (= w_fwd, or w_bwd for the backward-data pass), cin, 8, pair_axis, wp)
+ *   pair_axis 0: rows pair outputs along x (forward, pad 0); 2: along z (backward-data, pad 3)
+ * wp holds nvf_pack_mfma_k4_floats(cin, pair_axis) floats (layout [ci group][ky][kx][kz][lane]).  Per-output accumulation order is fixed
+ * (input-channel group, ky, kx, kz), so results do not depend on batch size or tiling; they differ from
+ * nvf_conv3d_gather's order by fp32 rounding only.  NVF_EINVAL = no instantiation for this shape. */
+size_t nvf_pack_mfma_k4_floats(int cin, int pair_axis);
+int nvf_pack_mfma_k4(const float* gather_w, int cin, int cout, int pair_axis, float* wp, void* stream);
+/* up to 8 packings (8 output channels each) in one launch */
+int nvf_pack_mfma_k4_multi(const float* const* gather_ws, float* const* wps, const int* cins, const int* pair_axes,
+                           int n, void* stream);
+int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* bias, float* y, const float* addend,
+                       const float* mask, int batch, int cin, int cout, int pad, int pair_axis, int din, int hin,
+                       int win, int dout, int hout, int wout, int act, int variant, void* stream);
+
 /* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when

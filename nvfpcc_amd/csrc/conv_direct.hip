@@ -271,23 +271,6 @@ __global__ __launch_bounds__(C::NT) void conv_gather_tiled(const float* __restri
 // asm, so hipcc does not count it: the explicit vmcnt(0) before the barrier is the wait.
 // Results are bit-identical to conv_gather_tiled (same LDS image, same fmaf chain).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void nvf_glds_row(const float* row_base, unsigned voff_bytes, unsigned lds_byte) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff_bytes), "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "s"(row_base)
-      : "memory");
-}
-__device__ __forceinline__ void nvf_glds_lane(const float* src, unsigned lds_byte) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
-      : "memory");
-}
-
 template <class C>
 __device__ __forceinline__ void conv_glds_issue(const float* __restrict__ xc, unsigned lds_byte, int wave, int lane,
                                                 int gz0, int gy0, int gx0, const ConvDims& d) {

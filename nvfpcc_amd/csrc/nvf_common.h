@@ -124,3 +124,25 @@ __device__ __forceinline__ void nvf_lds_row(const float* p, float* out) {
     for (int i = 0; i < N; ++i) out[i] = p[i];
   }
 }
+
+// ---- LDS-DMA (global_load_lds_dword: HBM/L2 -> LDS with no VGPR destination) ----------------------
+// One wave-instruction writes LDS[m0 + 4*lane] for every active lane.  M0 is compiler-reserved, so it is
+// saved, set and restored inside the one asm statement that uses it; hipcc does not count these loads,
+// the caller waits with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void nvf_glds_row(const float* row_base, unsigned voff_bytes, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_bytes), "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "s"(row_base)
+      : "memory");
+}
+__device__ __forceinline__ void nvf_glds_lane(const float* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_byte))
+      : "memory");
+}
+

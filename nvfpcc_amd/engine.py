@@ -26,6 +26,7 @@ from .network import NoiseState
 R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
 TRUNK = ("up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls")
 HEADS = ("conv1_cls", "conv0_cls")
+MFMA_BWD = ("conv1",)      # layers whose backward-data also runs on the matrix cores (conv2's is faster on the VALU)
 
 _DESC = np.dtype([("kernel", "<u8"), ("kernel_init", "<u8"), ("b", "<u8"), ("b_init", "<u8"), ("w_fwd", "<u8"),
                   ("w_bwd", "<u8"), ("b_eff", "<u8"), ("dim0", "<i4"), ("dim1", "<i4"), ("k3", "<i4"),
@@ -41,7 +42,8 @@ class _NullCtx:
 
 
 class _Layer:
-    __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad")
+    __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
+                 "wp_b")
 
 
 class TrainEngine:
@@ -124,6 +126,12 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
+            L.wp_f = L.wp_b = None
+            if L.k == 4 and L.cin % 4 == 0 and L.cout == 8 and L.cin == 8 and L.pad == 0:
+                # matrix-core form of the 4^3 convolutions: MFMA A-fragments, re-packed after every weight preparation
+                L.wp_f = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cin, 0)), device=self.dev)
+                if name in MFMA_BWD:
+                    L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, 2)), device=self.dev)
             self.layers[name] = L
             t = table[i]
             t["kernel"], t["kernel_init"] = m.kernel.data_ptr(), m.kernel_init.data_ptr()
@@ -134,6 +142,8 @@ class TrainEngine:
             t["quantised"] = 1 if name in TRUNK else 0
             t["layer_id"] = m.layer_id
             t["nbias"] = m.b.numel()
+        self._mfma_jobs = [(L.w_fwd, L.cin, 0, L.wp_f) for L in self.layers.values() if L.wp_f is not None]
+        self._mfma_jobs += [(L.w_bwd, L.cout, 2, L.wp_b) for L in self.layers.values() if L.wp_b is not None]
         self._table_host = table
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.dev)
         self.nlayers = len(mods)
@@ -143,12 +153,16 @@ class TrainEngine:
         check(lib().nvf_prepare_weights(self.table.data_ptr(), self.nlayers, int(q), self.seed,
                                         0 if sd is not None else self.noise_step, None if sd is None else sd.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights")
+        if self._mfma_jobs:
+            ops.pack_mfma_k4_multi(self._mfma_jobs)
 
     # ------------------------------------------------------------------ forward
     def _convT(self, L, x, act):
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
     def _conv(self, L, x, act):
+        if L.wp_f is not None:
+            return ops.conv3d_k4_mfma(x, L.wp_f, L.b_eff, 0, 0, act)
         osz = tuple(s + 2 * L.pad - L.k + 1 for s in x.shape[2:])
         return ops.conv3d_gather(x, L.w_fwd, L.b_eff, L.cout, L.k, 1, L.pad, osz, act)
 
@@ -206,6 +220,8 @@ class TrainEngine:
         self._bias_jobs.append((g_out, L.gb))
 
     def _dx_conv(self, L, g_out, x_in, mask=None, addend=None):
+        if L.wp_b is not None:
+            return ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, 2, NONE, addend=addend, mask=mask)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
                                  addend=addend, mask=mask)
 

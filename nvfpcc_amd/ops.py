@@ -116,6 +116,53 @@ def conv3d_gather(x, w_packed, bias, cout, k, stride, pad, out_spatial, act=ACT_
     return y
 
 
+def pack_mfma_k4(gather_w, cin, pair_axis, out=None):
+    """MFMA A-fragments of a 4^3, 8-output-channel gather weight [cin][64][8] (w_fwd, or w_bwd for backward-data)."""
+    _f32(gather_w, out)
+    n = int(lib().nvf_pack_mfma_k4_floats(cin, pair_axis))
+    wp = out if out is not None else torch.empty(n, device=gather_w.device)
+    if gather_w.numel() != cin * 64 * 8 or wp.numel() != n:
+        raise RuntimeError("pack_mfma_k4: weight size does not match (cin, 4, 8)")
+    check(lib().nvf_pack_mfma_k4(_ptr(gather_w), cin, 8, pair_axis, _ptr(wp), _stream()), "nvf_pack_mfma_k4")
+    return wp
+
+
+def pack_mfma_k4_multi(jobs):
+    """jobs: list of (gather_w, cin, pair_axis, wp_out): all packed by one launch."""
+    import ctypes
+    n = len(jobs)
+    _f32(*[j[0] for j in jobs])
+    _f32(*[j[3] for j in jobs])
+    check(lib().nvf_pack_mfma_k4_multi((ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
+                                       (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in jobs]),
+                                       (ctypes.c_int * n)(*[j[1] for j in jobs]),
+                                       (ctypes.c_int * n)(*[j[2] for j in jobs]), n, _stream()),
+          "nvf_pack_mfma_k4_multi")
+
+
+def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=None, out=None):
+    """Matrix-core 4^3 convolution, 8 output channels: same contract as conv3d_gather(k=4, stride=1)."""
+    _f32(x, wp, bias, addend, mask)
+    B, cin, di, hi, wi = x.shape
+    do, ho, wo = di + 2 * pad - 3, hi + 2 * pad - 3, wi + 2 * pad - 3
+    y = out if out is not None else torch.empty((B, 8, do, ho, wo), device=x.device)
+    for t in (addend, mask):
+        if t is not None and t.shape != y.shape:
+            raise RuntimeError("addend/mask shape must equal the output shape")
+    check(lib().nvf_conv3d_k4_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(addend), _ptr(mask), B, cin, 8, pad,
+                                   pair_axis, di, hi, wi, do, ho, wo, act, _MFMA_VARIANT, _stream()),
+          "nvf_conv3d_k4_mfma")
+    return y
+
+
+_MFMA_VARIANT = int(os.environ.get("NVF_MFMA_VARIANT", "0"))
+
+
+def set_mfma_variant(v):
+    global _MFMA_VARIANT
+    _MFMA_VARIANT = int(v)
+
+
 def convT3d_k5s2_fwd(x, w_fwd, bias, cout, pad, act=ACT_NONE, out=None):
     _f32(x, w_fwd, bias)
     B, cin, di, hi, wi = x.shape

@@ -83,6 +83,44 @@ CONVT_CASES = [(3, 8, 2, 1, 2), (8, 16, 2, 1, 4), (16, 8, 0, 0, 8), (8, 8, 0, 0,
                (8, 16, 2, 1, 2), (16, 32, 2, 1, 4), (32, 16, 0, 0, 8), (16, 16, 0, 0, 16)]
 
 
+# matrix-core (MFMA) form of the 4^3, 8 -> 8 channel convolutions: (spatial_in, batch)
+@pytest.mark.parametrize("n,B", [(35, 2), (19, 3), (35, 1), (19, 5)])
+def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
+    """Forward (pair axis x) and backward-data (pair axis z) against torch's conv3d / its autograd: the MFMA is an
+    exact fp32 fmaf chain in its own fixed order, so the tolerance is the one of the VALU kernels; every variant
+    must also be invariant to the batch it runs in, bit for bit (encode at any batch == decode at batch 1)."""
+    g = gen(4000 + n + B)
+    x = torch.randn(B, 8, n, n, n, generator=g)
+    w = torch.randn(8, 8, 4, 4, 4, generator=g) / 512 ** 0.5
+    b = torch.randn(8, generator=g)
+    x.requires_grad_(True)
+    y_ref = F.conv3d(x, w, b)
+    wf, wb = ops.pack_conv_weight(dev(w))
+    wpf, wpb = ops.pack_mfma_k4(wf, 8, 0), ops.pack_mfma_k4(wb, 8, 2)
+    xd = dev(x.detach())
+    y = ops.conv3d_k4_mfma(xd, wpf, dev(b), 0, 0, ops.ACT_RELU)
+    assert (y.cpu() - F.relu(y_ref.detach())).abs().max() < 2e-5
+    y_lin = ops.conv3d_k4_mfma(xd, wpf, dev(b), 0, 0, ops.ACT_NONE)          # generic epilogue
+    assert (y_lin.cpu() - y_ref.detach()).abs().max() < 2e-5
+    for i in range(B):                                                       # batch invariance, bit for bit
+        yi = ops.conv3d_k4_mfma(xd[i:i + 1].contiguous(), wpf, dev(b), 0, 0, ops.ACT_RELU)
+        assert torch.equal(yi[0], y[i])
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    mask = torch.randn(x.shape, generator=g)
+    add = torch.randn(x.shape, generator=g)
+    dx = ops.conv3d_k4_mfma(dev(gy), wpb, None, 3, 2, ops.ACT_NONE, mask=dev(mask))
+    assert rel_err(dx, x.grad * (mask > 0)) < 1e-5
+    dx2 = ops.conv3d_k4_mfma(dev(gy), wpb, None, 3, 2, ops.ACT_NONE, addend=dev(add), mask=dev(mask))
+    assert rel_err(dx2, (x.grad + add) * (mask > 0)) < 1e-5
+    dx3 = ops.conv3d_k4_mfma(dev(gy), wpb, None, 3, 2, ops.ACT_NONE)
+    assert rel_err(dx3, x.grad) < 1e-5
+    # the multi-pack launch produces the same fragments
+    wpf2, wpb2 = torch.empty_like(wpf), torch.empty_like(wpb)
+    ops.pack_mfma_k4_multi([(wf, 8, 0, wpf2), (wb, 8, 2, wpb2)])
+    assert torch.equal(wpf, wpf2) and torch.equal(wpb, wpb2)
+
+
 @pytest.mark.parametrize("cin,cout,pad,opad,n", CONVT_CASES)
 def test_conv_transpose_forward_and_backward_data(ops, cin, cout, pad, opad, n):
     g = gen(cin * 100 + cout + pad)
