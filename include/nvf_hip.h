@@ -103,6 +103,16 @@ int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* bias, float
                        const float* mask, int batch, int cin, int cout, int pad, int pair_axis, int din, int hin,
                        int win, int dout, int hout, int wout, int act, int variant, void* stream);
 
+/* ---- matrix-core form of the transposed convolutions k5 s2 with 8 output channels and padding 0 (up1, up2 of
+ * chanstr 8,16,8,8; F.conv_transpose3d network.py:621).  Same contract as nvf_convT3d_k5s2_fwd; the weights are
+ * MFMA A-fragments: nvf_pack_convT_mfma(w_fwd [cin][125][8], cin, 8, wp), nvf_pack_convT_mfma_floats(cin) floats.
+ * Fixed per-output accumulation order (input-channel group, jy, jx, jz): independent of batch and tiling.
+ * NVF_EINVAL = no instantiation for this shape. */
+size_t nvf_pack_convT_mfma_floats(int cin);
+int nvf_pack_convT_mfma(const float* w_fwd, int cin, int cout, float* wp, void* stream);
+int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const float* bias, float* y, int batch, int cin, int cout,
+                          int din, int act, int variant, void* stream);
+
 /* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when

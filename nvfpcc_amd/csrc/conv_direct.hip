@@ -411,6 +411,16 @@ extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bi
   ConvDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0};
   hipStream_t s = nvf_stream(stream);
   int rc = 1;  // 1 = not dispatched yet
+  // the one-channel classifier heads (3^3, padding 1, cubes) have their own kernels (heads.hip): same fmaf order
+  if (variant == 0 && k == 3 && stride == 1 && pad == 1 && din == hin && hin == win && dout == din && hout == din &&
+      wout == din) {
+    if (cout == 1 && cin > 1) rc = nvf_head_fwd_launch(x, w, bias, y, addend, mask, batch, cin, win, act, s);
+    else if (cin == 1 && cout > 1) rc = nvf_head_bwd_data_launch(x, w, bias, y, addend, mask, batch, cout, win, act, s);
+    if (rc == 0) {
+      NVF_LAUNCH_CHECK();
+      return NVF_OK;
+    }
+  }
   // variant 0: the tuned configuration; 1: one-thread-per-output kernel; >= 2: alternatives kept for tuning runs.
   // Small batches cannot fill 256 CUs with whole-Cout tiles, so they take the Cout-split (COG) instantiations.
   if (variant == 0 && batch <= 64) {

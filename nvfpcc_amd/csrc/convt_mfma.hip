@@ -1,0 +1,216 @@
+// Matrix-core (v_mfma_f32_16x16x4_f32, exact fp32) forward of the stride-2, 5^3 transposed convolutions
+// with 8 output channels and no padding (up1: 16 -> 8 channels, 8^3 -> 19^3; up2: 8 -> 8, 16^3 -> 35^3;
+// F.conv_transpose3d, utils/network.py:621).
+//
+// Sub-pixel form: output o = 2c + e per axis (cell c, parity e) reads inputs i = c - j through taps
+// k = e + 2j (j = 0..2 for e = 0, j = 0..1 for e = 1): all 125 taps do useful work, no inserted zeros.
+// MFMA mapping: rows = (co, ex) -- the two x parities of a cell share their inputs, the odd one has a
+// zero weight on jx = 2 (5 of 6 row-taps useful); K = four input channels; columns = 16 consecutive
+// cells of the FLATTENED (cy, cx) cell plane.  The LDS image of an input plane has row stride = cells
+// per row (= input width + 2), two zero words in front of every row and zero rows around it, so
+//   address(cell p, jy, jx) = p - jy * NCELL - jx + const
+// is linear in p (a row's overrun lands on the next row's zero words): any 16 consecutive cells are one
+// conflict-free ds_read_b32, and 18- or 10-cell rows cost no padding columns.  The (ez, ey) parity
+// classes are separate accumulators; one B fragment feeds every (plane parity, row parity) that uses it.
+// Per output the accumulation order is fixed: (ci group, jy, jx, jz).
+#include "nvf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// number of A fragments per channel group: sum over classes (ez,ey) of (3-ez)(3-ey) * 3
+constexpr int kAPerGroup = 75;
+
+__host__ __device__ constexpr int a_index(int ez, int ey, int jz, int jy, int jx) {
+  // classes in order (0,0) (0,1) (1,0) (1,1); inside a class [jz][jy][jx]
+  const int base = ez == 0 ? (ey == 0 ? 0 : 27) : (ey == 0 ? 27 + 18 : 27 + 18 + 18);
+  return base + (jz * (3 - ey) + jy) * 3 + jx;
+}
+
+__global__ void pack_convT_mfma_kernel(const float* __restrict__ wf /* [cin][125][8] */, float* __restrict__ wp,
+                                       int cin) {
+  const int total = (cin / 4) * kAPerGroup * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx % 64, f = (idx / 64) % kAPerGroup, g = idx / (64 * kAPerGroup);
+    int ez = 0, ey = 0, r = f;
+    if (r >= 27 + 18 + 18) { ez = 1; ey = 1; r -= 63; }
+    else if (r >= 27 + 18) { ez = 1; r -= 45; }
+    else if (r >= 27) { ey = 1; r -= 27; }
+    const int jx = r % 3, jy = (r / 3) % (3 - ey), jz = r / (3 * (3 - ey));
+    const int i = lane & 15, co = i >> 1, ex = i & 1, ci = 4 * g + (lane >> 4);
+    const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
+    wp[idx] = kx < 5 ? wf[(ci * 125 + (kz * 5 + ky) * 5 + kx) * 8 + co] : 0.f;
+  }
+}
+
+template <int CIN_, int NIN_, int NCT_, int NSPLIT_>
+struct TMCfg {
+  static constexpr int CIN = CIN_, NIN = NIN_, NCT = NCT_, NSPLIT = NSPLIT_;
+  static constexpr int NCELL = NIN + 2;                        // cells per axis; outputs 2 NIN + 3
+  static constexpr int NPT = (NCELL * NCELL + 15) / 16;        // column tiles of a cell plane
+  static constexpr int NW = 4, CPW = NW * NCT;                 // column tiles per workgroup
+  static_assert(CPW * NSPLIT >= NPT, "the splits cover the plane");
+  static constexpr int PLANE = (NCELL + 3) * NCELL + 18;       // LDS words per (channel, plane), zero margins
+  static constexpr int cs_for(int v) { while (v % 32 != 16) ++v; return v; }
+  static constexpr int CS = cs_for(3 * PLANE);                 // channel stride: second channel -> banks 16..31
+  static constexpr int NG = CIN / 4;
+  static constexpr int XS = CIN * CS;                          // input image
+  static constexpr int AS = NG * kAPerGroup * 64;              // A fragments
+  static_assert((XS + AS) * 4 <= 160 * 1024, "LDS");
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int act) {
+  constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
+                NG = T::NG, NOUT = 2 * NIN + 3;
+  __shared__ __attribute__((aligned(16))) float xs[T::XS];
+  __shared__ __attribute__((aligned(16))) float as[T::AS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x % T::NSPLIT, cz = (blockIdx.x / T::NSPLIT) % NCELL, b = blockIdx.x / (T::NSPLIT * NCELL);
+  // ---- stage: every global load of the workgroup (A fragments, the three input planes cz-2 .. cz of every
+  // channel) is issued before anything is waited for; the image is zeroed while they are in flight
+  constexpr int NA4 = (T::AS / 4 + 255) / 256;                 // float4 A loads per thread
+  constexpr int ITEMS = CIN * 3 * NIN * NIN / 4;               // float4 input loads (rows are NIN = 8 or 16 floats)
+  constexpr int NX4 = (ITEMS + 255) / 256;
+  float4 av[NA4], xv[NX4];
+#pragma unroll
+  for (int u = 0; u < NA4; ++u) {
+    const int i = tid + u * 256;
+    av[u] = i < T::AS / 4 ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * 256;
+      const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
+      const int zi = cz - 2 + pl;
+      const bool ok = i < ITEMS && zi >= 0 && zi < NIN;
+      xv[u] = ok ? *(const float4*)(xb + (((size_t)c * NIN + zi) * NIN + iy) * NIN + 4 * xq)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < NA4; ++u) {
+    const int i = tid + u * 256;
+    if (i < T::AS / 4) ((float4*)as)[i] = av[u];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NX4; ++u) {
+    const int i = tid + u * 256;
+    if (i < ITEMS) {
+      const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
+      float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + 4 * xq + 2;
+      dst[0] = xv[u].x; dst[1] = xv[u].y; dst[2] = xv[u].z; dst[3] = xv[u].w;
+    }
+  }
+  __syncthreads();
+  const int j = lane & 15, kq = lane >> 4;
+  f32x4 acc[NCT][2][2];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[c][e >> 1][e & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int tl[NCT];
+  int colbase[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    tl[c] = split * T::CPW + c * T::NW + wave;                 // wave-uniform
+    // cell p = 16 tl + j reads plane word (cy - jy + 2) NCELL + cx - jx + 2 = p + 2 NCELL + 2 - jy NCELL - jx
+    // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
+    colbase[c] = kq * CS + 16 * min(tl[c], NPT - 1) + j + 2 * NCELL + 2;
+  }
+#pragma unroll 1
+  for (int g = 0; g < NG; ++g) {
+    const float* xg = xs + g * 4 * CS;
+    const float* ag = as + g * kAPerGroup * 64 + lane;
+#pragma unroll
+    for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+        for (int jz = 0; jz < 3; ++jz) {
+          float a[2][2];
+#pragma unroll
+          for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+            for (int ey = 0; ey < 2; ++ey)
+              a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey) ? ag[a_index(ez, ey, jz, jy, jx) * 64] : 0.f;
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) {
+            const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // input plane cz - jz
+#pragma unroll
+            for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+              for (int ey = 0; ey < 2; ++ey)
+                if (jz <= 2 - ez && jy <= 2 - ey)
+                  acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
+          }
+        }
+  }
+  // ---- epilogue: lane holds rows i = 4 kq + r -> co = 2 kq + (r >> 1), ex = r & 1 of cell p
+  const size_t cstride = (size_t)NOUT * NOUT * NOUT;
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int p = 16 * tl[c] + j;
+    if (tl[c] >= NPT || p >= NCELL * NCELL) continue;
+    const int cy = p / NCELL, cx = p % NCELL;
+#pragma unroll
+    for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+      for (int ey = 0; ey < 2; ++ey) {
+        const int oz = 2 * cz + ez, oy = 2 * cy + ey;
+        if (oz >= NOUT || oy >= NOUT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 2 * kq + (r >> 1), ox = 2 * cx + (r & 1);
+          if (ox < NOUT)
+            y[((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
+                nvf_act(acc[c][ez][ey][r] + (bias ? bias[co] : 0.f), act);
+        }
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t nvf_pack_convT_mfma_floats(int cin) { return (size_t)(cin / 4) * kAPerGroup * 64; }
+
+// w_fwd = the [cin][125][8] packed forward weight of a transposed convolution with 8 output channels
+extern "C" int nvf_pack_convT_mfma(const float* w_fwd, int cin, int cout, float* wp, void* stream) {
+  if (!w_fwd || !wp || cin <= 0 || cin % 4 || cout != 8) return NVF_EINVAL;
+  const int total = (int)nvf_pack_convT_mfma_floats(cin);
+  pack_convT_mfma_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(w_fwd, wp, cin);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// y[b,co,o] = act(bias[co] + sum_{ci,k : o - k = 2 i} x[b,ci,i] w[ci][k][co]), padding 0, dout = 2 din + 3.
+// NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_convT3d_k5s2_fwd).
+extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const float* bias, float* y, int batch, int cin,
+                                     int cout, int din, int act, int variant, void* stream) {
+  if (!x || !wp || !y || batch <= 0 || cout != 8) return NVF_EINVAL;
+  hipStream_t s = nvf_stream(stream);
+  int rc = 1;
+#define NVF_TM(VAR, CI, NIN, NCT, NSPLIT)                                                              \
+  if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
+    using T = TMCfg<CI, NIN, NCT, NSPLIT>;                                                             \
+    convT_k5s2_mfma<T><<<batch * T::NCELL * NSPLIT, 256, 0, s>>>(x, wp, bias, y, act);                 \
+    rc = NVF_OK;                                                                                       \
+  }
+  NVF_TM(0, 8, 16, 2, 3)     // up2: 21 column tiles per cell plane, 8 per workgroup
+  NVF_TM(0, 16, 8, 2, 1)     // up1: all 7 column tiles of a cell plane in one workgroup
+  NVF_TM(2, 8, 16, 3, 2)
+  NVF_TM(3, 8, 16, 6, 1)
+  NVF_TM(4, 8, 16, 1, 6)
+  NVF_TM(2, 16, 8, 1, 2)
+#undef NVF_TM
+  if (rc == 1) return NVF_EINVAL;
+  NVF_LAUNCH_CHECK();
+  return rc;
+}

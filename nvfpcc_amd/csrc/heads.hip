@@ -1,0 +1,313 @@
+// The three one-channel classifier heads of the NVF decoder (conv0_cls / conv1_cls / conv2_cls:
+// Conv3d(C -> 1, k = 3, padding 1) + sigmoid, utils/network.py:4761-4768 through IConv3d :735-742 and
+// QConv3d :677-687) and their autograd backward passes.
+//
+// They are 4 % of the FLOPs, but as instances of the general tiled kernels they were a fifth of the
+// batch-16 step: 27-tap stencils over tensors that are read once are bound by memory latency, and
+// the general kernels keep only a few loads in flight per wave and fetch weights through chains of
+// scalar loads.  These kernels (reached through nvf_conv3d_gather / nvf_wgrad, same contract, same
+// per-output fmaf order as the one-thread-per-output kernels) instead
+//   * take full-width tiles (TZ x TY rows of S voxels), so every global access is an aligned float4
+//     and a thread issues all of its tile loads before the first one is consumed,
+//   * keep the 27 C weights in LDS (broadcast ds_read_b128) -- no scalar-load chains,
+//   * give each thread four consecutive x outputs, so one row segment (a b128 plus two b32 LDS
+//     reads) feeds 12 FMAs per input channel.
+#include "nvf_common.h"
+
+namespace {
+
+template <int C_, int S_, int TZ_, int TY_>
+struct HCfg {
+  static constexpr int C = C_, S = S_, TZ = TZ_, TY = TY_;
+  static constexpr int XG = S / 4;                 // float4 groups per row
+  static constexpr int RS = S + 8;                 // LDS row: x = -1 at word 3, x = 0 at word 4 (16-B aligned)
+  static constexpr int IZ = TZ + 2, IY = TY + 2;
+  static constexpr int NT = TZ * TY * XG;          // one thread per four outputs
+  static_assert(S % 4 == 0 && NT >= 64 && NT <= 1024 && NT % 64 == 0, "tile");
+};
+
+// C channels of the x tile (with a one-voxel halo, zero outside the tensor) -> LDS [c][IZ][IY][RS]
+template <int CH, int S, int IZ, int IY, int RS, int NT>
+__device__ __forceinline__ void head_stage(const float* __restrict__ xb, float* xs, int tid, int z0, int y0) {
+  constexpr int XG = S / 4, ITEMS = CH * IZ * IY * XG, U = 8;
+#pragma unroll 1
+  for (int i0 = tid; i0 < ITEMS; i0 += NT * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * NT;
+      const int xq = i % XG, r = i / XG, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
+      const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
+      const bool ok = i < ITEMS && gz >= 0 && gz < S && gy >= 0 && gy < S;
+      v[u] = ok ? *(const float4*)(xb + (((size_t)c * S + gz) * S + gy) * S + 4 * xq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * NT;
+      if (i < ITEMS) {
+        const int xq = i % XG, r = i / XG;
+        float* row = xs + (size_t)r * RS;
+        *(float4*)(row + 4 + 4 * xq) = v[u];
+        if (xq == 0) row[3] = 0.f;
+        if (xq == XG - 1) row[S + 4] = 0.f;
+      }
+    }
+  }
+}
+
+// ---- forward: p = act(bias + sum_{c,k} x[c, o + k - 1] w[c][k]) -----------------------------------------------
+template <class H>
+__global__ __launch_bounds__(H::NT) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ addend,
+                                                         const float* __restrict__ mask, int act) {
+  constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT;
+  __shared__ __attribute__((aligned(16))) float xs[C * IZ * IY * RS];
+  __shared__ __attribute__((aligned(16))) float ws[C * 9 * 4];
+  const int tid = threadIdx.x;
+  constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
+  const int tile = blockIdx.x % (TILES_Y * TILES_Z), b = blockIdx.x / (TILES_Y * TILES_Z);
+  const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
+  for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
+  head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
+  __syncthreads();
+  const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float* row = xs + ((size_t)(c * IZ + tz + kz) * IY + ty + ky) * RS + 4 * xg;
+        const float4 m = *(const float4*)(row + 4);
+        const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+        const float4 wv = *(const float4*)(ws + (c * 9 + kz * 3 + ky) * 4);
+        const float wk[3] = {wv.x, wv.y, wv.z};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + kx], wk[kx], acc[o]);
+      }
+  const float bv = bias ? bias[0] : 0.f;
+  const size_t off = (((size_t)b * S + z0 + tz) * S + y0 + ty) * S + 4 * xg;
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = nvf_act(acc[i] + bv, act);
+  if (addend) {
+    const float4 a = *(const float4*)(addend + off);
+    o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+  }
+  if (mask) {
+    const float4 m = *(const float4*)(mask + off);
+    o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
+    o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
+  }
+  *(float4*)(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ---- backward-data: dx[c, i] = sum_k' dl[i - 1 + k'] wb[k'][c]  (wb = w_bwd: taps flipped) ---------------------
+template <class H>
+__global__ __launch_bounds__(H::NT) void head_bwd_data_kernel(const float* __restrict__ dl, const float* __restrict__ wb,
+                                                              const float* __restrict__ bias, float* __restrict__ dx,
+                                                              const float* __restrict__ addend,
+                                                              const float* __restrict__ mask, int act) {
+  constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT;
+  __shared__ __attribute__((aligned(16))) float ds[IZ * IY * RS];
+  __shared__ __attribute__((aligned(16))) float ws[27 * C];
+  const int tid = threadIdx.x;
+  constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
+  const int tile = blockIdx.x % (TILES_Y * TILES_Z), b = blockIdx.x / (TILES_Y * TILES_Z);
+  const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
+  for (int i = tid; i < 27 * C; i += NT) ws[i] = wb[i];
+  head_stage<1, S, IZ, IY, RS, NT>(dl + (size_t)b * S * S * S, ds, tid, z0, y0);
+  __syncthreads();
+  const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
+  float acc[C][4];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[c][o] = 0.f;
+#pragma unroll 1
+  for (int kz = 0; kz < 3; ++kz)
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* row = ds + ((size_t)(tz + kz) * IY + ty + ky) * RS + 4 * xg;
+      const float4 m = *(const float4*)(row + 4);
+      const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* wr = ws + ((kz * 3 + ky) * 3 + kx) * C;
+#pragma unroll
+        for (int c4 = 0; c4 < C; c4 += 4) {
+          const float4 wv = *(const float4*)(wr + c4);
+          const float wk[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[c4 + cc][o] = fmaf(v[o + kx], wk[cc], acc[c4 + cc][o]);
+        }
+      }
+    }
+  const size_t vol = (size_t)S * S * S;
+  const size_t off = (size_t)b * C * vol + (((size_t)(z0 + tz)) * S + y0 + ty) * S + 4 * xg;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float bv = bias ? bias[c] : 0.f;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = nvf_act(acc[c][i] + bv, act);
+    if (addend) {
+      const float4 a = *(const float4*)(addend + off + c * vol);
+      o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+    }
+    if (mask) {
+      const float4 m = *(const float4*)(mask + off + c * vol);
+      o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
+      o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
+    }
+    *(float4*)(dx + off + c * vol) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- weight gradient: dw[c][k] = sum_{b,i} dl[b,i] x[b,c,i + k - 1] -------------------------------------------
+// lane = (row of the tile, float4 group along x): every LDS access of a wave is a run of consecutive float4s, and a
+// lane keeps the 27 tap sums of one channel for its four x positions; a wave takes C / 4 channels in turn and adds
+// its lanes' sums by shuffles at the end (fixed order), one slab per workgroup.
+template <int C_, int S_, int TZ_, int TY_, int CSPLIT_>
+struct HWCfg {
+  static constexpr int C = C_, S = S_, TZ = TZ_, TY = TY_, CSPLIT = CSPLIT_;
+  static constexpr int XG = S / 4, RS = S + 8, IZ = TZ + 2, IY = TY + 2;
+  static constexpr int NW = 4, NT = NW * 64;
+  static constexpr int RPW = 64 / XG;                  // tile rows a wave covers at once
+  static constexpr int CW = C / CSPLIT;                // channels per workgroup (grid.y picks the group)
+  static constexpr int CPW = CW / NW;                  // channels per wave
+  static_assert((TZ * TY) % RPW == 0 && C % CSPLIT == 0 && CW % NW == 0, "tile rows / channels split evenly");
+};
+
+template <class H>
+__global__ __launch_bounds__(H::NT) void head_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                           float* __restrict__ slabs, int items, int items_per_wg) {
+  constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT,
+                RPW = H::RPW, CPW = H::CPW, CW = H::CW;
+  __shared__ __attribute__((aligned(16))) float xs[CW * IZ * IY * RS];
+  const int cg0 = blockIdx.y * CW;                     // first channel of this workgroup
+  __shared__ __attribute__((aligned(16))) float dls[TZ * TY * S];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xq = lane % XG, rl = lane / XG;
+  constexpr int TILES_Y = S / TY, TILES_Z = S / TZ, TILES = TILES_Y * TILES_Z;
+  float acc[CPW][27];
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[cc][t] = 0.f;
+  const int first = blockIdx.x * items_per_wg, last = min(first + items_per_wg, items);
+#pragma unroll 1
+  for (int item = first; item < last; ++item) {
+    const int tile = item % TILES, b = item / TILES;
+    const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
+    if (item != first) __syncthreads();
+    head_stage<CW, S, IZ, IY, RS, NT>(x + ((size_t)b * C + cg0) * S * S * S, xs, tid, z0, y0);
+    for (int i = tid; i < TZ * TY * XG; i += NT) {
+      const int q = i % XG, r = i / XG, ty = r % TY, tz = r / TY;
+      *(float4*)(dls + r * S + 4 * q) = *(const float4*)(dl + (((size_t)b * S + z0 + tz) * S + y0 + ty) * S + 4 * q);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r0 = 0; r0 < TZ * TY; r0 += RPW) {
+      const int r = r0 + rl, ty = r % TY, tz = r / TY;
+      const float4 d4 = *(const float4*)(dls + r * S + 4 * xq);
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int c = wave * CPW + cc;
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float* row = xs + ((size_t)(c * IZ + tz + kz) * IY + ty + ky) * RS + 4 * xq;
+            const float4 m = *(const float4*)(row + 4);
+            const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx)
+                acc[cc][(kz * 3 + ky) * 3 + kx] = fmaf(d[o], v[o + kx], acc[cc][(kz * 3 + ky) * 3 + kx]);
+          }
+      }
+    }
+  }
+  float* slab = slabs + (size_t)blockIdx.x * (C * 27);
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const float sum = nvf_wave_sum(acc[cc][t]);
+      if (lane == 0) slab[(cg0 + wave * CPW + cc) * 27 + t] = sum;
+    }
+}
+
+}  // namespace
+
+// ---- launchers used by the dispatchers of nvf_conv3d_gather / nvf_wgrad ----------------------------------------
+// return 1 when there is no instantiation for the shape (the caller falls back to the general kernels)
+int nvf_head_fwd_launch(const float* x, const float* w, const float* bias, float* y, const float* addend,
+                        const float* mask, int batch, int c, int s, int act, hipStream_t st) {
+#define NVF_H(CC, SS, TZ, TY)                                                                                   \
+  if (c == CC && s == SS) {                                                                                     \
+    using H = HCfg<CC, SS, TZ, TY>;                                                                             \
+    head_fwd_kernel<H><<<batch * (SS / TZ) * (SS / TY), H::NT, 0, st>>>(x, w, bias, y, addend, mask, act);      \
+    return 0;                                                                                                   \
+  }
+  NVF_H(8, 32, 4, 8)
+  NVF_H(8, 16, 4, 4)
+  NVF_H(16, 8, 4, 8)
+  NVF_H(16, 32, 2, 8)
+  NVF_H(16, 16, 4, 4)
+  NVF_H(32, 8, 4, 8)
+#undef NVF_H
+  return 1;
+}
+
+int nvf_head_bwd_data_launch(const float* dl, const float* wb, const float* bias, float* dx, const float* addend,
+                             const float* mask, int batch, int c, int s, int act, hipStream_t st) {
+#define NVF_H(CC, SS, TZ, TY)                                                                                        \
+  if (c == CC && s == SS) {                                                                                          \
+    using H = HCfg<CC, SS, TZ, TY>;                                                                                  \
+    head_bwd_data_kernel<H><<<batch * (SS / TZ) * (SS / TY), H::NT, 0, st>>>(dl, wb, bias, dx, addend, mask, act);   \
+    return 0;                                                                                                        \
+  }
+  NVF_H(8, 32, 4, 8)
+  NVF_H(8, 16, 4, 4)
+  NVF_H(16, 8, 4, 8)
+  NVF_H(16, 32, 4, 8)
+  NVF_H(16, 16, 4, 4)
+  NVF_H(32, 8, 4, 8)
+#undef NVF_H
+  return 1;
+}
+
+// slabs: up to max_slabs partial results of c*27 floats each; *nslab receives the number written
+int nvf_head_wgrad_launch(const float* dl, const float* x, float* slabs, int max_slabs, int batch, int c, int s,
+                          int* nslab, hipStream_t st) {
+#define NVF_H(CC, SS, TZ, TY, CSPLIT)                                                          \
+  if (c == CC && s == SS) {                                                                    \
+    using H = HWCfg<CC, SS, TZ, TY, CSPLIT>;                                                   \
+    const int items = batch * (SS / TZ) * (SS / TY);                                           \
+    int n = items < max_slabs ? items : max_slabs;                                             \
+    const int per = (items + n - 1) / n;                                                       \
+    n = (items + per - 1) / per;                                                               \
+    head_wgrad_kernel<H><<<dim3(n, CSPLIT), H::NT, 0, st>>>(dl, x, slabs, items, per);         \
+    *nslab = n;                                                                                \
+    return 0;                                                                                  \
+  }
+  NVF_H(8, 32, 2, 8, 2)
+  NVF_H(8, 16, 4, 4, 2)
+  NVF_H(16, 8, 4, 8, 4)
+  NVF_H(16, 32, 2, 8, 4)
+  NVF_H(16, 16, 4, 4, 4)
+  NVF_H(32, 8, 4, 8, 8)
+#undef NVF_H
+  return 1;
+}

@@ -146,3 +146,11 @@ __device__ __forceinline__ void nvf_glds_lane(const float* src, unsigned lds_byt
       : "memory");
 }
 
+
+// ---- classifier-head kernels (heads.hip), reached through nvf_conv3d_gather / nvf_wgrad; 1 = no instantiation ----
+int nvf_head_fwd_launch(const float* x, const float* w, const float* bias, float* y, const float* addend,
+                        const float* mask, int batch, int c, int s, int act, hipStream_t st);
+int nvf_head_bwd_data_launch(const float* dl, const float* wb, const float* bias, float* dx, const float* addend,
+                             const float* mask, int batch, int c, int s, int act, hipStream_t st);
+int nvf_head_wgrad_launch(const float* dl, const float* x, float* slabs, int max_slabs, int batch, int c, int s,
+                          int* nslab, hipStream_t st);

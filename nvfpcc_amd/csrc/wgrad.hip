@@ -354,6 +354,15 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
   if (rc == 1 && variant == VAR && a == AA && k == KS && stride == ST && wp == WP && hp % TY == 0 && dp % TZ == 0 && \
       b % NB == 0)                                                                                                 \
     rc = launch_wgrad<WCfg<AA, KS, ST, NB, TX, TY, TZ, IXU>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
+    if (variant == 0 && a == 1 && k == 3 && stride == 1 && pad == 1 && out_mode == 0 && dp == hp && hp == wp &&
+        dq == dp && hq == dp && wq == dp) {     // classifier heads (heads.hip): p = dlogit, q = X
+      int n = 0;
+      if (nvf_head_wgrad_launch(p, q, slabs, kMaxSlabs, batch, b, wp, &n, s) == 0) {
+        if (defer_nslab) *defer_nslab = n;
+        else wgrad_reduce<<<(d.jtotal + 63) / 64, 1024, 0, s>>>(slabs, dw, n, d.jtotal, accumulate);
+        rc = NVF_OK;
+      }
+    }
     const bool cube_k4 = a == 8 && b == 8 && k == 4 && stride == 1 && pad == 0 && out_mode == 0 && dp == wp &&
                          hp == wp && dq == wp + 3 && hq == wp + 3 && wq == wp + 3;
     if (rc == 1 && variant == 0 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 4, 4>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);

@@ -43,7 +43,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b")
+                 "wp_b", "wp_t")
 
 
 class TrainEngine:
@@ -126,7 +126,10 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = None
+            L.wp_f = L.wp_b = L.wp_t = None
+            if L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
+                # matrix-core form of the padding-0 transposed convolutions (forward)
+                L.wp_t = torch.empty(int(lib().nvf_pack_convT_mfma_floats(L.cin)), device=self.dev)
             if L.k == 4 and L.cin % 4 == 0 and L.cout == 8 and L.cin == 8 and L.pad == 0:
                 # matrix-core form of the 4^3 convolutions: MFMA A-fragments, re-packed after every weight preparation
                 L.wp_f = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cin, 0)), device=self.dev)
@@ -155,9 +158,14 @@ class TrainEngine:
                                         torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights")
         if self._mfma_jobs:
             ops.pack_mfma_k4_multi(self._mfma_jobs)
+        for L in self.layers.values():
+            if L.wp_t is not None:
+                ops.pack_convT_mfma(L.w_fwd, L.cin, out=L.wp_t)
 
     # ------------------------------------------------------------------ forward
     def _convT(self, L, x, act):
+        if L.wp_t is not None:
+            return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
     def _conv(self, L, x, act):

@@ -176,6 +176,28 @@ def convT3d_k5s2_fwd(x, w_fwd, bias, cout, pad, act=ACT_NONE, out=None):
     return y
 
 
+def pack_convT_mfma(w_fwd, cin, out=None):
+    """MFMA A-fragments of a k5 s2 transposed-conv weight in the packed forward layout [cin][125][8]."""
+    _f32(w_fwd, out)
+    n = int(lib().nvf_pack_convT_mfma_floats(cin))
+    wp = out if out is not None else torch.empty(n, device=w_fwd.device)
+    if w_fwd.numel() != cin * 125 * 8 or wp.numel() != n:
+        raise RuntimeError("pack_convT_mfma: weight size does not match (cin, 5, 8)")
+    check(lib().nvf_pack_convT_mfma(_ptr(w_fwd), cin, 8, _ptr(wp), _stream()), "nvf_pack_convT_mfma")
+    return wp
+
+
+def convT3d_k5s2_mfma(x, wp, bias, act=ACT_NONE, out=None):
+    """Matrix-core transposed convolution k5 s2 padding 0, 8 output channels."""
+    _f32(x, wp, bias)
+    B, cin, di = x.shape[0], x.shape[1], x.shape[2]
+    do = 2 * di + 3
+    y = out if out is not None else torch.empty((B, 8, do, do, do), device=x.device)
+    check(lib().nvf_convT3d_k5s2_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, cin, 8, di, act, _MFMA_VARIANT,
+                                      _stream()), "nvf_convT3d_k5s2_mfma")
+    return y
+
+
 def stem_fwd(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b):
     """Fused up0 -> IGDN -> conv0 + ReLU for chanstr (8, 16, ...): returns (a0, h0, y1)."""
     _f32(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b)

@@ -83,6 +83,28 @@ CONVT_CASES = [(3, 8, 2, 1, 2), (8, 16, 2, 1, 4), (16, 8, 0, 0, 8), (8, 8, 0, 0,
                (8, 16, 2, 1, 2), (16, 32, 2, 1, 4), (32, 16, 0, 0, 8), (16, 16, 0, 0, 16)]
 
 
+@pytest.mark.parametrize("cin,n,B", [(8, 16, 2), (16, 8, 3), (8, 16, 1)])
+def test_conv_transpose_k5s2_mfma_forward(ops, cin, n, B):
+    """Matrix-core form of up1 / up2 (padding 0, 8 output channels) against torch's conv_transpose3d; batch
+    invariance bit for bit."""
+    g = gen(5000 + cin + n + B)
+    x = torch.randn(B, cin, n, n, n, generator=g)
+    w = torch.randn(cin, 8, 5, 5, 5, generator=g) / (cin * 125 / 8) ** 0.5
+    b = torch.randn(8, generator=g)
+    y_ref = F.conv_transpose3d(x, w, b, stride=2)
+    wf, _ = ops.pack_convT_weight(dev(w))
+    wp = ops.pack_convT_mfma(wf, cin)
+    xd = dev(x)
+    y = ops.convT3d_k5s2_mfma(xd, wp, dev(b), ops.ACT_RELU)
+    assert y.shape == y_ref.shape
+    assert (y.cpu() - F.relu(y_ref)).abs().max() < 2e-5
+    y_lin = ops.convT3d_k5s2_mfma(xd, wp, dev(b), ops.ACT_NONE)
+    assert (y_lin.cpu() - y_ref).abs().max() < 2e-5
+    for i in range(B):
+        yi = ops.convT3d_k5s2_mfma(xd[i:i + 1].contiguous(), wp, dev(b), ops.ACT_RELU)
+        assert torch.equal(yi[0], y[i])
+
+
 # matrix-core (MFMA) form of the 4^3, 8 -> 8 channel convolutions: (spatial_in, batch)
 @pytest.mark.parametrize("n,B", [(35, 2), (19, 3), (35, 1), (19, 5)])
 def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):

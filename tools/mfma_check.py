@@ -61,6 +61,28 @@ def main():
             t = timeit(lambda: ops.conv3d_k4_mfma(x, wp, bb, pad, pair, act, mask=mask))
             row += f" v{v}: {t:7.1f}us {2 * macs / t / 1e6:6.1f}TF err {err:.1e} |"
         print(row, flush=True)
+    for name, cin, n in (("up2.fwd", 8, 16), ("up1.fwd", 16, 8)):
+        x = torch.randn(B, cin, n, n, n, device=dev)
+        w = torch.randn(cin, 8, 5, 5, 5, device=dev) * 0.05
+        bias = torch.randn(8, device=dev)
+        wf, _ = ops.pack_convT_weight(w)
+        ops.set_mfma_variant(0)
+        ref = ops.convT3d_k5s2_fwd(x, wf, bias, 8, 0, ops.ACT_RELU)
+        t_ref = timeit(lambda: ops.convT3d_k5s2_fwd(x, wf, bias, 8, 0, ops.ACT_RELU))
+        macs = B * cin * n ** 3 * 8 * 125
+        wp = ops.pack_convT_mfma(wf, cin)
+        row = f"{name:16s} valu {t_ref:8.1f}us {2 * macs / t_ref / 1e6:6.1f}TF |"
+        for v in [int(v) for v in a.variants.split(",")]:
+            ops.set_mfma_variant(v)
+            try:
+                got = ops.convT3d_k5s2_mfma(x, wp, bias, ops.ACT_RELU)
+            except Exception:
+                continue
+            torch.cuda.synchronize()
+            err = (got - ref).abs().max().item() / ref.abs().max().item()
+            t = timeit(lambda: ops.convT3d_k5s2_mfma(x, wp, bias, ops.ACT_RELU))
+            row += f" v{v}: {t:7.1f}us {2 * macs / t / 1e6:6.1f}TF err {err:.1e} |"
+        print(row, flush=True)
     ops.set_mfma_variant(0)
 
 
