@@ -113,6 +113,16 @@ int nvf_pack_convT_mfma(const float* w_fwd, int cin, int cout, float* wp, void* 
 int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const float* bias, float* y, int batch, int cin, int cout,
                           int din, int act, int variant, void* stream);
 
+/* ---- matrix-core backward-data of those transposed convolutions (a stride-2 gather convolution, autograd
+ * backward of network.py:621): dx[b,ci,i] = (sum_{co,k} g[b,co,2i+k] w[ci][co][k] (+ addend)) (* (mask > 0)),
+ * din = 2 dout + 3, cog = 8 (up2) or 16 (up1) output channels, cig channels of g.  Weights:
+ * nvf_pack_s2k5_mfma(w_bwd [cig][125][cog], cig, cog, wp), nvf_pack_s2k5_mfma_floats(cig, cog) floats.
+ * Fixed per-output accumulation order (channel group, ky, kx window, kz).  NVF_EINVAL = no instantiation. */
+size_t nvf_pack_s2k5_mfma_floats(int cig, int cog);
+int nvf_pack_s2k5_mfma(const float* gather_w, int cig, int cog, float* wp, void* stream);
+int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, const float* addend, const float* mask,
+                         int batch, int cig, int cog, int din, int dout, int variant, void* stream);
+
 /* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when

@@ -1,0 +1,225 @@
+// Matrix-core (v_mfma_f32_16x16x4_f32, exact fp32) backward-data of the stride-2, 5^3, padding-0 transposed
+// convolutions up1 / up2 (autograd backward of F.conv_transpose3d, utils/network.py:621):
+//
+//   dx[ci, i] = sum_{co, k} g[co, 2 i + k] w[ci][co][k]        -- a stride-2 gather convolution, 125 taps
+//
+// rows  : 16 = the layer's 16 input channels (up1), or (ci, s) for 8 channels (up2), where s picks one of two
+//         x-adjacent outputs i_x = 2m + s; both read g[.., 4m + tx], tx = 2s + kx in 0..6, each row uses 5 of the
+//         7 taps (zero weights on the other two);
+// K     : four channels of g;
+// cols  : 2 output rows x 8 cells (up2: 8 cells = 16 x outputs; up1: 8 x outputs).
+// A wave stacks NT tiles along z; one B fragment (one input plane/row/tap) feeds every (tile, kz) that touches it.
+// A workgroup owns a (4 rows x NZ planes) region; per group of four g channels it brings that group's A fragments
+// (45 KB) and input tile into LDS -- all global loads of a pass are issued into registers before any is waited for,
+// and the loads of the second pass are in flight while the first computes.  Fixed per-output accumulation order:
+// (channel group, ky, tx, kz).  Epilogue: (+ addend) and the ReLU mask of the layer's input, as nvf_conv3d_gather.
+#include "nvf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// PAIR = 1: 8 output channels, rows (ci, s); PAIR = 0: 16 output channels
+template <int PAIR_, int NIN_, int NOUT_, int RY_, int NWZ_, int NT_, int RS_>
+struct S2Cfg {
+  static constexpr int PAIR = PAIR_, NIN = NIN_, NOUT = NOUT_, RY = RY_, NWZ = NWZ_, NT = NT_, RS = RS_;
+  static constexpr int COG = PAIR ? 8 : 16;
+  static constexpr int KEX = PAIR ? 7 : 5;                 // x taps of a row pair / of a row
+  static constexpr int XSTEP = PAIR ? 4 : 2;               // input words between neighbouring columns
+  static constexpr int NW = RY * NWZ;
+  static_assert(NW == 4, "four waves");
+  static constexpr int OY = 2 * RY, OZ = NWZ * NT;         // output rows / planes of a workgroup
+  static constexpr int IZ = 2 * (OZ - 1) + 5, IY = 2 * (OY - 1) + 5;
+  static constexpr int IZW = 2 * (NT - 1) + 5;             // input planes one wave reads
+  static constexpr int PS = IY * RS;
+  static constexpr int CS = (IZ * PS) | 1;                 // odd: the second channel of a read group -> other banks
+  static constexpr int XW = 4 * CS;                        // input tile of one channel group (words)
+  static constexpr int NFR = 25 * KEX;                     // A fragments per channel group
+  static constexpr int AW = NFR * 64;
+  static constexpr int ROWCH = (NIN + 3) / 4;              // float4 chunks per input row
+  static constexpr int XITEMS = 4 * IZ * IY * ROWCH;
+  static constexpr int NX4 = (XITEMS + 255) / 256, NA4 = (AW / 4 + 255) / 256;
+  static_assert(RS >= NIN && (XW + AW) * 4 <= 160 * 1024, "LDS");
+};
+
+__global__ void pack_s2k5_mfma_kernel(const float* __restrict__ gw /* [cig][125][cog] */, float* __restrict__ wp,
+                                      int cig, int cog) {
+  const int pair = cog == 8, KEX = pair ? 7 : 5;
+  const int total = (cig / 4) * 25 * KEX * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int lane = r % 64; r /= 64;
+    const int tx = r % KEX; r /= KEX;
+    const int ky = r % 5; r /= 5;
+    const int kz = r % 5;
+    const int g = r / 5;
+    const int i = lane & 15, ch = 4 * g + (lane >> 4);
+    const int co = pair ? i >> 1 : i, kx = pair ? tx - 2 * (i & 1) : tx;
+    wp[idx] = (kx >= 0 && kx < 5) ? gw[(ch * 125 + (kz * 5 + ky) * 5 + kx) * cog + co] : 0.f;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_s2k5_mfma(const float* __restrict__ g, const float* __restrict__ wp,
+                                                      float* __restrict__ dx, const float* __restrict__ addend,
+                                                      const float* __restrict__ mask, int cig) {
+  constexpr int NIN = C::NIN, NOUT = C::NOUT, RS = C::RS, PS = C::PS, CS = C::CS, KEX = C::KEX, NT = C::NT,
+                IZ = C::IZ, IY = C::IY, ROWCH = C::ROWCH, NX4 = C::NX4, NA4 = C::NA4, COG = C::COG;
+  __shared__ __attribute__((aligned(16))) float xs[C::XW];
+  __shared__ __attribute__((aligned(16))) float as[C::AW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int TY = NOUT / C::OY, TZ = NOUT / C::OZ;
+  const int tile = blockIdx.x % (TY * TZ), b = blockIdx.x / (TY * TZ);
+  const int oy0 = (tile % TY) * C::OY, oz0 = (tile / TY) * C::OZ;
+  const int wy = wave % C::RY, wz = wave / C::RY;
+  const int j = lane & 15, kq = lane >> 4, yy = j >> 3, m = j & 7;
+  // column (yy, m) of this wave's tile stack: input word of tap (zi, ky, tx) = colbase + zi PS + ky RS + tx
+  const int colbase = kq * CS + (2 * wz * NT) * PS + (2 * (2 * wy + yy)) * RS + C::XSTEP * m;
+  const float* gb = g + (size_t)b * cig * NIN * NIN * NIN;
+  const int gz0 = 2 * oz0, gy0 = 2 * oy0;
+
+  float4 xv[NX4], av[NA4];
+  auto load = [&](int grp) {
+    const float* gg = gb + (size_t)grp * 4 * NIN * NIN * NIN;
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * 256;
+      const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
+      const int gz = gz0 + zi, gy = gy0 + yi;
+      const bool ok = i < C::XITEMS && gz < NIN && gy < NIN;
+      const float* p = gg + (((size_t)c * NIN + gz) * NIN + gy) * NIN + 4 * xq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        if (4 * xq + 3 < NIN) {
+          v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+        } else {                                  // the last chunk of a row holds NIN % 4 elements
+          v.x = p[0];
+          if (4 * xq + 1 < NIN) v.y = p[1];
+          if (4 * xq + 2 < NIN) v.z = p[2];
+        }
+      }
+      xv[u] = v;
+    }
+    const float4* ap = (const float4*)(wp + (size_t)grp * C::AW);
+#pragma unroll
+    for (int u = 0; u < NA4; ++u) {
+      const int i = tid + u * 256;
+      av[u] = i < C::AW / 4 ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * 256;
+      if (i < C::XITEMS) {
+        const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
+        float* d = xs + c * CS + zi * PS + yi * RS + 4 * xq;
+        d[0] = xv[u].x;
+        if (4 * xq + 1 < RS) d[1] = xv[u].y;
+        if (4 * xq + 2 < RS) d[2] = xv[u].z;
+        if (4 * xq + 3 < RS) d[3] = xv[u].w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NA4; ++u) {
+      const int i = tid + u * 256;
+      if (i < C::AW / 4) ((float4*)as)[i] = av[u];
+    }
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ngroups = cig / 4;
+  load(0);
+#pragma unroll 1
+  for (int grp = 0; grp < ngroups; ++grp) {
+    if (grp) __syncthreads();                     // everyone is done reading the previous group's tile
+    store();
+    __syncthreads();
+    if (grp + 1 < ngroups) load(grp + 1);         // in flight while this group computes
+    const float* al = as + lane;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int tx = 0; tx < KEX; ++tx) {
+        float a[5];
+#pragma unroll
+        for (int kz = 0; kz < 5; ++kz) a[kz] = al[((kz * 5 + ky) * KEX + tx) * 64];
+#pragma unroll
+        for (int zi = 0; zi < C::IZW; ++zi) {
+          const float bv = xs[colbase + zi * PS + ky * RS + tx];
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            const int kz = zi - 2 * q;
+            if (kz >= 0 && kz < 5) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kz], bv, acc[q], 0, 0, 0);
+          }
+        }
+      }
+  }
+  // ---- epilogue
+  const size_t vol = (size_t)NOUT * NOUT * NOUT;
+  const int oy = oy0 + 2 * wy + yy;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int oz = oz0 + wz * NT + q;
+    if (C::PAIR) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                 // channel 2 kq + h, outputs x = 2m, 2m + 1
+        const size_t o = ((size_t)b * COG + 2 * kq + h) * vol + ((size_t)oz * NOUT + oy) * NOUT + 2 * m;
+        float v0 = acc[q][2 * h], v1 = acc[q][2 * h + 1];
+        if (addend) { const float2 a2 = *(const float2*)(addend + o); v0 += a2.x; v1 += a2.y; }
+        if (mask) { const float2 m2 = *(const float2*)(mask + o); v0 = m2.x > 0.f ? v0 : 0.f; v1 = m2.y > 0.f ? v1 : 0.f; }
+        *(float2*)(dx + o) = make_float2(v0, v1);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                 // channel 4 kq + r, output x = m
+        const size_t o = ((size_t)b * COG + 4 * kq + r) * vol + ((size_t)oz * NOUT + oy) * NOUT + m;
+        float v = acc[q][r];
+        if (addend) v += addend[o];
+        if (mask) v = mask[o] > 0.f ? v : 0.f;
+        dx[o] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t nvf_pack_s2k5_mfma_floats(int cig, int cog) { return (size_t)(cig / 4) * 25 * (cog == 8 ? 7 : 5) * 64; }
+
+// gather_w = the [cig][125][cog] gather-form weight (= w_bwd of a transposed convolution: cig = its output channels)
+extern "C" int nvf_pack_s2k5_mfma(const float* gather_w, int cig, int cog, float* wp, void* stream) {
+  if (!gather_w || !wp || cig <= 0 || cig % 4 || (cog != 8 && cog != 16)) return NVF_EINVAL;
+  const int total = (int)nvf_pack_s2k5_mfma_floats(cig, cog);
+  pack_s2k5_mfma_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(gather_w, wp, cig, cog);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// dx[b,ci,i] = (sum_{co,k} g[b,co,2i+k] w[co][k][ci] (+ addend)) (masked), din = 2 dout + 3.
+// NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_conv3d_gather).
+extern "C" int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, const float* addend, const float* mask,
+                                    int batch, int cig, int cog, int din, int dout, int variant, void* stream) {
+  if (!g || !wp || !dx || batch <= 0 || din != 2 * dout + 3) return NVF_EINVAL;
+  hipStream_t s = nvf_stream(stream);
+  int rc = 1;
+#define NVF_S2(VAR, CIG, COGV, NIN, NOUT, RY, NWZ, NT, RS)                                             \
+  if (rc == 1 && variant == VAR && cig == CIG && cog == COGV && din == NIN) {                          \
+    using C = S2Cfg<(COGV == 8), NIN, NOUT, RY, NWZ, NT, RS>;                                          \
+    conv_s2k5_mfma<C><<<batch * (NOUT / C::OY) * (NOUT / C::OZ), 256, 0, s>>>(g, wp, dx, addend, mask, cig); \
+    rc = NVF_OK;                                                                                       \
+  }
+  NVF_S2(0, 8, 8, 35, 16, 2, 2, 2, 37)     // up2 backward-data: 4 rows x 4 planes per workgroup
+  NVF_S2(0, 8, 16, 19, 8, 2, 2, 1, 24)     // up1 backward-data: 4 rows x 2 planes
+  NVF_S2(2, 8, 8, 35, 16, 2, 2, 1, 37)
+  NVF_S2(3, 8, 8, 35, 16, 1, 4, 2, 37)
+  NVF_S2(2, 8, 16, 19, 8, 2, 2, 2, 24)
+  NVF_S2(3, 8, 16, 19, 8, 1, 4, 1, 24)
+#undef NVF_S2
+  if (rc == 1) return NVF_EINVAL;
+  NVF_LAUNCH_CHECK();
+  return rc;
+}

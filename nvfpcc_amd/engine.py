@@ -43,7 +43,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t")
+                 "wp_b", "wp_t", "wp_s")
 
 
 class TrainEngine:
@@ -126,10 +126,13 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = L.wp_t = None
+            L.wp_f = L.wp_b = L.wp_t = L.wp_s = None
             if L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
-                # matrix-core form of the padding-0 transposed convolutions (forward)
+                # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
+                # stride-2 gather convolution with cin output channels)
                 L.wp_t = torch.empty(int(lib().nvf_pack_convT_mfma_floats(L.cin)), device=self.dev)
+                if L.cin in (8, 16):
+                    L.wp_s = torch.empty(int(lib().nvf_pack_s2k5_mfma_floats(L.cout, L.cin)), device=self.dev)
             if L.k == 4 and L.cin % 4 == 0 and L.cout == 8 and L.cin == 8 and L.pad == 0:
                 # matrix-core form of the 4^3 convolutions: MFMA A-fragments, re-packed after every weight preparation
                 L.wp_f = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cin, 0)), device=self.dev)
@@ -161,6 +164,8 @@ class TrainEngine:
         for L in self.layers.values():
             if L.wp_t is not None:
                 ops.pack_convT_mfma(L.w_fwd, L.cin, out=L.wp_t)
+            if L.wp_s is not None:
+                ops.pack_s2k5_mfma(L.w_bwd, L.cout, L.cin, out=L.wp_s)
 
     # ------------------------------------------------------------------ forward
     def _convT(self, L, x, act):
@@ -234,6 +239,8 @@ class TrainEngine:
                                  addend=addend, mask=mask)
 
     def _dx_convT(self, L, g_out, x_in, mask=None, addend=None):
+        if L.wp_s is not None:
+            return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)
 

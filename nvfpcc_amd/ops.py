@@ -198,6 +198,31 @@ def convT3d_k5s2_mfma(x, wp, bias, act=ACT_NONE, out=None):
     return y
 
 
+def pack_s2k5_mfma(w_bwd, cig, cog, out=None):
+    """MFMA A-fragments for the backward-data of a k5 s2 transposed conv: w_bwd is its [cout][125][cin] layout."""
+    _f32(w_bwd, out)
+    n = int(lib().nvf_pack_s2k5_mfma_floats(cig, cog))
+    wp = out if out is not None else torch.empty(n, device=w_bwd.device)
+    if w_bwd.numel() != cig * 125 * cog or wp.numel() != n:
+        raise RuntimeError("pack_s2k5_mfma: weight size does not match (cig, 5, cog)")
+    check(lib().nvf_pack_s2k5_mfma(_ptr(w_bwd), cig, cog, _ptr(wp), _stream()), "nvf_pack_s2k5_mfma")
+    return wp
+
+
+def conv3d_s2k5_mfma(g, wp, cog, addend=None, mask=None, out=None):
+    """Matrix-core backward-data of a k5 s2 padding-0 transposed convolution (stride-2 gather conv)."""
+    _f32(g, wp, addend, mask)
+    B, cig, di = g.shape[0], g.shape[1], g.shape[2]
+    do = (di - 3) // 2
+    dx = out if out is not None else torch.empty((B, cog, do, do, do), device=g.device)
+    for t in (addend, mask):
+        if t is not None and t.shape != dx.shape:
+            raise RuntimeError("addend/mask shape must equal the output shape")
+    check(lib().nvf_conv3d_s2k5_mfma(_ptr(g), _ptr(wp), _ptr(dx), _ptr(addend), _ptr(mask), B, cig, cog, di, do,
+                                     _MFMA_VARIANT, _stream()), "nvf_conv3d_s2k5_mfma")
+    return dx
+
+
 def stem_fwd(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b):
     """Fused up0 -> IGDN -> conv0 + ReLU for chanstr (8, 16, ...): returns (a0, h0, y1)."""
     _f32(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b)

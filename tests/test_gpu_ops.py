@@ -105,6 +105,27 @@ def test_conv_transpose_k5s2_mfma_forward(ops, cin, n, B):
         assert torch.equal(yi[0], y[i])
 
 
+@pytest.mark.parametrize("cin,n,B", [(8, 16, 2), (16, 8, 3)])
+def test_conv_transpose_k5s2_mfma_backward_data(ops, cin, n, B):
+    """Matrix-core backward-data of up1 / up2 against torch's autograd (with the fused addend and ReLU mask)."""
+    g = gen(6000 + cin + n + B)
+    x = torch.randn(B, cin, n, n, n, generator=g, requires_grad=True)
+    w = torch.randn(cin, 8, 5, 5, 5, generator=g) / (cin * 125 / 8) ** 0.5
+    y = F.conv_transpose3d(x, w, None, stride=2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    mask = torch.randn(x.shape, generator=g)
+    add = torch.randn(x.shape, generator=g)
+    _, wb = ops.pack_convT_weight(dev(w))
+    wp = ops.pack_s2k5_mfma(wb, 8, cin)
+    dx = ops.conv3d_s2k5_mfma(dev(gy), wp, cin)
+    assert rel_err(dx, x.grad) < 1e-5
+    dx2 = ops.conv3d_s2k5_mfma(dev(gy), wp, cin, addend=dev(add), mask=dev(mask))
+    assert rel_err(dx2, (x.grad + add) * (mask > 0)) < 1e-5
+    one = ops.conv3d_s2k5_mfma(dev(gy)[1:2].contiguous(), wp, cin)
+    assert torch.equal(one[0], dx[1])
+
+
 # matrix-core (MFMA) form of the 4^3, 8 -> 8 channel convolutions: (spatial_in, batch)
 @pytest.mark.parametrize("n,B", [(35, 2), (19, 3), (35, 1), (19, 5)])
 def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):

@@ -83,6 +83,30 @@ def main():
             t = timeit(lambda: ops.convT3d_k5s2_mfma(x, wp, bias, ops.ACT_RELU))
             row += f" v{v}: {t:7.1f}us {2 * macs / t / 1e6:6.1f}TF err {err:.1e} |"
         print(row, flush=True)
+    for name, cin, n in (("up2.bwd_data", 8, 16), ("up1.bwd_data", 16, 8)):
+        no = 2 * n + 3
+        gy = torch.randn(B, 8, no, no, no, device=dev)
+        w = torch.randn(cin, 8, 5, 5, 5, device=dev) * 0.05
+        _, wb = ops.pack_convT_weight(w)
+        mask = torch.randn(B, cin, n, n, n, device=dev)
+        add = torch.randn(B, cin, n, n, n, device=dev)
+        ops.set_mfma_variant(0)
+        ref = ops.conv3d_gather(gy, wb, None, cin, 5, 2, 0, (n, n, n), addend=add, mask=mask)
+        t_ref = timeit(lambda: ops.conv3d_gather(gy, wb, None, cin, 5, 2, 0, (n, n, n), addend=add, mask=mask))
+        macs = B * cin * n ** 3 * 8 * 125
+        wp = ops.pack_s2k5_mfma(wb, 8, cin)
+        row = f"{name:16s} valu {t_ref:8.1f}us {2 * macs / t_ref / 1e6:6.1f}TF |"
+        for v in [int(v) for v in a.variants.split(",")]:
+            ops.set_mfma_variant(v)
+            try:
+                got = ops.conv3d_s2k5_mfma(gy, wp, cin, addend=add, mask=mask)
+            except Exception:
+                continue
+            torch.cuda.synchronize()
+            err = (got - ref).abs().max().item() / ref.abs().max().item()
+            t = timeit(lambda: ops.conv3d_s2k5_mfma(gy, wp, cin, addend=add, mask=mask))
+            row += f" v{v}: {t:7.1f}us {2 * macs / t / 1e6:6.1f}TF err {err:.1e} |"
+        print(row, flush=True)
     ops.set_mfma_variant(0)
 
 
