@@ -202,37 +202,64 @@ __global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g
   const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
   const int first = blockIdx.x * d.items_per_wg;
   const int last = min(first + d.items_per_wg, d.items);
-#pragma unroll 1
-  for (int item = first; item < last; ++item) {
+  // Tile staging through registers: ALL global loads of an item (dY: aligned float4 rows; X: 35- or 19-float rows,
+  // element by element) are issued before any is waited for, and the next item's loads are in flight while this
+  // item's MFMAs issue.  The zero padding of the LDS image (u = 0, u > W, xx >= WQ) is written once.
+  constexpr int RX = (TZ + 3) * (TY + 3);                 // X rows per channel
+  constexpr int NG4 = 8 * TZ * TY * (W / 4);              // float4 items of the dY tile
+  constexpr int NXE = 8 * RX * (W + 3);                   // elements of the X tile
+  constexpr int UG = (NG4 + 255) / 256, UX = (NXE + 255) / 256;
+  float4 gv[UG];
+  float xv[UX];
+  auto load = [&](int item) {
     const int n = item / tiles, t = item % tiles;
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
-    if (item != first) __syncthreads();
-    // dY tile, zero-padded in x: u = x + 1
     const float* gn = g + (size_t)n * 8 * W * W * W;
-    nvf_stage_rows<256, 8 * TZ * TY, GRS, GRS, 8>(
-        gn, ldsG, tid,
-        [&](int r, int u, bool& ok) -> size_t {
-          const int yy = r % TY, t2 = r / TY, zz = t2 % TZ, c = t2 / TZ;
-          ok = u >= 1 && u <= W;
-          return (((size_t)c * W + z0 + zz) * W + y0 + yy) * W + (u - 1);
-        },
-        [&](int r, int u) {
-          const int c = r / (TZ * TY);
-          return c * GCS + (r - c * TZ * TY) * GRS + u;
-        });
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int i = tid + u * 256;
+      const int xq = i % (W / 4), r = i / (W / 4), yy = r % TY, t2 = r / TY, zz = t2 % TZ, c = t2 / TZ;
+      gv[u] = i < NG4 ? *(const float4*)(gn + (((size_t)c * W + z0 + zz) * W + y0 + yy) * W + 4 * xq)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float* xn = x + (size_t)n * 8 * WQ * WQ * WQ;
-    nvf_stage_rows<256, 8 * (TZ + 3) * (TY + 3), XRS, XRS, 8>(
-        xn, ldsX, tid,
-        [&](int r, int xx, bool& ok) -> size_t {
-          const int yy = r % (TY + 3), t2 = r / (TY + 3), zz = t2 % (TZ + 3), c = t2 / (TZ + 3);
-          ok = xx < WQ;
-          return (((size_t)c * WQ + z0 + zz) * WQ + y0 + yy) * WQ + xx;
-        },
-        [&](int r, int xx) {
-          const int c = r / ((TZ + 3) * (TY + 3));
-          return c * XCS + (r - c * (TZ + 3) * (TY + 3)) * XRS + xx;
-        });
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int e = tid + u * 256;
+      const int xx = e % (W + 3), r = e / (W + 3), yy = r % (TY + 3), t2 = r / (TY + 3), zz = t2 % (TZ + 3), c = t2 / (TZ + 3);
+      xv[u] = e < NXE ? xn[(((size_t)c * WQ + z0 + zz) * WQ + y0 + yy) * WQ + xx] : 0.f;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int i = tid + u * 256;
+      if (i < NG4) {
+        const int xq = i % (W / 4), r = i / (W / 4), c = r / (TZ * TY);
+        float* dst = ldsG + c * GCS + (r - c * TZ * TY) * GRS + 4 * xq + 1;      // u = x + 1
+        dst[0] = gv[u].x; dst[1] = gv[u].y; dst[2] = gv[u].z; dst[3] = gv[u].w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int e = tid + u * 256;
+      if (e < NXE) {
+        const int xx = e % (W + 3), r = e / (W + 3), c = r / RX;
+        ldsX[c * XCS + (r - c * RX) * XRS + xx] = xv[u];
+      }
+    }
+  };
+  for (int i = tid; i < C::LDSF; i += 256) lds[i] = 0.f;
+  if (first < last) load(first);
+#pragma unroll 1
+  for (int item = first; item < last; ++item) {
+    const int t = item % tiles;
+    const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
+    (void)y0; (void)z0;
+    __syncthreads();                                        // zero fill done / previous item no longer being read
+    store();
     __syncthreads();
+    if (item + 1 < last) load(item + 1);
 #pragma unroll 1
     for (int row = wave; row < TZ * TY; row += 4) {
       const int zz = row / TY, yy = row % TY;
@@ -285,7 +312,8 @@ template <class C>
 static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* slabs, WgDims d, int accumulate,
                              hipStream_t s, int* defer_nslab) {
   d.items = d.batch * (C::W / C::TY) * (C::W / C::TZ);
-  int nslab = d.items < kMaxSlabs ? d.items : kMaxSlabs;
+  // one workgroup per CU (it holds 256 VGPRs per lane): each walks its items with the next item's loads in flight
+  int nslab = d.items < 256 ? d.items : 256;
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
   wgrad_k4_mfma<C><<<nslab, 256, 0, s>>>(g, x, slabs, d);
@@ -551,14 +579,25 @@ __global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d,
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int n = n_lo; n < n_hi; ++n) {
     const float* row = x + ((size_t)n * c + ch) * spatial;     // one contiguous row per (n, channel)
-    if ((spatial & 3) == 0) {
-      for (int i = threadIdx.x * 4; i < spatial; i += blockDim.x * 4) {
-        const float4 v = *(const float4*)(row + i);
-        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-      }
-    } else {
-      for (int i = threadIdx.x; i < spatial; i += blockDim.x) s0 += row[i];
+    // rows of 35^3 or 19^3 floats start at any 4-byte phase: a scalar head up to the next 16-byte boundary, then
+    // aligned float4s (four per thread in flight), then a scalar tail
+    const int head = (int)((4 - (((uintptr_t)row >> 2) & 3)) & 3);
+    const int body = (spatial - head) & ~3;
+    if ((int)threadIdx.x < head) s0 += row[threadIdx.x];
+    const float4* r4 = (const float4*)(row + head);
+    const int n4 = body >> 2;
+    int i = threadIdx.x;
+    for (; i + 3 * (int)blockDim.x < n4; i += 4 * blockDim.x) {
+      const float4 a = r4[i], b4 = r4[i + blockDim.x], c4 = r4[i + 2 * blockDim.x], d4 = r4[i + 3 * blockDim.x];
+      s0 += (a.x + b4.x) + (c4.x + d4.x); s1 += (a.y + b4.y) + (c4.y + d4.y);
+      s2 += (a.z + b4.z) + (c4.z + d4.z); s3 += (a.w + b4.w) + (c4.w + d4.w);
     }
+    for (; i < n4; i += blockDim.x) {
+      const float4 v = r4[i];
+      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    const int tail = head + body + threadIdx.x;
+    if (tail < spatial) s1 += row[tail];
   }
   const float s = nvf_block_sum((s0 + s1) + (s2 + s3), red);
   if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
