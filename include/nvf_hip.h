@@ -123,6 +123,11 @@ int nvf_pack_s2k5_mfma(const float* gather_w, int cig, int cog, float* wp, void*
 int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, const float* addend, const float* mask,
                          int batch, int cig, int cog, int din, int dout, int variant, void* stream);
 
+/* every MFMA weight packing of a step in one launch (<= 8 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
+ * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog) */
+int nvf_pack_mfma_all(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s, const int* c1s,
+                      int n, void* stream);
+
 /* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when

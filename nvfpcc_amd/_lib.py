@@ -36,6 +36,7 @@ PROTOTYPES = {
     "nvf_pack_s2k5_mfma_floats": (Z, [I, I]),
     "nvf_pack_s2k5_mfma": (I, [P, I, I, P, P]),
     "nvf_conv3d_s2k5_mfma": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "nvf_pack_mfma_all": (I, [P, P, P, P, P, I, P]),
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "nvf_stem_bwd_workspace": (Z, [I, I]),
     "nvf_stem_bwd": (I, [P] * 13 + [Z, I, I, I, I, P]),

@@ -618,12 +618,14 @@ __global__ __launch_bounds__(256) void focal_multi_kernel(FocalMulti m, float* _
   if (threadIdx.x == 0) part[t * kLossMaxWG + blockIdx.x] = tot;
 }
 
+// one wave per loss term: lanes take the partials 64 apart (ascending), then a fixed-order wave sum
 __global__ void focal_multi_final(FocalMulti m, const float* __restrict__ part, float* __restrict__ loss, int nterm) {
-  int t = threadIdx.x;
+  const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (t >= nterm) return;
   float s = 0.f;
-  for (int g = 0; g < m.nwg[t]; ++g) s += part[t * kLossMaxWG + g];
-  loss[t] = s;
+  for (int g = lane; g < m.nwg[t]; g += 64) s += part[t * kLossMaxWG + g];
+  s = nvf_wave_sum(s);
+  if (lane == 0) loss[t] = s;
 }
 
 extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const float* const* dists,
@@ -645,7 +647,7 @@ extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* 
   }
   hipStream_t s = nvf_stream(stream);
   focal_multi_kernel<<<dim3(maxwg, nterm), 256, 0, s>>>(m, (float*)workspace, chain_sigmoid);
-  focal_multi_final<<<1, 64, 0, s>>>(m, (const float*)workspace, loss, nterm);
+  focal_multi_final<<<1, 64 * nterm, 0, s>>>(m, (const float*)workspace, loss, nterm);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

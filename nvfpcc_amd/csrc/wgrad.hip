@@ -31,30 +31,29 @@ struct WgDims {
   int out_mode, jtotal;    // slab layout, slab length A*Bc*K^3
 };
 
+// general shape, one WAVE per output: lanes stride over the (n, iz, iy, ix) positions, fixed-order wave sum
 __global__ void wgrad_naive(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ dw, int a_ch,
                             int k, int stride, WgDims d, int accumulate) {
   int k3 = k * k * k;
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (j >= a_ch * d.bc * k3) return;
   int kk = j % k3, b = (j / k3) % d.bc, a = j / (k3 * d.bc);
   int kz = kk / (k * k), ky = (kk / k) % k, kx = kk % k;
+  const long plane = (long)d.hp * d.wp, vol = (long)d.dp * plane, total = (long)d.batch * vol;
   float acc = 0.f;
-  for (int n = 0; n < d.batch; ++n)
-    for (int iz = 0; iz < d.dp; ++iz) {
-      int qz = iz * stride - d.pad + kz;
-      if (qz < 0 || qz >= d.dq) continue;
-      for (int iy = 0; iy < d.hp; ++iy) {
-        int qy = iy * stride - d.pad + ky;
-        if (qy < 0 || qy >= d.hq) continue;
-        for (int ix = 0; ix < d.wp; ++ix) {
-          int qx = ix * stride - d.pad + kx;
-          if (qx < 0 || qx >= d.wq) continue;
-          float pv = p[(((size_t)n * a_ch + a) * d.dp + iz) * d.hp * d.wp + iy * d.wp + ix];
-          float qv = q[(((size_t)n * d.bc + b) * d.dq + qz) * d.hq * d.wq + qy * d.wq + qx];
-          acc = fmaf(pv, qv, acc);
-        }
-      }
-    }
+  for (long e = lane; e < total; e += 64) {
+    const int n = (int)(e / vol);
+    const long r = e - (long)n * vol;
+    const int iz = (int)(r / plane), iy = (int)((r - (long)iz * plane) / d.wp), ix = (int)(r % d.wp);
+    const int qz = iz * stride - d.pad + kz, qy = iy * stride - d.pad + ky, qx = ix * stride - d.pad + kx;
+    if (qz < 0 || qz >= d.dq || qy < 0 || qy >= d.hq || qx < 0 || qx >= d.wq) continue;
+    const float pv = p[((size_t)n * a_ch + a) * vol + r];
+    const float qv = q[(((size_t)n * d.bc + b) * d.dq + qz) * d.hq * d.wq + qy * d.wq + qx];
+    acc = fmaf(pv, qv, acc);
+  }
+  acc = nvf_wave_sum(acc);
+  if (lane != 0) return;
   int o = d.out_mode == 0 ? j : (b * a_ch + a) * k3 + (k3 - 1 - kk);
   dw[o] = accumulate ? dw[o] + acc : acc;
 }
@@ -432,7 +431,7 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
 #undef NVF_W
   }
   if (rc == 1) {
-    wgrad_naive<<<(d.jtotal + 63) / 64, 64, 0, s>>>(p, q, dw, a, k, stride, d, accumulate);
+    wgrad_naive<<<(d.jtotal + 3) / 4, 256, 0, s>>>(p, q, dw, a, k, stride, d, accumulate);
     if (defer_nslab) *defer_nslab = 0;   // dw is already final
     rc = NVF_OK;
   }

@@ -16,6 +16,8 @@ Result-preserving shortcuts taken from the reference's own data flow: the mini-b
 uses the latent gradients (they are zeroed at NVFPCC.py:226) and the latent phase never uses the
 decoder weight gradients (zeroed at NVFPCC.py:150), so each phase skips the half it discards.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -81,7 +83,7 @@ class TrainEngine:
         # second HIP stream: weight gradients, head backward-data, bias sums and the weight-rate term do not sit on
         # the backward-data chain, so they overlap with it (at batch 16 one kernel cannot fill 256 CUs by itself)
         self.side = torch.cuda.Stream(device=self.dev)
-        self.allow_overlap = True
+        self.allow_overlap = os.environ.get("NVF_OVERLAP", "1") != "0"   # tuning switch
         self.fused_stem = tuple(net.reconstructor.channels[:2]) == (8, 16) and net.entropy_coder.sigma.shape[1] <= 8
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
@@ -148,8 +150,11 @@ class TrainEngine:
             t["quantised"] = 1 if name in TRUNK else 0
             t["layer_id"] = m.layer_id
             t["nbias"] = m.b.numel()
-        self._mfma_jobs = [(L.w_fwd, L.cin, 0, L.wp_f) for L in self.layers.values() if L.wp_f is not None]
-        self._mfma_jobs += [(L.w_bwd, L.cout, 2, L.wp_b) for L in self.layers.values() if L.wp_b is not None]
+        jobs = [(L.w_fwd, L.wp_f, 0, L.cin, 8) for L in self.layers.values() if L.wp_f is not None]
+        jobs += [(L.w_bwd, L.wp_b, 2, L.cout, 8) for L in self.layers.values() if L.wp_b is not None]
+        jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for L in self.layers.values() if L.wp_t is not None]
+        jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for L in self.layers.values() if L.wp_s is not None]
+        self._mfma_jobs = jobs
         self._table_host = table
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.dev)
         self.nlayers = len(mods)
@@ -160,12 +165,7 @@ class TrainEngine:
                                         0 if sd is not None else self.noise_step, None if sd is None else sd.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights")
         if self._mfma_jobs:
-            ops.pack_mfma_k4_multi(self._mfma_jobs)
-        for L in self.layers.values():
-            if L.wp_t is not None:
-                ops.pack_convT_mfma(L.w_fwd, L.cin, out=L.wp_t)
-            if L.wp_s is not None:
-                ops.pack_s2k5_mfma(L.w_bwd, L.cout, L.cin, out=L.wp_s)
+            ops.pack_mfma_all(self._mfma_jobs)      # conv1, conv2, up1, up2: every MFMA weight layout, one launch
 
     # ------------------------------------------------------------------ forward
     def _convT(self, L, x, act):

@@ -140,6 +140,18 @@ def pack_mfma_k4_multi(jobs):
           "nvf_pack_mfma_k4_multi")
 
 
+def pack_mfma_all(jobs):
+    """jobs: list of (src, dst, kind, c0, c1) -- see nvf_pack_mfma_all; one launch for all of them."""
+    import ctypes
+    n = len(jobs)
+    _f32(*[j[0] for j in jobs])
+    _f32(*[j[1] for j in jobs])
+    check(lib().nvf_pack_mfma_all((ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs]),
+                                  (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in jobs]),
+                                  (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]),
+                                  (ctypes.c_int * n)(*[j[4] for j in jobs]), n, _stream()), "nvf_pack_mfma_all")
+
+
 def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=None, out=None):
     """Matrix-core 4^3 convolution, 8 output channels: same contract as conv3d_gather(k=4, stride=1)."""
     _f32(x, wp, bias, addend, mask)

@@ -162,6 +162,14 @@ def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
     wpf2, wpb2 = torch.empty_like(wpf), torch.empty_like(wpb)
     ops.pack_mfma_k4_multi([(wf, 8, 0, wpf2), (wb, 8, 2, wpb2)])
     assert torch.equal(wpf, wpf2) and torch.equal(wpb, wpb2)
+    # ... and so does the all-kinds launch the step engine uses (here with a transposed-conv weight as well)
+    wt = torch.randn(16, 8, 5, 5, 5, generator=g) * 0.05
+    wtf, wtb = ops.pack_convT_weight(dev(wt))
+    ref_t, ref_s = ops.pack_convT_mfma(wtf, 16), ops.pack_s2k5_mfma(wtb, 8, 16)
+    outs = [torch.empty_like(t) for t in (wpf, wpb, ref_t, ref_s)]
+    ops.pack_mfma_all([(wf, outs[0], 0, 8, 8), (wb, outs[1], 2, 8, 8), (wtf, outs[2], 10, 16, 8), (wtb, outs[3], 20, 8, 16)])
+    for got, ref in zip(outs, (wpf, wpb, ref_t, ref_s)):
+        assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("cin,cout,pad,opad,n", CONVT_CASES)
