@@ -22,8 +22,9 @@ struct HCfg {
   static constexpr int XG = S / 4;                 // float4 groups per row
   static constexpr int RS = S + 8;                 // LDS row: x = -1 at word 3, x = 0 at word 4 (16-B aligned)
   static constexpr int IZ = TZ + 2, IY = TY + 2;
-  static constexpr int NT = TZ * TY * XG;          // one thread per four outputs
-  static_assert(S % 4 == 0 && NT >= 64 && NT <= 1024 && NT % 64 == 0, "tile");
+  static constexpr int NACT = TZ * TY * XG;        // one thread per four outputs
+  static constexpr int NT = NACT < 256 ? 256 : NACT;   // small tiles: the other threads only help staging
+  static_assert(S % 4 == 0 && NACT >= 64 && NT <= 1024 && NACT % 64 == 0, "tile");
 };
 
 // C channels of the x tile (with a one-voxel halo, zero outside the tensor) -> LDS [c][IZ][IY][RS]
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(H::NT) void head_fwd_kernel(const float* __restrict
   for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
   head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
   __syncthreads();
+  if (tid >= H::NACT) return;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(H::NT) void head_bwd_data_kernel(const float* __res
   for (int i = tid; i < 27 * C; i += NT) ws[i] = wb[i];
   head_stage<1, S, IZ, IY, RS, NT>(dl + (size_t)b * S * S * S, ds, tid, z0, y0);
   __syncthreads();
+  if (tid >= H::NACT) return;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
   float acc[C][4];
 #pragma unroll

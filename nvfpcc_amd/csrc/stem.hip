@@ -75,8 +75,11 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
   __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1
   __shared__ __attribute__((aligned(16))) float s_w0[MAXCH * 125 * C0];
   __shared__ __attribute__((aligned(16))) float s_w1[C0 * 125 * COG];
+  __shared__ float s_beta[C0], s_gamma[C0 * C0];
   const int b = blockIdx.x, part = blockIdx.y, co0 = part * COG, tid = threadIdx.x;
   if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
+  if (tid >= 64 && tid < 64 + C0) s_beta[tid - 64] = st_beta(beta_hat[tid - 64]);
+  if (tid >= 128 && tid < 128 + C0 * C0) s_gamma[tid - 128] = st_gamma(gamma_hat[tid - 128]);
   for (int e = tid; e < C0 * 216; e += 512) s_h[e] = 0.f;
   for (int e = tid; e < ch * 125 * C0; e += 512) s_w0[e] = w0[e];
   for (int e = tid; e < C0 * 125 * COG; e += 512) s_w1[e] = w1[(size_t)(e / COG) * C1 + co0 + e % COG];
@@ -105,10 +108,11 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
   }
   __syncthreads();
   {  // IGDN: h0 = a0 * sqrt(beta_c + sum_j gamma_cj a0_j^2)
-    float nrm = st_beta(beta_hat[c]);
+    float nrm = s_beta[c];
+#pragma unroll
     for (int j = 0; j < C0; ++j) {
       const float xj = s_a[j * 64 + v];
-      nrm = fmaf(st_gamma(gamma_hat[c * C0 + j]), xj * xj, nrm);
+      nrm = fmaf(s_gamma[c * C0 + j], xj * xj, nrm);
     }
     const float hv = s_a[tid] * sqrtf(nrm);
     if (part == 0) h0[(size_t)b * C0 * 64 + tid] = hv;

@@ -328,9 +328,20 @@ __global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ s
   __shared__ float part[16][64];
   const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jl;
-  float s = 0.f;
-  if (j < jtotal)
-    for (int g = sl; g < nslab; g += 16) s += slabs[(size_t)g * jtotal + j];
+  // four independent partial sums keep four loads in flight; the order (4 strided chains, then a fixed tree) is
+  // the same in wgrad_reduce and wgrad_reduce_multi
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < jtotal) {
+    int g = sl;
+    for (; g + 48 < nslab; g += 64) {
+      s0 += slabs[(size_t)g * jtotal + j];
+      s1 += slabs[(size_t)(g + 16) * jtotal + j];
+      s2 += slabs[(size_t)(g + 32) * jtotal + j];
+      s3 += slabs[(size_t)(g + 48) * jtotal + j];
+    }
+    for (; g < nslab; g += 16) s0 += slabs[(size_t)g * jtotal + j];
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   part[sl][jl] = s;
   __syncthreads();
   if (sl == 0 && j < jtotal) {
@@ -473,9 +484,20 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi(WgReduceMulti d) {
   const int nslab = d.nslab[t], jtotal = d.jtotal[t];
   const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int j = ((int)blockIdx.x - d.blk_base[t]) * 64 + jl;
-  float s = 0.f;
-  if (j < jtotal)
-    for (int g = sl; g < nslab; g += 16) s += slabs[(size_t)g * jtotal + j];
+  // four independent partial sums keep four loads in flight; the order (4 strided chains, then a fixed tree) is
+  // the same in wgrad_reduce and wgrad_reduce_multi
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < jtotal) {
+    int g = sl;
+    for (; g + 48 < nslab; g += 64) {
+      s0 += slabs[(size_t)g * jtotal + j];
+      s1 += slabs[(size_t)(g + 16) * jtotal + j];
+      s2 += slabs[(size_t)(g + 32) * jtotal + j];
+      s3 += slabs[(size_t)(g + 48) * jtotal + j];
+    }
+    for (; g < nslab; g += 16) s0 += slabs[(size_t)g * jtotal + j];
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   part[sl][jl] = s;
   __syncthreads();
   if (sl == 0 && j < jtotal) {
