@@ -166,12 +166,16 @@ def main():
 
     probe = KernelProbe()
     c3 = int(args.chanstr.split(",")[3])
+    # conv2 forward runs on the matrix cores (nvf_conv3d_k4_mfma), its backward-data on the VALU gather kernel
+    # (nvf_conv3d_gather), its weight gradient on the matrix cores (partial-sum launch of nvf_wgrad_partial)
+    probe.wrap(ops, "conv3d_k4_mfma", "conv2_fwd",
+               lambda x, wp, b, pad, pair, *a, **kw: pad == 0 and x.shape[-1] == 35 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_gather", "conv2_fwd",
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 35 and x.shape[1] == c3)
-    probe.wrap(ops, "wgrad", "conv2_bwd_weight(2 launches)",
-               lambda p_, q_, k, s, pad, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
+    probe.wrap(ops.WgradBatch, "add", "conv2_bwd_weight",
+               lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
 
     def barrier():
         torch.cuda.synchronize()
@@ -231,7 +235,7 @@ def main():
         macs = CONV2_MACS.get(args.chanstr)
         roofline = None
         if kern_us and macs:
-            single = {k: v for k, v in kern_us.items() if "2 launches" not in k}
+            single = dict(kern_us)
             label = max(single, key=single.get)
             us = single[label]
             flops = 2.0 * macs * B
