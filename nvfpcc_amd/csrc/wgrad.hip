@@ -321,6 +321,146 @@ static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* s
   return NVF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MFMA weight gradient of the stride-2, 5^3 transposed convolution with 8 -> 8 channels (up2):
+//   dW[ci][co][kz][ky][kx] = sum_{n,i} x[ci, i] g[co, 2 i + k]
+// K of the MFMA runs along four consecutive input positions ix; rows m = (ci, sA) take x shifted by sA, columns
+// n = (co, sB) take g[.., 2 ix + sB (+ 2)]:
+//   tile 1: D[(ci,sA)][(co,sB)]   = dW[kx = 2 sA + sB]        -- kx 0..3, every lane useful
+//   tile 2: the same A with g two words further: kx = 2 sA + sB + 2 -- only (sA,sB) = (1,0), kx = 4, is kept
+// so each (kz, ky) costs two accumulators and 5 of 8 lane-taps are useful.  The 25 (kz, ky) pairs are dealt
+// round-robin to the four waves (no cross-wave reduction); a workgroup walks items (n, 2 input planes, 2 input
+// rows) with the next item's global loads already in registers, and writes one slab at the end.
+// ---------------------------------------------------------------------------------------------------
+template <int TZ_, int TY_>
+struct TWCfg {
+  static constexpr int W = 16, WG = 35, TZ = TZ_, TY = TY_;
+  static constexpr int GZ = 2 * TZ + 3, GY = 2 * TY + 3;
+  static constexpr int GRS = 36, XRS = 22;                  // g row: 35 words; x row: u = ix + 1 in 0..20, zero outside 1..16
+  static constexpr int mod32(int v, int r) { return v + ((r - v % 32) + 32) % 32; }
+  static constexpr int GCS = mod32(GZ * GY * GRS, 8), XCS = mod32(TZ * TY * XRS, 8);
+  static constexpr int GOFF = 0, XOFF = 8 * GCS, LDSF = 8 * GCS + 8 * XCS;
+  static constexpr int NGE = 8 * GZ * GY * WG, NXE = 8 * TZ * TY * W;     // elements to load per item
+  static constexpr int UG = (NGE + 255) / 256, UX = (NXE + 255) / 256;
+  static_assert(LDSF * 4 <= 160 * 1024, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__ x, const float* __restrict__ g,
+                                                       float* __restrict__ slabs, WgDims d) {
+  constexpr int W = C::W, WG = C::WG, TZ = C::TZ, TY = C::TY, GZ = C::GZ, GY = C::GY, GRS = C::GRS, XRS = C::XRS,
+                GCS = C::GCS, XCS = C::XCS, UG = C::UG, UX = C::UX;
+  __shared__ float lds[C::LDSF];
+  float* ldsG = lds + C::GOFF;
+  float* ldsX = lds + C::XOFF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kk = lane >> 4, ch = (lane & 15) >> 1, sh = lane & 1;
+  const int laneA = ch * XCS + kk - sh + 1;                  // x[ci = ch, ix0 + kk - sA], u = ix + 1
+  const int laneB = ch * GCS + 2 * kk + sh;                  // g[co = ch, 2 (ix0 + kk) + sB]
+  constexpr int NTW = 7;                                     // (kz, ky) pairs per wave: t = wave + 4 i
+  f32x4 acc1[NTW], acc2[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) { acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
+  const int first = blockIdx.x * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
+  float gv[UG], xv[UX];
+  auto load = [&](int item) {
+    const int n = item / tiles, t = item % tiles;
+    const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
+    const float* gn = g + (size_t)n * 8 * WG * WG * WG;
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int e = tid + u * 256;
+      const int xx = e % WG, r = e / WG, yy = r % GY, t2 = r / GY, zz = t2 % GZ, c = t2 / GZ;
+      gv[u] = e < C::NGE ? gn[(((size_t)c * WG + 2 * z0 + zz) * WG + 2 * y0 + yy) * WG + xx] : 0.f;
+    }
+    const float* xn = x + (size_t)n * 8 * W * W * W;
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int e = tid + u * 256;
+      const int xx = e % W, r = e / W, yy = r % TY, t2 = r / TY, zz = t2 % TZ, c = t2 / TZ;
+      xv[u] = e < C::NXE ? xn[(((size_t)c * W + z0 + zz) * W + y0 + yy) * W + xx] : 0.f;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int e = tid + u * 256;
+      if (e < C::NGE) {
+        const int xx = e % WG, r = e / WG, c = r / (GZ * GY);
+        ldsG[c * GCS + (r - c * GZ * GY) * GRS + xx] = gv[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int e = tid + u * 256;
+      if (e < C::NXE) {
+        const int xx = e % W, r = e / W, c = r / (TZ * TY);
+        ldsX[c * XCS + (r - c * TZ * TY) * XRS + xx + 1] = xv[u];
+      }
+    }
+  };
+  for (int i = tid; i < C::LDSF; i += 256) lds[i] = 0.f;     // padding words stay zero for the whole launch
+  if (first < last) load(first);
+#pragma unroll 1
+  for (int item = first; item < last; ++item) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (item + 1 < last) load(item + 1);
+#pragma unroll 1
+    for (int r = 0; r < TZ * TY; ++r) {
+      const int zl = r / TY, yl = r % TY;
+      const float* pa = ldsX + laneA + r * XRS;
+      const float* pb = ldsG + laneB + ((2 * zl) * GY + 2 * yl) * GRS;
+#pragma unroll 1
+      for (int xg = 0; xg < W / 4 + 1; ++xg) {               // the rows shifted by sA = 1 need ix = 15 from a fifth group
+        const float a = pa[4 * xg];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          const int t = wave + 4 * i;                        // wave-uniform; t < 25
+          if (t < 25) {
+            const int kz = t / 5, ky = t % 5;
+            const float* q = pb + (kz * GY + ky) * GRS + 8 * xg;
+            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, q[0], acc1[i], 0, 0, 0);
+            acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, q[2], acc2[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // lane holds column n = (co, sB) = lane & 15 and rows m = 4 (lane >> 4) + r = (ci, sA)
+  float* slab = slabs + (size_t)blockIdx.x * 8000;
+  const int co = (lane & 15) >> 1, sB = lane & 1;
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int t = wave + 4 * i;
+    if (t < 25) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (lane >> 4) + r, ci = m >> 1, sA = m & 1;
+        float* o = slab + (ci * 8 + co) * 125 + t * 5;
+        o[2 * sA + sB] = acc1[i][r];
+        if (sA == 1 && sB == 0) o[4] = acc2[i][r];
+      }
+    }
+  }
+}
+
+template <class C>
+static int launch_wgrad_s2k5(const float* x, const float* g, float* dw, float* slabs, WgDims d, int accumulate,
+                             hipStream_t s, int* defer_nslab) {
+  d.items = d.batch * (C::W / C::TY) * (C::W / C::TZ);
+  int nslab = d.items < 256 ? d.items : 256;                 // one workgroup per CU
+  d.items_per_wg = (d.items + nslab - 1) / nslab;
+  nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+  wgrad_s2k5_mfma<C><<<nslab, 256, 0, s>>>(x, g, slabs, d);
+  if (defer_nslab) *defer_nslab = nslab;
+  else wgrad_reduce<<<(8000 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 8000, accumulate);
+  return NVF_OK;
+}
+
 // dw[j] (+)= sum_g slabs[g][j]: 16 interleaved slices of g per output (each summed in ascending g), then the
 // slices added in order 0..15 -- a fixed order, so the result is reproducible
 __global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw,
@@ -407,9 +547,14 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
     if (rc == 1 && variant == 0 && cube_k4 && wp == 16) rc = launch_wgrad_mfma<MCfg<16, 2, 8>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
     if (rc == 1 && variant == 7 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 8>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
     if (rc == 1 && variant == 8 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 2, 4>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
+    const bool cube_t5 = a == 8 && b == 8 && k == 5 && stride == 2 && pad == 0 && out_mode == 0 && dp == 16 && hp == 16 &&
+                         wp == 16 && dq == 35 && hq == 35 && wq == 35;      // up2: p = X [8,16^3], q = dY [8,35^3]
+    if (rc == 1 && variant == 0 && cube_t5) rc = launch_wgrad_s2k5<TWCfg<2, 2>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
+    if (rc == 1 && variant == 7 && cube_t5) rc = launch_wgrad_s2k5<TWCfg<1, 4>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);
     NVF_W(9, 8, 4, 1, 32, 8, 32, 8, 2, 0)    // conv2 narrow, VALU form: p = dY [8,32^3], q = X [8,35^3]
     NVF_W(9, 8, 4, 1, 16, 8, 16, 8, 2, 0)    // conv1 narrow, VALU form
-    NVF_W(0, 8, 5, 2, 16, 4, 16, 4, 2, 0)    // up2 narrow: p = X [8,16^3], q = dY [8,35^3]
+    NVF_W(0, 8, 5, 2, 16, 4, 16, 4, 2, 0)    // up2 narrow, VALU form (variant 9 below selects it explicitly)
+    NVF_W(9, 8, 5, 2, 16, 4, 16, 4, 2, 0)
     NVF_W(0, 16, 5, 2, 8, 4, 8, 4, 2, 0)     // up1 narrow: p = X [16,8^3], q = dY [8,19^3]
     NVF_W(0, 8, 5, 2, 4, 4, 4, 4, 4, 0)      // conv0 narrow: p = X [8,4^3], q = dY [16,8^3]
     NVF_W(0, 16, 4, 1, 32, 8, 32, 8, 2, 0)   // conv2 wide
