@@ -166,10 +166,12 @@ def main():
 
     probe = KernelProbe()
     c3 = int(args.chanstr.split(",")[3])
-    # conv2 forward runs on the matrix cores (nvf_conv3d_k4_mfma), its backward-data on the VALU gather kernel
-    # (nvf_conv3d_gather), its weight gradient on the matrix cores (partial-sum launch of nvf_wgrad_partial)
+    # conv2 forward, backward-data (batch <= 64; VALU gather kernel above that) and weight gradient (partial-sum
+    # launch of nvf_wgrad_partial) all run on the matrix cores
     probe.wrap(ops, "conv3d_k4_mfma", "conv2_fwd",
                lambda x, wp, b, pad, pair, *a, **kw: pad == 0 and x.shape[-1] == 35 and x.shape[1] == c3)
+    probe.wrap(ops, "conv3d_k4_mfma", "conv2_bwd_data",
+               lambda x, wp, b, pad, pair, *a, **kw: pad == 3 and x.shape[-1] == 32 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_gather", "conv2_fwd",
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",

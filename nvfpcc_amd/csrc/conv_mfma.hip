@@ -142,6 +142,46 @@ struct MCv {
   static constexpr int BUF = (4 * CS + 3) / 4 * 4;
   static_assert(2 * BUF * 4 <= 160 * 1024, "two tile buffers in LDS");
   static_assert(IY < 256 && IXW < 256, "packed tile coordinates");
+  // geometry of column cc (of the workgroup) and lane j: LDS word offset of its first tap, output (y, x) offsets
+  static __device__ __forceinline__ int lds_off(int cc, int j) {
+    return ((cc / RX) * CTY + j / CTX) * RS + ((cc % RX) * CTX + j % CTX) * XS;
+  }
+  static __device__ __forceinline__ bool out_yx(int cc, int j, int& oy, int& ox) {
+    oy = (cc / RX) * CTY + j / CTX;
+    ox = ((cc % RX) * CTX + j % CTX) * XS;
+    return true;
+  }
+};
+
+// Pair axis x with FLATTENED columns, for outputs whose rows are not a multiple of 16 cells (conv2's backward-data:
+// 35 wide = 18 cells): the input is the zero-padded gradient, staged with an LDS row stride of exactly 2 * CPR
+// words, so that a row's last taps fall on the next row's (zero) left margin and
+//     address(cell p = y * CPR + m, ty, tx) = 2 p + ty * RS + tx
+// is linear in p: any 16 consecutive cells of the RY-row region are one column tile, no padding columns.
+template <int CIN_, int CPR_, int RY_, int NWC_, int NWZ_, int NT_>
+struct MCvFlat {
+  static constexpr int CIN = CIN_, PAIR = 0, CPR = CPR_, RY = RY_, NT = NT_;
+  static constexpr int NWC = NWC_, NWZ = NWZ_, NW = NWC_ * NWZ_;
+  static constexpr int NCOLS = (RY * CPR + 15) / 16;
+  static_assert(NCOLS % NWC == 0 && CIN % 4 == 0, "columns split evenly over the waves");
+  static constexpr int NC = NCOLS / NWC;
+  static constexpr int XS = 2, ZS = 1, KEZ = 4, KEY = 4, KEX = 5;
+  static constexpr int NA = (CIN / 4) * KEY * KEX * KEZ;
+  static constexpr int OZ = NWZ * NT, OY = RY, OX = 2 * CPR;
+  // (one extra staged row: the last tap row's overrun must land on staged zeros as well)
+  static constexpr int IZW = NT + 3, IZ = NWZ * NT + 3, IY = RY + 4, IXW = 2 * CPR, RS = 2 * CPR;
+  static constexpr int PS = IY * RS;
+  static constexpr int CS = (IZ * PS + 64) | 1;          // slack: the unused cells of the last column tile read on
+  static constexpr int BUF = (4 * CS + 3) / 4 * 4;
+  static_assert(2 * BUF * 4 <= 160 * 1024, "two tile buffers in LDS");
+  static_assert(IY < 256 && IXW < 256, "packed tile coordinates");
+  static __device__ __forceinline__ int lds_off(int cc, int j) { return 2 * (16 * cc + j); }
+  static __device__ __forceinline__ bool out_yx(int cc, int j, int& oy, int& ox) {
+    const int p = 16 * cc + j;
+    oy = p / CPR;
+    ox = 2 * (p % CPR);
+    return p < RY * CPR;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -227,8 +267,8 @@ __device__ __forceinline__ void mfma_step(const float* ldsb, const int (&colbase
 template <class C, int EPI>
 __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], const float* __restrict__ bias,
                                            float* __restrict__ y, const float* __restrict__ addend,
-                                           const float* __restrict__ mask, const MDims& d, int b, int ozw, int oyl,
-                                           int oxl, int wc, int kq) {
+                                           const float* __restrict__ mask, const MDims& d, int b, int ozw, int oy0,
+                                           int ox0, int j, int wc, int kq) {
   const size_t cstride = (size_t)d.dout * d.hout * d.wout;
   const size_t base = ((size_t)b * 8 + 2 * kq) * cstride;
   float bv[2] = {0.f, 0.f};
@@ -236,8 +276,10 @@ __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], con
 #pragma unroll
   for (int c = 0; c < C::NC; ++c) {
     const int cc = wc * C::NC + c;
-    const int oy = oyl + (cc / C::RX) * C::CTY;
-    const int ox = oxl + (cc % C::RX) * C::CTX * C::XS;
+    int oy, ox;
+    if (!C::out_yx(cc, j, oy, ox)) continue;
+    oy += oy0;
+    ox += ox0;
     if (oy >= d.hout || ox >= d.wout) continue;
 #pragma unroll
     for (int q = 0; q < C::NT; ++q) {
@@ -300,14 +342,13 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
   if (t >= t_hi) return;
   const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
   const int j = lane & 15, kq = lane >> 4;
-  const int cyj = j / C::CTX, cxj = j % C::CTX;
-  const int laneB = kq * CS + cyj * RS + cxj * C::XS;
+  const int laneB = kq * CS;
   int colbase[NC];
   const int wc = wave % C::NWC, wz = wave / C::NWC;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int cc = wc * NC + c;
-    colbase[c] = laneB + wz * NT * ZS * C::PS + (cc / C::RX) * C::CTY * RS + (cc % C::RX) * C::CTX * C::XS;
+    colbase[c] = laneB + wz * NT * ZS * C::PS + C::lds_off(cc, j);
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   const size_t vol = (size_t)d.din * d.hin * d.win;
@@ -355,7 +396,7 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
       if (g == 2) mfma_step<C, (NG > 2 ? 2 : 0)>(lds + (g & 1) * BUF, colbase, A, acc);
       if (g == 3) mfma_step<C, (NG > 3 ? 3 : 0)>(lds + (g & 1) * BUF, colbase, A, acc);
     }
-    mfma_store<C, EPI>(acc, bias, y, addend, mask, d, b, oz0 + ZS * wz * NT, oy0 + cyj, ox0 + cxj * C::XS, wc, kq);
+    mfma_store<C, EPI>(acc, bias, y, addend, mask, d, b, oz0 + ZS * wz * NT, oy0, ox0, j, wc, kq);
     if (!more) break;
     t = tn; b = bn; oz0 = ozn; oy0 = oyn; ox0 = oxn;
   }
@@ -425,6 +466,17 @@ extern "C" int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* 
   NVF_M(2, 8, 2, 9, 20, 4, 4, 5, 1, 1, 2, 1)
   NVF_M(3, 8, 2, 9, 20, 4, 4, 5, 5, 5, 1, 1)
 #undef NVF_M
+#define NVF_MF(VAR, CI, WLO, WHI, CPR, RY, NWC, NWZ, NT)                                               \
+  if (rc == 1 && variant == VAR && cin == CI && pair_axis == 0 && pad == 3 && wout >= WLO && wout <= WHI) \
+    rc = launch_mfma<MCvFlat<CI, CPR, RY, NWC, NWZ, NT>>(x, wp, bias, y, addend, mask, batch, d, s);
+  // backward-data with pair axis x and flattened columns (weights packed with pair_axis 0 from w_bwd)
+  NVF_MF(0, 8, 33, 36, 18, 7, 4, 2, 2)     // conv2 backward-data: 7 rows x 4 planes x 36 = 8 column tiles, 8 waves
+  NVF_MF(2, 8, 33, 36, 18, 7, 4, 1, 7)
+  NVF_MF(3, 8, 33, 36, 18, 7, 8, 1, 4)
+  NVF_MF(4, 8, 33, 36, 18, 7, 4, 1, 4)
+  NVF_MF(0, 8, 17, 20, 10, 8, 5, 1, 4)     // conv1 backward-data: 19 wide = 10 cells; 8 rows = 5 column tiles
+  NVF_MF(2, 8, 17, 20, 10, 8, 5, 1, 2)
+#undef NVF_MF
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();
   return rc;

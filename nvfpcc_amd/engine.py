@@ -28,7 +28,8 @@ from .network import NoiseState
 R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
 TRUNK = ("up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls")
 HEADS = ("conv1_cls", "conv0_cls")
-MFMA_BWD = ("conv1",)      # layers whose backward-data also runs on the matrix cores (conv2's is faster on the VALU)
+# layers whose backward-data also runs on the matrix cores: name -> (pair axis, largest batch it is used for)
+MFMA_BWD = {"conv1": (2, 1 << 30), "conv2": (0, 64)}
 
 _DESC = np.dtype([("kernel", "<u8"), ("kernel_init", "<u8"), ("b", "<u8"), ("b_init", "<u8"), ("w_fwd", "<u8"),
                   ("w_bwd", "<u8"), ("b_eff", "<u8"), ("dim0", "<i4"), ("dim1", "<i4"), ("k3", "<i4"),
@@ -45,7 +46,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t", "wp_s")
+                 "wp_b", "wp_t", "wp_s", "bwd_pair", "bwd_max_batch")
 
 
 class TrainEngine:
@@ -132,6 +133,7 @@ class TrainEngine:
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
             L.wp_f = L.wp_b = L.wp_t = L.wp_s = None
+            L.bwd_pair, L.bwd_max_batch = 2, 0
             if L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
                 # stride-2 gather convolution with cin output channels)
@@ -142,7 +144,10 @@ class TrainEngine:
                 # matrix-core form of the 4^3 convolutions: MFMA A-fragments, re-packed after every weight preparation
                 L.wp_f = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cin, 0)), device=self.dev)
                 if name in MFMA_BWD:
-                    L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, 2)), device=self.dev)
+                    # backward-data mapping: rows pair outputs along z with 4x4 patches (conv1) or along x with
+                    # flattened 18-cell rows (conv2; faster than the VALU kernel only while the batch is small)
+                    L.bwd_pair, L.bwd_max_batch = MFMA_BWD[name]
+                    L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, L.bwd_pair)), device=self.dev)
             self.layers[name] = L
             t = table[i]
             t["kernel"], t["kernel_init"] = m.kernel.data_ptr(), m.kernel_init.data_ptr()
@@ -154,7 +159,7 @@ class TrainEngine:
             t["layer_id"] = m.layer_id
             t["nbias"] = m.b.numel()
         jobs = [(L.w_fwd, L.wp_f, 0, L.cin, 8) for L in self.layers.values() if L.wp_f is not None]
-        jobs += [(L.w_bwd, L.wp_b, 2, L.cout, 8) for L in self.layers.values() if L.wp_b is not None]
+        jobs += [(L.w_bwd, L.wp_b, L.bwd_pair, L.cout, 8) for L in self.layers.values() if L.wp_b is not None]
         jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for L in self.layers.values() if L.wp_t is not None]
         jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for L in self.layers.values() if L.wp_s is not None]
         self._mfma_jobs = jobs
@@ -236,8 +241,8 @@ class TrainEngine:
         self._bias_jobs.append((g_out, L.gb))
 
     def _dx_conv(self, L, g_out, x_in, mask=None, addend=None):
-        if L.wp_b is not None:
-            return ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, 2, NONE, addend=addend, mask=mask)
+        if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
+            return ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, addend=addend, mask=mask)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
                                  addend=addend, mask=mask)
 

@@ -158,6 +158,12 @@ def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
     assert rel_err(dx2, (x.grad + add) * (mask > 0)) < 1e-5
     dx3 = ops.conv3d_k4_mfma(dev(gy), wpb, None, 3, 2, ops.ACT_NONE)
     assert rel_err(dx3, x.grad) < 1e-5
+    # the x-pair mapping with flattened 18- / 10-cell rows (weights packed with pair axis 0 from w_bwd)
+    wpbx = ops.pack_mfma_k4(wb, 8, 0)
+    dx4 = ops.conv3d_k4_mfma(dev(gy), wpbx, None, 3, 0, ops.ACT_NONE, mask=dev(mask))
+    assert rel_err(dx4, x.grad * (mask > 0)) < 1e-5
+    dx5 = ops.conv3d_k4_mfma(dev(gy), wpbx, None, 3, 0, ops.ACT_NONE, addend=dev(add))
+    assert rel_err(dx5, x.grad + add) < 1e-5
     # the multi-pack launch produces the same fragments
     wpf2, wpb2 = torch.empty_like(wpf), torch.empty_like(wpb)
     ops.pack_mfma_k4_multi([(wf, 8, 0, wpf2), (wb, 8, 2, wpb2)])

@@ -35,7 +35,7 @@ def main():
     dev = torch.device("cuda")
     torch.manual_seed(0)
     for name, n, pad, pair in (("conv2.fwd", 35, 0, 0), ("conv1.fwd", 19, 0, 0), ("conv2.bwd_data", 32, 3, 2),
-                               ("conv1.bwd_data", 16, 3, 2)):
+                               ("conv1.bwd_data", 16, 3, 2), ("conv2.bwd_flat", 32, 3, 0), ("conv1.bwd_flat", 16, 3, 0)):
         no = n + 2 * pad - 3
         x = torch.randn(B, 8, n, n, n, device=dev)
         w = torch.randn(8, 8, 4, 4, 4, device=dev) * 0.05
