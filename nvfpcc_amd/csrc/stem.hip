@@ -86,18 +86,23 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
   __syncthreads();
   const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
   {  // up0: a0[co = c, o] = b0 + sum_ci sum_{k : o + 2 - k = 2 i} x0[ci, i] w0[ci][k][co]
+    // per axis the valid taps are k = o (input i = 1) and k = o + 2 (i = 0, if o <= 2): ascending k, the order of
+    // the per-layer kernel, without walking the 125 taps
     float acc = 0.f;
     for (int ci = 0; ci < ch; ++ci)
-      for (int kz = 0; kz < 5; ++kz) {
-        const int uz = oz + 2 - kz;
-        if (uz < 0 || (uz & 1) || (uz >> 1) >= 2) continue;
-        for (int ky = 0; ky < 5; ++ky) {
-          const int uy = oy + 2 - ky;
-          if (uy < 0 || (uy & 1) || (uy >> 1) >= 2) continue;
-          for (int kx = 0; kx < 5; ++kx) {
-            const int ux = ox + 2 - kx;
-            if (ux < 0 || (ux & 1) || (ux >> 1) >= 2) continue;
-            acc = fmaf(s_x[ci * 8 + (uz >> 1) * 4 + (uy >> 1) * 2 + (ux >> 1)],
+#pragma unroll
+      for (int az = 0; az < 2; ++az) {
+        const int kz = oz + 2 * az;
+        if (kz > 4) continue;
+#pragma unroll
+        for (int ay = 0; ay < 2; ++ay) {
+          const int ky = oy + 2 * ay;
+          if (ky > 4) continue;
+#pragma unroll
+          for (int ax = 0; ax < 2; ++ax) {
+            const int kx = ox + 2 * ax;
+            if (kx > 4) continue;
+            acc = fmaf(s_x[ci * 8 + (1 - az) * 4 + (1 - ay) * 2 + (1 - ax)],
                        s_w0[(ci * 125 + (kz * 5 + ky) * 5 + kx) * C0 + c], acc);
           }
         }
