@@ -128,6 +128,19 @@ int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, const float
 int nvf_pack_mfma_all(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s, const int* c1s,
                       int n, void* stream);
 
+/* ---- the three classifier heads of the narrow decoder in one launch each (conv0_cls on [16, 8^3], conv1_cls on
+ * [8, 16^3], conv2_cls on [8, 32^3], in that order; IConv3d/QConv3d C -> 1, k 3, padding 1, network.py:4761-4768).
+ * Same kernels, same results as three nvf_conv3d_gather / nvf_wgrad calls; the two small heads, latency-bound on a
+ * few CUs, run beside the big one.  NVF_EINVAL for any other (channels, size) triple. */
+int nvf_heads3_fwd(const float* const* xs, const float* const* w_fwds, const float* const* biases, float* const* ps,
+                   const int* cs, const int* ss, int batch, int act, void* stream);
+int nvf_heads3_bwd_data(const float* const* dlogits, const float* const* w_bwds, float* const* dxs,
+                        const float* const* masks, const int* cs, const int* ss, int batch, void* stream);
+/* partial sums only: slabs[h] receives nslabs[h] (<= max_slabs) slabs of cs[h] * 27 floats, to be added by
+ * nvf_wgrad_reduce_multi */
+int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs, float* const* slabs, const int* cs,
+                             const int* ss, int batch, int max_slabs, int* nslabs, void* stream);
+
 /* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when

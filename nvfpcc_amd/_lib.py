@@ -37,6 +37,9 @@ PROTOTYPES = {
     "nvf_pack_s2k5_mfma": (I, [P, I, I, P, P]),
     "nvf_conv3d_s2k5_mfma": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "nvf_pack_mfma_all": (I, [P, P, P, P, P, I, P]),
+    "nvf_heads3_fwd": (I, [P, P, P, P, P, P, I, I, P]),
+    "nvf_heads3_bwd_data": (I, [P, P, P, P, P, P, I, P]),
+    "nvf_heads3_wgrad_partial": (I, [P, P, P, P, P, I, I, P, P]),
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "nvf_stem_bwd_workspace": (Z, [I, I]),
     "nvf_stem_bwd": (I, [P] * 13 + [Z, I, I, I, I, P]),

@@ -58,16 +58,19 @@ __device__ __forceinline__ void head_stage(const float* __restrict__ xb, float* 
 
 // ---- forward: p = act(bias + sum_{c,k} x[c, o + k - 1] w[c][k]) -----------------------------------------------
 template <class H>
-__global__ __launch_bounds__(H::NT) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
-                                                         const float* __restrict__ addend,
-                                                         const float* __restrict__ mask, int act) {
+struct HFwdSmem { static constexpr int WORDS = H::C * H::IZ * H::IY * H::RS + H::C * 9 * 4; };
+
+template <class H>
+__device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
+                                              const float* __restrict__ bias, float* __restrict__ y,
+                                              const float* __restrict__ addend, const float* __restrict__ mask, int act,
+                                              int bid, float* smem) {
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT;
-  __shared__ __attribute__((aligned(16))) float xs[C * IZ * IY * RS];
-  __shared__ __attribute__((aligned(16))) float ws[C * 9 * 4];
+  float* xs = smem;
+  float* ws = smem + C * IZ * IY * RS;
   const int tid = threadIdx.x;
   constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
-  const int tile = blockIdx.x % (TILES_Y * TILES_Z), b = blockIdx.x / (TILES_Y * TILES_Z);
+  const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
   for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
   head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
@@ -108,18 +111,30 @@ __global__ __launch_bounds__(H::NT) void head_fwd_kernel(const float* __restrict
   *(float4*)(y + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+template <class H>
+__global__ __launch_bounds__(H::NT) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ addend,
+                                                         const float* __restrict__ mask, int act) {
+  __shared__ __attribute__((aligned(16))) float smem[HFwdSmem<H>::WORDS];
+  head_fwd_body<H>(x, w, bias, y, addend, mask, act, blockIdx.x, smem);
+}
+
 // ---- backward-data: dx[c, i] = sum_k' dl[i - 1 + k'] wb[k'][c]  (wb = w_bwd: taps flipped) ---------------------
 template <class H>
-__global__ __launch_bounds__(H::NT) void head_bwd_data_kernel(const float* __restrict__ dl, const float* __restrict__ wb,
-                                                              const float* __restrict__ bias, float* __restrict__ dx,
-                                                              const float* __restrict__ addend,
-                                                              const float* __restrict__ mask, int act) {
+struct HBwdSmem { static constexpr int WORDS = (H::IZ * H::IY * H::RS + 3) / 4 * 4 + 27 * H::C; };
+
+template <class H>
+__device__ __forceinline__ void head_bwd_data_body(const float* __restrict__ dl, const float* __restrict__ wb,
+                                                   const float* __restrict__ bias, float* __restrict__ dx,
+                                                   const float* __restrict__ addend, const float* __restrict__ mask,
+                                                   int act, int bid, float* smem) {
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT;
-  __shared__ __attribute__((aligned(16))) float ds[IZ * IY * RS];
-  __shared__ __attribute__((aligned(16))) float ws[27 * C];
+  float* ds = smem;
+  float* ws = smem + (IZ * IY * RS + 3) / 4 * 4;
   const int tid = threadIdx.x;
   constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
-  const int tile = blockIdx.x % (TILES_Y * TILES_Z), b = blockIdx.x / (TILES_Y * TILES_Z);
+  const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
   for (int i = tid; i < 27 * C; i += NT) ws[i] = wb[i];
   head_stage<1, S, IZ, IY, RS, NT>(dl + (size_t)b * S * S * S, ds, tid, z0, y0);
@@ -173,6 +188,15 @@ __global__ __launch_bounds__(H::NT) void head_bwd_data_kernel(const float* __res
   }
 }
 
+template <class H>
+__global__ __launch_bounds__(H::NT) void head_bwd_data_kernel(const float* __restrict__ dl, const float* __restrict__ wb,
+                                                              const float* __restrict__ bias, float* __restrict__ dx,
+                                                              const float* __restrict__ addend,
+                                                              const float* __restrict__ mask, int act) {
+  __shared__ __attribute__((aligned(16))) float smem[HBwdSmem<H>::WORDS];
+  head_bwd_data_body<H>(dl, wb, bias, dx, addend, mask, act, blockIdx.x, smem);
+}
+
 // ---- weight gradient: dw[c][k] = sum_{b,i} dl[b,i] x[b,c,i + k - 1] -------------------------------------------
 // lane = (row of the tile, float4 group along x): every LDS access of a wave is a run of consecutive float4s, and a
 // lane keeps the 27 tap sums of one channel for its four x positions; a wave takes C / 4 channels in turn and adds
@@ -189,13 +213,17 @@ struct HWCfg {
 };
 
 template <class H>
-__global__ __launch_bounds__(H::NT) void head_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ x,
-                                                           float* __restrict__ slabs, int items, int items_per_wg) {
+struct HWSmem { static constexpr int WORDS = H::CW * H::IZ * H::IY * H::RS + H::TZ * H::TY * H::S; };
+
+template <class H>
+__device__ __forceinline__ void head_wgrad_body(const float* __restrict__ dl, const float* __restrict__ x,
+                                                float* __restrict__ slabs, int items, int items_per_wg, int bx, int by,
+                                                float* smem) {
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT,
                 RPW = H::RPW, CPW = H::CPW, CW = H::CW;
-  __shared__ __attribute__((aligned(16))) float xs[CW * IZ * IY * RS];
-  const int cg0 = blockIdx.y * CW;                     // first channel of this workgroup
-  __shared__ __attribute__((aligned(16))) float dls[TZ * TY * S];
+  float* xs = smem;
+  const int cg0 = by * CW;                             // first channel of this workgroup
+  float* dls = smem + CW * IZ * IY * RS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xq = lane % XG, rl = lane / XG;
@@ -205,7 +233,7 @@ __global__ __launch_bounds__(H::NT) void head_wgrad_kernel(const float* __restri
   for (int cc = 0; cc < CPW; ++cc)
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[cc][t] = 0.f;
-  const int first = blockIdx.x * items_per_wg, last = min(first + items_per_wg, items);
+  const int first = bx * items_per_wg, last = min(first + items_per_wg, items);
 #pragma unroll 1
   for (int item = first; item < last; ++item) {
     const int tile = item % TILES, b = item / TILES;
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(H::NT) void head_wgrad_kernel(const float* __restri
       }
     }
   }
-  float* slab = slabs + (size_t)blockIdx.x * (C * 27);
+  float* slab = slabs + (size_t)bx * (C * 27);
 #pragma unroll
   for (int cc = 0; cc < CPW; ++cc)
 #pragma unroll
@@ -249,6 +277,65 @@ __global__ __launch_bounds__(H::NT) void head_wgrad_kernel(const float* __restri
       const float sum = nvf_wave_sum(acc[cc][t]);
       if (lane == 0) slab[(cg0 + wave * CPW + cc) * 27 + t] = sum;
     }
+}
+
+template <class H>
+__global__ __launch_bounds__(H::NT) void head_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                           float* __restrict__ slabs, int items, int items_per_wg) {
+  __shared__ __attribute__((aligned(16))) float smem[HWSmem<H>::WORDS];
+  head_wgrad_body<H>(dl, x, slabs, items, items_per_wg, blockIdx.x, blockIdx.y, smem);
+}
+
+// ---- the three heads of the narrow decoder in ONE launch each (forward / backward-data / weight gradient): the two
+// small heads are latency-bound on a handful of CUs; beside the big one they cost nothing.  Workgroups
+// [0, n0) run head 0, [n0, n0 + n1) head 1, the rest head 2; same bodies, so results are identical.
+struct Heads3 {
+  const float* a[3];      // x      | dlogit | dlogit
+  const float* w[3];      // w_fwd  | w_bwd  | x
+  const float* bias[3];
+  float* out[3];          // p      | dx     | slabs
+  const float* mask[3];
+  int32_t n[3];           // workgroups (x dimension) per head
+  int32_t items[3], per[3];
+  int32_t act;
+};
+constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+template <class H0, class H1, class H2>
+__global__ __launch_bounds__(256) void heads3_fwd_kernel(Heads3 m) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax3(HFwdSmem<H0>::WORDS, HFwdSmem<H1>::WORDS, HFwdSmem<H2>::WORDS)];
+  const int bid = blockIdx.x;
+  if (bid < m.n[0]) head_fwd_body<H0>(m.a[0], m.w[0], m.bias[0], m.out[0], nullptr, nullptr, m.act, bid, smem);
+  else if (bid < m.n[0] + m.n[1])
+    head_fwd_body<H1>(m.a[1], m.w[1], m.bias[1], m.out[1], nullptr, nullptr, m.act, bid - m.n[0], smem);
+  else head_fwd_body<H2>(m.a[2], m.w[2], m.bias[2], m.out[2], nullptr, nullptr, m.act, bid - m.n[0] - m.n[1], smem);
+}
+
+template <class H0, class H1, class H2>
+__global__ __launch_bounds__(256) void heads3_bwd_data_kernel(Heads3 m) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax3(HBwdSmem<H0>::WORDS, HBwdSmem<H1>::WORDS, HBwdSmem<H2>::WORDS)];
+  const int bid = blockIdx.x;
+  if (bid < m.n[0]) head_bwd_data_body<H0>(m.a[0], m.w[0], nullptr, m.out[0], nullptr, m.mask[0], 0, bid, smem);
+  else if (bid < m.n[0] + m.n[1])
+    head_bwd_data_body<H1>(m.a[1], m.w[1], nullptr, m.out[1], nullptr, m.mask[1], 0, bid - m.n[0], smem);
+  else head_bwd_data_body<H2>(m.a[2], m.w[2], nullptr, m.out[2], nullptr, m.mask[2], 0, bid - m.n[0] - m.n[1], smem);
+}
+
+template <class H0, class H1, class H2>
+__global__ __launch_bounds__(256) void heads3_wgrad_kernel(Heads3 m) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax3(HWSmem<H0>::WORDS, HWSmem<H1>::WORDS, HWSmem<H2>::WORDS)];
+  int bid = blockIdx.x;                               // head h owns n[h] * CSPLIT_h workgroups: (slab, channel group)
+  if (bid < m.n[0] * H0::CSPLIT) {
+    head_wgrad_body<H0>(m.a[0], m.w[0], m.out[0], m.items[0], m.per[0], bid % m.n[0], bid / m.n[0], smem);
+    return;
+  }
+  bid -= m.n[0] * H0::CSPLIT;
+  if (bid < m.n[1] * H1::CSPLIT) {
+    head_wgrad_body<H1>(m.a[1], m.w[1], m.out[1], m.items[1], m.per[1], bid % m.n[1], bid / m.n[1], smem);
+    return;
+  }
+  bid -= m.n[1] * H1::CSPLIT;
+  head_wgrad_body<H2>(m.a[2], m.w[2], m.out[2], m.items[2], m.per[2], bid % m.n[2], bid / m.n[2], smem);
 }
 
 }  // namespace
@@ -314,3 +401,63 @@ int nvf_head_wgrad_launch(const float* dl, const float* x, float* slabs, int max
 #undef NVF_H
   return 1;
 }
+
+// ---- three-head launches (narrow decoder: conv0_cls on [16, 8^3], conv1_cls on [8, 16^3], conv2_cls on [8, 32^3]) ----
+extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, const float* const* biases,
+                              float* const* ps, const int* cs, const int* ss, int batch, int act, void* stream) {
+  if (!xs || !ws || !biases || !ps || !cs || !ss || batch <= 0) return NVF_EINVAL;
+  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
+  using H0 = HCfg<16, 8, 4, 8>; using H1 = HCfg<8, 16, 4, 4>; using H2 = HCfg<8, 32, 4, 8>;
+  Heads3 m{};
+  for (int h = 0; h < 3; ++h) {
+    if (!xs[h] || !ws[h] || !ps[h]) return NVF_EINVAL;
+    m.a[h] = xs[h]; m.w[h] = ws[h]; m.bias[h] = biases[h]; m.out[h] = ps[h];
+  }
+  m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
+  m.act = act;
+  heads3_fwd_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// dxs[h] = backward-data of head h from dls[h] with w_bwd wbs[h]; masks[h] (may be NULL) is the ReLU mask
+extern "C" int nvf_heads3_bwd_data(const float* const* dls, const float* const* wbs, float* const* dxs,
+                                   const float* const* masks, const int* cs, const int* ss, int batch, void* stream) {
+  if (!dls || !wbs || !dxs || !masks || !cs || !ss || batch <= 0) return NVF_EINVAL;
+  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
+  using H0 = HCfg<16, 8, 4, 8>; using H1 = HCfg<8, 16, 4, 4>; using H2 = HCfg<8, 32, 4, 8>;
+  Heads3 m{};
+  for (int h = 0; h < 3; ++h) {
+    if (!dls[h] || !wbs[h] || !dxs[h]) return NVF_EINVAL;
+    m.a[h] = dls[h]; m.w[h] = wbs[h]; m.out[h] = dxs[h]; m.mask[h] = masks[h];
+  }
+  m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
+  heads3_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)
+extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* const* xs, float* const* slabs,
+                                        const int* cs, const int* ss, int batch, int max_slabs, int* nslabs,
+                                        void* stream) {
+  if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
+  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
+  using H0 = HWCfg<16, 8, 4, 8, 4>; using H1 = HWCfg<8, 16, 4, 4, 2>; using H2 = HWCfg<8, 32, 2, 8, 2>;
+  Heads3 m{};
+  const int items[3] = {batch * (8 / 4) * (8 / 8), batch * (16 / 4) * (16 / 4), batch * (32 / 2) * (32 / 8)};
+  for (int h = 0; h < 3; ++h) {
+    if (!dls[h] || !xs[h] || !slabs[h]) return NVF_EINVAL;
+    m.a[h] = dls[h]; m.w[h] = xs[h]; m.out[h] = slabs[h];
+    int n = items[h] < max_slabs ? items[h] : max_slabs;
+    const int per = (items[h] + n - 1) / n;
+    n = (items[h] + per - 1) / per;
+    m.n[h] = n; m.items[h] = items[h]; m.per[h] = per;
+    nslabs[h] = n;
+  }
+  const int grid = m.n[0] * H0::CSPLIT + m.n[1] * H1::CSPLIT + m.n[2] * H2::CSPLIT;
+  heads3_wgrad_kernel<H0, H1, H2><<<grid, 256, 0, nvf_stream(stream)>>>(m);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+

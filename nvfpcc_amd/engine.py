@@ -92,6 +92,8 @@ class TrainEngine:
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
         self._wg = None
+        # the three classifier heads of the narrow decoder go through the one-launch kernels
+        self.heads3 = tuple(net.reconstructor.channels) == (8, 16, 8, 8)
 
     # ------------------------------------------------------------------ parameters
     def _flatten_parameters(self):
@@ -208,17 +210,24 @@ class TrainEngine:
             a["a0"] = self._convT(Ls["up0"], a["x0"], NONE)
             a["h0"] = ops.gdn_fwd(a["a0"], ig.beta, ig.gamma, True)
             a["y1"] = self._convT(Ls["conv0"], a["h0"], R)
-        self._fork()
-        with self._on_side():                       # the two coarse heads run beside the trunk
-            a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
+        if not self.heads3:
+            self._fork()
+            with self._on_side():                   # the two coarse heads run beside the trunk
+                a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
         a["y2"] = self._convT(Ls["up1"], a["y1"], R)
         a["y3"] = self._conv(Ls["conv1"], a["y2"], R)
-        self._fork()
-        with self._on_side():
-            a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
+        if not self.heads3:
+            self._fork()
+            with self._on_side():
+                a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
         a["y4"] = self._convT(Ls["up2"], a["y3"], R)
         a["y5"] = self._conv(Ls["conv2"], a["y4"], R)
-        a["p2"] = self._conv(Ls["conv2_cls"], a["y5"], S)
+        if self.heads3:                             # all three heads in one launch, after the trunk
+            hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
+            a["p0"], a["p1"], a["p2"] = ops.heads3_fwd([a["y1"], a["y3"], a["y5"]], [L.w_fwd for L in hl],
+                                                       [L.b_eff for L in hl])
+        else:
+            a["p2"] = self._conv(Ls["conv2_cls"], a["y5"], S)
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.side)
         return a
@@ -268,20 +277,28 @@ class TrainEngine:
         dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
                                               (a["p1"], gt16, None, 0.85, 0.0)], loss)
         ev_t1 = ev_t0 = None
-        self._fork()
-        with self._on_side():
-            t1 = self._dx_conv(Ls["conv1_cls"], dl1, a["y3"])
-            ev_t1 = torch.cuda.Event() if self.overlap else None
-            if ev_t1 is not None:
-                ev_t1.record()
-            t0 = self._dx_conv(Ls["conv0_cls"], dl0, a["y1"])
-            ev_t0 = torch.cuda.Event() if self.overlap else None
-            if ev_t0 is not None:
-                ev_t0.record()
+        if self.heads3:
+            hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
+            t0, t1, g5 = ops.heads3_bwd_data([dl0, dl1, dl2], [L.w_bwd for L in hl], [L.cin for L in hl],
+                                             [None, None, a["y5"]])
             if want_w:
-                self._wgrad_conv(Ls["conv2_cls"], dl2, a["y5"])
-                self._wgrad_conv(Ls["conv1_cls"], dl1, a["y3"])
-                self._wgrad_conv(Ls["conv0_cls"], dl0, a["y1"])
+                self._wg.add_heads3([dl0, dl1, dl2], [a["y1"], a["y3"], a["y5"]], [L.gk for L in hl])
+                self._bias_jobs += [(dl2, hl[2].gb), (dl1, hl[1].gb), (dl0, hl[0].gb)]
+        else:
+            self._fork()
+            with self._on_side():
+                t1 = self._dx_conv(Ls["conv1_cls"], dl1, a["y3"])
+                ev_t1 = torch.cuda.Event() if self.overlap else None
+                if ev_t1 is not None:
+                    ev_t1.record()
+                t0 = self._dx_conv(Ls["conv0_cls"], dl0, a["y1"])
+                ev_t0 = torch.cuda.Event() if self.overlap else None
+                if ev_t0 is not None:
+                    ev_t0.record()
+                if want_w:
+                    self._wgrad_conv(Ls["conv2_cls"], dl2, a["y5"])
+                    self._wgrad_conv(Ls["conv1_cls"], dl1, a["y3"])
+                    self._wgrad_conv(Ls["conv0_cls"], dl0, a["y1"])
 
         def side_wgrad(fn, L, g, x):
             if not want_w:
@@ -290,7 +307,8 @@ class TrainEngine:
             with self._on_side():
                 fn(L, g, x)
 
-        g5 = self._dx_conv(Ls["conv2_cls"], dl2, a["y5"], mask=a["y5"])
+        if not self.heads3:
+            g5 = self._dx_conv(Ls["conv2_cls"], dl2, a["y5"], mask=a["y5"])
         side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
         g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])
         side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"])

@@ -276,6 +276,36 @@ def wgrad(p, q, k, stride, pad, out_mode=0, out=None, accumulate=False):
     return dw
 
 
+def _parr(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def _iarr(vs):
+    import ctypes
+    return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
+
+
+def heads3_fwd(xs, w_fwds, biases, act=ACT_SIGMOID):
+    """The three classifier heads (inputs [B,16,8^3], [B,8,16^3], [B,8,32^3]) in one launch: returns [p0, p1, p2]."""
+    _f32(*xs, *w_fwds, *biases)
+    B = xs[0].shape[0]
+    ps = [torch.empty((B, 1) + tuple(x.shape[2:]), device=x.device) for x in xs]
+    check(lib().nvf_heads3_fwd(_parr(xs), _parr(w_fwds), _parr(biases), _parr(ps), _iarr([x.shape[1] for x in xs]),
+                               _iarr([x.shape[-1] for x in xs]), B, act, _stream()), "nvf_heads3_fwd")
+    return ps
+
+
+def heads3_bwd_data(dls, w_bwds, cs, masks):
+    """Backward-data of the three heads in one launch: returns [dx0, dx1, dx2] (masks[h] = ReLU mask or None)."""
+    _f32(*dls, *w_bwds, *[m for m in masks if m is not None])
+    B = dls[0].shape[0]
+    dxs = [torch.empty((B, c) + tuple(d.shape[2:]), device=d.device) for d, c in zip(dls, cs)]
+    check(lib().nvf_heads3_bwd_data(_parr(dls), _parr(w_bwds), _parr(dxs), _parr(masks), _iarr(cs),
+                                    _iarr([d.shape[-1] for d in dls]), B, _stream()), "nvf_heads3_bwd_data")
+    return dxs
+
+
 class WgradBatch:
     """Weight gradients of one backward pass with a single reduction launch: ``add`` launches only the partial
     sums (each gradient keeps its own slab region until ``finish``), ``finish`` adds all slabs in one kernel."""
@@ -303,6 +333,29 @@ class WgradBatch:
               "nvf_wgrad_partial")
         self.jobs.append((base, out.data_ptr(), nslab.value, a * b * k ** 3))
         self.offset += (nbytes + 255) // 256 * 256
+
+    def add_heads3(self, dls, xs, outs, max_slabs=512):
+        """Weight gradients of the three classifier heads: one partial-sum launch, three reduction jobs."""
+        import ctypes
+        _f32(*dls, *xs, *outs)
+        B = xs[0].shape[0]
+        cs = [x.shape[1] for x in xs]
+        sizes = [(max_slabs * c * 27 * 4 + 255) // 256 * 256 for c in cs]
+        if self.offset + sum(sizes) > self.ws.numel():
+            if self.jobs:
+                self.finish()
+            self._retired.append(self.ws)
+            self.ws = torch.empty(max(sum(sizes), 2 * self.ws.numel()), dtype=torch.uint8, device=self.device)
+        bases = []
+        for sz in sizes:
+            bases.append(self.ws.data_ptr() + self.offset)
+            self.offset += sz
+        nsl = (ctypes.c_int * 3)()
+        check(lib().nvf_heads3_wgrad_partial(_parr(dls), _parr(xs), (ctypes.c_void_p * 3)(*bases), _iarr(cs),
+                                             _iarr([x.shape[-1] for x in xs]), B, max_slabs, nsl, _stream()),
+              "nvf_heads3_wgrad_partial")
+        for h in range(3):
+            self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], cs[h] * 27))
 
     def finish(self):
         import ctypes

@@ -126,6 +126,32 @@ def test_conv_transpose_k5s2_mfma_backward_data(ops, cin, n, B):
     assert torch.equal(one[0], dx[1])
 
 
+def test_three_head_launches_equal_the_single_head_kernels(ops):
+    """nvf_heads3_* run the same kernel bodies as the per-head calls: forward, backward-data and weight gradients
+    must agree bit for bit."""
+    g = gen(7000)
+    B = 3
+    shapes = [(16, 8), (8, 16), (8, 32)]
+    xs = [dev(torch.randn(B, c, s, s, s, generator=g)) for c, s in shapes]
+    ws = [torch.randn(1, c, 3, 3, 3, generator=g) * 0.1 for c, s in shapes]
+    bs = [dev(torch.randn(1, generator=g)) for _ in shapes]
+    packed = [ops.pack_conv_weight(dev(w)) for w in ws]
+    ps = ops.heads3_fwd(xs, [p[0] for p in packed], bs)
+    for x, (wf, wb), b, p, (c, s) in zip(xs, packed, bs, ps, shapes):
+        assert torch.equal(p, ops.conv3d_gather(x, wf, b, 1, 3, 1, 1, (s, s, s), ops.ACT_SIGMOID))
+    dls = [dev(torch.randn(B, 1, s, s, s, generator=g)) for c, s in shapes]
+    masks = [None, None, xs[2]]
+    dxs = ops.heads3_bwd_data(dls, [p[1] for p in packed], [c for c, s in shapes], masks)
+    for dl, (wf, wb), dx, m, (c, s) in zip(dls, packed, dxs, masks, shapes):
+        assert torch.equal(dx, ops.conv3d_gather(dl, wb, None, c, 3, 1, 1, (s, s, s), mask=m))
+    outs = [torch.empty(1, c, 3, 3, 3, device=xs[0].device) for c, s in shapes]
+    wg = ops.WgradBatch(xs[0].device, nbytes=64 << 20)
+    wg.add_heads3(dls, xs, outs)
+    wg.finish()
+    for dl, x, o in zip(dls, xs, outs):
+        assert torch.equal(o, ops.wgrad(dl, x, 3, 1, 1, out_mode=0))
+
+
 # matrix-core (MFMA) form of the 4^3, 8 -> 8 channel convolutions: (spatial_in, batch)
 @pytest.mark.parametrize("n,B", [(35, 2), (19, 3), (35, 1), (19, 5)])
 def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
