@@ -180,6 +180,13 @@ int nvf_wgrad_partial(const float* p, const float* q, float* dw, void* workspace
 int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const int* nslabs, const int* jtotals,
                            int n, void* stream);
 
+/* the three matrix-core weight gradients of the narrow trunk in one launch (partial sums only): job 0 = conv2
+ * (p = dY [B,8,32^3], q = X [B,8,35^3]), job 1 = up2 (p = X [B,8,16^3], q = dY [B,8,35^3]), job 2 = conv1
+ * (p = dY [B,8,16^3], q = X [B,8,19^3]); slabs[j] holds 256 slabs of 4096 / 8000 / 4096 floats, nslabs[j] = number
+ * written.  Same kernels and results as three nvf_wgrad_partial calls; two workgroups share a CU. */
+int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                            int* nslabs, void* stream);
+
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */
 size_t nvf_channel_sum_workspace(int c);

@@ -183,10 +183,9 @@ struct MCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g, const float* __restrict__ x,
-                                                     float* __restrict__ slabs, WgDims d) {
+__device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, const float* __restrict__ x,
+                                                   float* __restrict__ slabs, const WgDims& d, int bx, float* lds) {
   constexpr int W = C::W, TZ = C::TZ, TY = C::TY, NG = C::NG, GRS = C::GRS, XRS = C::XRS, GCS = C::GCS, XCS = C::XCS;
-  __shared__ float lds[C::LDSF];
   float* ldsG = lds + C::GOFF;
   float* ldsX = lds + C::XOFF;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -199,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g
 
   const int WQ = W + 3;                       // q grid extent (valid conv, k = 4)
   const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
-  const int first = blockIdx.x * d.items_per_wg;
+  const int first = bx * d.items_per_wg;
   const int last = min(first + d.items_per_wg, d.items);
   // Tile staging through registers: ALL global loads of an item (dY: aligned float4 rows; X: 35- or 19-float rows,
   // element by element) are issued before any is waited for, and the next item's loads are in flight while this
@@ -303,8 +302,15 @@ __global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g
     }
     __syncthreads();
   }
-  float* slab = slabs + (size_t)blockIdx.x * 4096;
+  float* slab = slabs + (size_t)bx * 4096;
   for (int o = tid; o < 4096; o += 256) slab[o] = lds[o];
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g, const float* __restrict__ x,
+                                                     float* __restrict__ slabs, WgDims d) {
+  __shared__ float lds[C::LDSF];
+  wgrad_k4_mfma_body<C>(g, x, slabs, d, blockIdx.x, lds);
 }
 
 template <class C>
@@ -346,11 +352,10 @@ struct TWCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__ x, const float* __restrict__ g,
-                                                       float* __restrict__ slabs, WgDims d) {
+__device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x, const float* __restrict__ g,
+                                                     float* __restrict__ slabs, const WgDims& d, int bx, float* lds) {
   constexpr int W = C::W, WG = C::WG, TZ = C::TZ, TY = C::TY, GZ = C::GZ, GY = C::GY, GRS = C::GRS, XRS = C::XRS,
                 GCS = C::GCS, XCS = C::XCS, UG = C::UG, UX = C::UX;
-  __shared__ float lds[C::LDSF];
   float* ldsG = lds + C::GOFF;
   float* ldsX = lds + C::XOFF;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < NTW; ++i) { acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
-  const int first = blockIdx.x * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
+  const int first = bx * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
   float gv[UG], xv[UX];
   auto load = [&](int item) {
     const int n = item / tiles, t = item % tiles;
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
     }
   }
   // lane holds column n = (co, sB) = lane & 15 and rows m = 4 (lane >> 4) + r = (ci, sA)
-  float* slab = slabs + (size_t)blockIdx.x * 8000;
+  float* slab = slabs + (size_t)bx * 8000;
   const int co = (lane & 15) >> 1, sB = lane & 1;
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
@@ -446,6 +451,61 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
       }
     }
   }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__ x, const float* __restrict__ g,
+                                                       float* __restrict__ slabs, WgDims d) {
+  __shared__ float lds[C::LDSF];
+  wgrad_s2k5_mfma_body<C>(x, g, slabs, d, blockIdx.x, lds);
+}
+
+// The three matrix-core weight gradients of the narrow trunk (conv2, up2, conv1) in ONE launch.  Each of them keeps
+// its MFMA pipes busy about half of the time (tile staging, LDS waits); 256 VGPRs and <= 80 KB of LDS per workgroup
+// let two workgroups share a CU, so the second kernel's workgroups run in the first one's bubbles.  Same bodies, same
+// slabs, same results as three launches.
+struct WgMfma3 {
+  const float* p[3];
+  const float* q[3];
+  float* slabs[3];
+  WgDims d[3];
+  int32_t n[3];
+};
+constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+template <class C0, class T1, class C2>
+__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m) {
+  __shared__ float lds[wg_max3(C0::LDSF, T1::LDSF, C2::LDSF)];
+  int bid = blockIdx.x;
+  if (bid < m.n[0]) { wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds); return; }
+  bid -= m.n[0];
+  if (bid < m.n[1]) { wgrad_s2k5_mfma_body<T1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid, lds); return; }
+  bid -= m.n[1];
+  wgrad_k4_mfma_body<C2>(m.p[2], m.q[2], m.slabs[2], m.d[2], bid, lds);
+}
+
+// job 0: conv2 (p = dY [B,8,32^3], q = X [B,8,35^3]); job 1: up2 (p = X [B,8,16^3], q = dY [B,8,35^3]);
+// job 2: conv1 (p = dY [B,8,16^3], q = X [B,8,19^3]).  slabs[j] must hold 256 slabs of 4096 / 8000 / 4096 floats;
+// nslabs[j] receives the number written (to be added by nvf_wgrad_reduce_multi).
+extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                                       int* nslabs, void* stream) {
+  if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
+  using C0 = MCfg<32, 4, 4>; using T1 = TWCfg<2, 2>; using C2 = MCfg<16, 2, 8>;
+  WgMfma3 m{};
+  const int items[3] = {batch * (32 / 4) * (32 / 4), batch * (16 / 2) * (16 / 2), batch * (16 / 8) * (16 / 2)};
+  for (int j = 0; j < 3; ++j) {
+    if (!ps[j] || !qs[j] || !slabs[j]) return NVF_EINVAL;
+    m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j];
+    WgDims d{};
+    d.batch = batch; d.bc = 8; d.items = items[j];
+    int n = items[j] < 256 ? items[j] : 256;
+    d.items_per_wg = (items[j] + n - 1) / n;
+    n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
+    m.d[j] = d; m.n[j] = n; nslabs[j] = n;
+  }
+  wgrad_mfma3_kernel<C0, T1, C2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 template <class C>

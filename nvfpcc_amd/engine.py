@@ -26,6 +26,11 @@ from ._lib import lib, check
 from .network import NoiseState
 
 R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
+
+
+def _NAIVE_OFF():
+    """The one-launch groupings bypass the variant switch of the per-layer entry points: only with the tuned kernels."""
+    return ops._NAIVE == 0
 TRUNK = ("up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls")
 HEADS = ("conv1_cls", "conv0_cls")
 # layers whose backward-data also runs on the matrix cores: name -> (pair axis, largest batch it is used for)
@@ -309,13 +314,20 @@ class TrainEngine:
 
         if not self.heads3:
             g5 = self._dx_conv(Ls["conv2_cls"], dl2, a["y5"], mask=a["y5"])
-        side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
+        wg3 = want_w and self.heads3 and _NAIVE_OFF()      # conv2 / up2 / conv1 weight gradients in one launch
+        if not wg3:
+            side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
         g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])
-        side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"])
+        if not wg3:
+            side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"])
         if ev_t1 is not None:
             main.wait_event(ev_t1)
         g3 = self._dx_convT(Ls["up2"], g4, a["y3"], mask=a["y3"], addend=t1)
-        side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
+        if wg3:
+            self._wg.add_mfma3([g5, a["y3"], g3], [a["y4"], g4, a["y2"]], [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk])
+            self._bias_jobs += [(g5, Ls["conv2"].gb), (g4, Ls["up2"].gb), (g3, Ls["conv1"].gb)]
+        else:
+            side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
         g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
         side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"])
         if ev_t0 is not None:

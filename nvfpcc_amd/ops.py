@@ -334,6 +334,28 @@ class WgradBatch:
         self.jobs.append((base, out.data_ptr(), nslab.value, a * b * k ** 3))
         self.offset += (nbytes + 255) // 256 * 256
 
+    def add_mfma3(self, ps, qs, outs):
+        """conv2 / up2 / conv1 weight gradients of the narrow trunk: one partial-sum launch, three reduction jobs."""
+        import ctypes
+        _f32(*ps, *qs, *outs)
+        B = ps[0].shape[0]
+        jt = (4096, 8000, 4096)
+        sizes = [(256 * j * 4 + 255) // 256 * 256 for j in jt]
+        if self.offset + sum(sizes) > self.ws.numel():
+            if self.jobs:
+                self.finish()
+            self._retired.append(self.ws)
+            self.ws = torch.empty(max(sum(sizes), 2 * self.ws.numel()), dtype=torch.uint8, device=self.device)
+        bases = []
+        for sz in sizes:
+            bases.append(self.ws.data_ptr() + self.offset)
+            self.offset += sz
+        nsl = (ctypes.c_int * 3)()
+        check(lib().nvf_wgrad_mfma3_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 3)(*bases), B, nsl, _stream()),
+              "nvf_wgrad_mfma3_partial")
+        for h in range(3):
+            self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
+
     def add_heads3(self, dls, xs, outs, max_slabs=512):
         """Weight gradients of the three classifier heads: one partial-sum launch, three reduction jobs."""
         import ctypes

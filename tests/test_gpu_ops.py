@@ -152,6 +152,23 @@ def test_three_head_launches_equal_the_single_head_kernels(ops):
         assert torch.equal(o, ops.wgrad(dl, x, 3, 1, 1, out_mode=0))
 
 
+def test_three_mfma_weight_gradients_in_one_launch(ops):
+    """nvf_wgrad_mfma3_partial (conv2, up2, conv1 of the narrow trunk) equals three nvf_wgrad calls bit for bit."""
+    g = gen(7100)
+    B = 2
+    R = lambda *s: dev(torch.randn(*s, generator=g))
+    g5, y4 = R(B, 8, 32, 32, 32), R(B, 8, 35, 35, 35)
+    y3, g4 = R(B, 8, 16, 16, 16), R(B, 8, 35, 35, 35)
+    g3, y2 = R(B, 8, 16, 16, 16), R(B, 8, 19, 19, 19)
+    outs = [torch.empty(8, 8, k, k, k, device=g5.device) for k in (4, 5, 4)]
+    wg = ops.WgradBatch(g5.device, nbytes=64 << 20)
+    wg.add_mfma3([g5, y3, g3], [y4, g4, y2], outs)
+    wg.finish()
+    assert torch.equal(outs[0], ops.wgrad(g5, y4, 4, 1, 0, out_mode=0))
+    assert torch.equal(outs[1], ops.wgrad(y3, g4, 5, 2, 0, out_mode=0))
+    assert torch.equal(outs[2], ops.wgrad(g3, y2, 4, 1, 0, out_mode=0))
+
+
 # matrix-core (MFMA) form of the 4^3, 8 -> 8 channel convolutions: (spatial_in, batch)
 @pytest.mark.parametrize("n,B", [(35, 2), (19, 3), (35, 1), (19, 5)])
 def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
