@@ -304,38 +304,38 @@ constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b >
 template <class H0, class H1, class H2>
 __global__ __launch_bounds__(256) void heads3_fwd_kernel(Heads3 m) {
   __shared__ __attribute__((aligned(16))) float smem[cmax3(HFwdSmem<H0>::WORDS, HFwdSmem<H1>::WORDS, HFwdSmem<H2>::WORDS)];
-  const int bid = blockIdx.x;
-  if (bid < m.n[0]) head_fwd_body<H0>(m.a[0], m.w[0], m.bias[0], m.out[0], nullptr, nullptr, m.act, bid, smem);
-  else if (bid < m.n[0] + m.n[1])
-    head_fwd_body<H1>(m.a[1], m.w[1], m.bias[1], m.out[1], nullptr, nullptr, m.act, bid - m.n[0], smem);
-  else head_fwd_body<H2>(m.a[2], m.w[2], m.bias[2], m.out[2], nullptr, nullptr, m.act, bid - m.n[0] - m.n[1], smem);
+  const int bid = blockIdx.x;                          // the big head's workgroups first: the small ones fill the tail
+  if (bid < m.n[2]) head_fwd_body<H2>(m.a[2], m.w[2], m.bias[2], m.out[2], nullptr, nullptr, m.act, bid, smem);
+  else if (bid < m.n[2] + m.n[1])
+    head_fwd_body<H1>(m.a[1], m.w[1], m.bias[1], m.out[1], nullptr, nullptr, m.act, bid - m.n[2], smem);
+  else head_fwd_body<H0>(m.a[0], m.w[0], m.bias[0], m.out[0], nullptr, nullptr, m.act, bid - m.n[2] - m.n[1], smem);
 }
 
 template <class H0, class H1, class H2>
 __global__ __launch_bounds__(256) void heads3_bwd_data_kernel(Heads3 m) {
   __shared__ __attribute__((aligned(16))) float smem[cmax3(HBwdSmem<H0>::WORDS, HBwdSmem<H1>::WORDS, HBwdSmem<H2>::WORDS)];
   const int bid = blockIdx.x;
-  if (bid < m.n[0]) head_bwd_data_body<H0>(m.a[0], m.w[0], nullptr, m.out[0], nullptr, m.mask[0], 0, bid, smem);
-  else if (bid < m.n[0] + m.n[1])
-    head_bwd_data_body<H1>(m.a[1], m.w[1], nullptr, m.out[1], nullptr, m.mask[1], 0, bid - m.n[0], smem);
-  else head_bwd_data_body<H2>(m.a[2], m.w[2], nullptr, m.out[2], nullptr, m.mask[2], 0, bid - m.n[0] - m.n[1], smem);
+  if (bid < m.n[2]) head_bwd_data_body<H2>(m.a[2], m.w[2], nullptr, m.out[2], nullptr, m.mask[2], 0, bid, smem);
+  else if (bid < m.n[2] + m.n[1])
+    head_bwd_data_body<H1>(m.a[1], m.w[1], nullptr, m.out[1], nullptr, m.mask[1], 0, bid - m.n[2], smem);
+  else head_bwd_data_body<H0>(m.a[0], m.w[0], nullptr, m.out[0], nullptr, m.mask[0], 0, bid - m.n[2] - m.n[1], smem);
 }
 
 template <class H0, class H1, class H2>
 __global__ __launch_bounds__(256) void heads3_wgrad_kernel(Heads3 m) {
   __shared__ __attribute__((aligned(16))) float smem[cmax3(HWSmem<H0>::WORDS, HWSmem<H1>::WORDS, HWSmem<H2>::WORDS)];
   int bid = blockIdx.x;                               // head h owns n[h] * CSPLIT_h workgroups: (slab, channel group)
-  if (bid < m.n[0] * H0::CSPLIT) {
-    head_wgrad_body<H0>(m.a[0], m.w[0], m.out[0], m.items[0], m.per[0], bid % m.n[0], bid / m.n[0], smem);
+  if (bid < m.n[2] * H2::CSPLIT) {                    // the big head first
+    head_wgrad_body<H2>(m.a[2], m.w[2], m.out[2], m.items[2], m.per[2], bid % m.n[2], bid / m.n[2], smem);
     return;
   }
-  bid -= m.n[0] * H0::CSPLIT;
+  bid -= m.n[2] * H2::CSPLIT;
   if (bid < m.n[1] * H1::CSPLIT) {
     head_wgrad_body<H1>(m.a[1], m.w[1], m.out[1], m.items[1], m.per[1], bid % m.n[1], bid / m.n[1], smem);
     return;
   }
   bid -= m.n[1] * H1::CSPLIT;
-  head_wgrad_body<H2>(m.a[2], m.w[2], m.out[2], m.items[2], m.per[2], bid % m.n[2], bid / m.n[2], smem);
+  head_wgrad_body<H0>(m.a[0], m.w[0], m.out[0], m.items[0], m.per[0], bid % m.n[0], bid / m.n[0], smem);
 }
 
 }  // namespace
