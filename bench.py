@@ -178,6 +178,8 @@ def main():
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 35 and x.shape[1] == c3)
     probe.wrap(ops.WgradBatch, "add", "conv2_bwd_weight",
                lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
+    # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
+    probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -238,18 +240,19 @@ def main():
         roofline = None
         if kern_us and macs:
             single = dict(kern_us)
-            label = max(single, key=single.get)
+            label = max(single, key=single.get)      # the dominant single launch of the step
             us = single[label]
-            flops = 2.0 * macs * B
-            if label == "conv2_bwd_data":
-                flops = flops  # algorithmic MACs of the layer (the 35^3 gather form computes a halo on top)
+            # algorithmic MACs of what the launch computes (not the halo / padding lanes it also executes);
+            # the three-gradient launch: conv2 + up2 (32 768 000 MAC/block) + conv1 (16 777 216), SURVEY 2.1
+            layer_macs = {"wgrad_conv2_up2_conv1": macs + 32768000 + 16777216}
+            flops = 2.0 * layer_macs.get(label, macs) * B
             achieved = flops / (us * 1e-6) / 1e12
             traffic = None
             tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.isfile(tj):     # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/)
                 t = json.load(open(tj))
                 if t.get("batch") == B and t.get("chanstr") == args.chanstr:
-                    traffic = t["hbm_bytes_per_launch"].get(label)
+                    traffic = t["hbm_bytes_per_launch"].get({"wgrad_conv2_up2_conv1": "conv2_bwd_weight"}.get(label, label))
             roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_us": round(us, 2), "flops_per_launch": flops,

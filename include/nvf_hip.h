@@ -210,6 +210,15 @@ int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* gamma_hat, c
                 float* dbeta_hat, float* dgamma_hat, void* workspace, size_t workspace_bytes, int batch, int c,
                 int spatial, int inverse, void* stream);
 
+/* ---- latent generator + quantiser, forward, in one launch (SingleLayerLatentGen network.py:4592-4612 followed by
+ * QuantGaussianLikelihood network.py:4514-4539): h = conv1x1(e) + bias, lat = GDN(h), x_rounded = round(lat),
+ * bits[0] as nvf_latent_rate.  Same arithmetic and order as nvf_conv3d_gather(k = 1) + nvf_gdn_fwd +
+ * nvf_latent_rate (bit-identical outputs); c <= 8; w_fwd is the packed [ci][1][co] layout. */
+int nvf_latent_fwd(const float* e, const float* w_fwd, const float* bias, const float* beta_hat,
+                   const float* gamma_hat, const int64_t* block_ids, const float* sigma, const float* mu, float* h,
+                   float* lat, float* x_rounded, float* bits, int batch, int c, int spatial, int mode, uint64_t seed,
+                   uint64_t step, const uint64_t* step_dev, void* stream);
+
 /* ---- latent quantisation + Gaussian rate (network.py:4514-4539, 145-161) --------
  * x_rounded = round(x) (half-to-even); v = x + (U-.5) (mode 0 = train) or x_rounded (mode 1 = eval);
  * bits[0] = sum -log2(max(Phi((v-mu+.5)/|s|) - Phi((v-mu-.5)/|s|), 1e-8)).

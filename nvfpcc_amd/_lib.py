@@ -55,6 +55,7 @@ PROTOTYPES = {
     "nvf_gdn_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "nvf_gdn_bwd_workspace": (Z, [I]),
     "nvf_gdn_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "nvf_latent_fwd": (I, [P] * 12 + [I, I, I, I, U, U, P, P]),
     "nvf_latent_rate": (I, [P] * 12 + [F, I, I, I, I, U, U, P, P]),
     "nvf_weight_rate": (I, [P, I, P, P, P, P, P, P, P, F, I, P]),
     "nvf_weight_rate_batch_workspace": (Z, []),

@@ -198,14 +198,19 @@ class TrainEngine:
         """e [B,ch,2,2,2] latents-before-latent_gen.  Returns the dict of saved activations."""
         net, Ls = self.net, self.layers
         a = {"e": e}
-        a["h"] = self._conv(Ls["latent"], e, NONE)
         g2 = net.latent_gen.gdn_2
-        a["lat"] = ops.gdn_fwd(a["h"], g2.beta, g2.gamma, False)
         ec = net.entropy_coder
         sd = self._step_dev
-        a["x0"], a["lbits"], _, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
-                                                       block_ids=block_ids, seed=self.seed,
-                                                       step=0 if sd is not None else self.noise_step, step_dev=sd)
+        if e.shape[1] <= 8 and _NAIVE_OFF():         # latent generator + quantiser in one launch
+            a["h"], a["lat"], a["x0"], a["lbits"] = ops.latent_fwd(
+                e, Ls["latent"].w_fwd, Ls["latent"].b_eff, g2.beta, g2.gamma, ec.sigma.reshape(-1), ec.mu.reshape(-1),
+                mode, block_ids=block_ids, seed=self.seed, step=0 if sd is not None else self.noise_step, step_dev=sd)
+        else:
+            a["h"] = self._conv(Ls["latent"], e, NONE)
+            a["lat"] = ops.gdn_fwd(a["h"], g2.beta, g2.gamma, False)
+            a["x0"], a["lbits"], _, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
+                                                           block_ids=block_ids, seed=self.seed,
+                                                           step=0 if sd is not None else self.noise_step, step_dev=sd)
         ig = net.reconstructor.activation
         self.overlap = self.allow_overlap and e.shape[0] <= 64   # large batches fill the chip by themselves
         if self.fused_stem:

@@ -442,6 +442,20 @@ def gdn_bwd(x, beta_hat, gamma_hat, dy, inverse, dbeta_out=None, dgamma_out=None
 
 
 # ---------------------------------------------------------------- rates
+def latent_fwd(e, w_fwd, bias, beta_hat, gamma_hat, sigma, mu, mode, block_ids=None, seed=0, step=0, step_dev=None):
+    """conv1x1 + GDN + round/noise + rate in one launch: returns (h, lat, x_rounded, bits[1])."""
+    _f32(e, w_fwd, bias, beta_hat, gamma_hat, sigma, mu)
+    _chk(block_ids)
+    B, c = e.shape[0], e.shape[1]
+    h, lat, xr = torch.empty_like(e), torch.empty_like(e), torch.empty_like(e)
+    bits = torch.empty(1, device=e.device)
+    check(lib().nvf_latent_fwd(_ptr(e), _ptr(w_fwd), _ptr(bias), _ptr(beta_hat), _ptr(gamma_hat), _ptr(block_ids),
+                               _ptr(sigma), _ptr(mu), _ptr(h), _ptr(lat), _ptr(xr), _ptr(bits), B, c, e[0, 0].numel(),
+                               0 if mode == "train" else 1, int(seed), int(step), _ptr(step_dev), _stream()),
+          "nvf_latent_fwd")
+    return h, lat, xr, bits
+
+
 def latent_rate(x, sigma, mu, mode, u=None, block_ids=None, want_grad=False, g_dev=None, g_host=1.0, seed=0,
                 step=0, dx_addend=None, dsigma_out=None, dmu_out=None, step_dev=None):
     """Returns (x_rounded, bits[1], dx, dsigma, dmu); the gradient outputs are None unless want_grad."""

@@ -169,6 +169,26 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     assert torch.equal(outs[2], ops.wgrad(g3, y2, 4, 1, 0, out_mode=0))
 
 
+@pytest.mark.parametrize("mode,c", [("train", 3), ("eval", 8)])
+def test_latent_fwd_equals_the_three_kernels(ops, mode, c):
+    """nvf_latent_fwd = conv1x1 + GDN + quantiser/rate: every output bit-identical to the separate launches."""
+    g = gen(7200 + c)
+    B = 5
+    e = dev(1.0 + 0.5 * torch.randn(B, c, 2, 2, 2, generator=g))
+    w = torch.randn(c, c, 1, 1, 1, generator=g) * 0.5
+    b = dev(torch.randn(c, generator=g) * 0.1)
+    beta = dev(1.0 + 0.1 * torch.rand(c, generator=g))
+    gamma = dev(0.3 * torch.rand(c, c, generator=g))
+    sigma, mu = dev(0.5 + torch.rand(c, generator=g)), dev(torch.randn(c, generator=g) * 0.1)
+    wf, _ = ops.pack_conv_weight(dev(w))
+    ids = dev(torch.tensor([7, 3, 11, 0, 5]))
+    h, lat, xr, bits = ops.latent_fwd(e, wf, b, beta, gamma, sigma, mu, mode, block_ids=ids, seed=9, step=4)
+    h2 = ops.conv3d_gather(e, wf, b, c, 1, 1, 0, (2, 2, 2))
+    lat2 = ops.gdn_fwd(h2, beta, gamma, False)
+    xr2, bits2, _, _, _ = ops.latent_rate(lat2, sigma, mu, mode, block_ids=ids, seed=9, step=4)
+    assert torch.equal(h, h2) and torch.equal(lat, lat2) and torch.equal(xr, xr2) and torch.equal(bits, bits2)
+
+
 # matrix-core (MFMA) form of the 4^3, 8 -> 8 channel convolutions: (spatial_in, batch)
 @pytest.mark.parametrize("n,B", [(35, 2), (19, 3), (35, 1), (19, 5)])
 def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
