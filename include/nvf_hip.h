@@ -187,6 +187,11 @@ int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const i
 int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                             int* nslabs, void* stream);
 
+/* up1's and conv0's weight gradients of the narrow trunk in one launch (partial sums): job 0 = up1 (p = X [B,16,8^3],
+ * q = dY [B,8,19^3]), job 1 = conv0 (p = X [B,8,4^3], q = dY [B,16,8^3]); slabs[j]: up to 512 slabs of 16000 floats */
+int nvf_wgrad_up1_conv0_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                                int* nslabs, void* stream);
+
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */
 size_t nvf_channel_sum_workspace(int c);

@@ -78,24 +78,23 @@ struct WCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p, const float* __restrict__ q,
-                                                     float* __restrict__ slabs, WgDims d) {
+__device__ __forceinline__ void wgrad_tiled_body(const float* __restrict__ p, const float* __restrict__ q,
+                                                 float* __restrict__ slabs, const WgDims& d, int bx, int by, float* lds) {
   constexpr int A = C::A, KS = C::KS, S = C::S, NB = C::NB, TX = C::TX, TY = C::TY, TZ = C::TZ, K3 = C::K3;
   constexpr int QX = C::QX, QY = C::QY, QZ = C::QZ, QRS = C::QRS, QPS = C::QPS, QCS = C::QCS, NT = C::NT;
-  __shared__ float lds[C::LDSF];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int bb = wave / C::WPB;                 // q channel within this workgroup
   const int kk = (wave % C::WPB) * 64 + lane;   // tap
   const bool valid = kk < K3;
   const int kz = kk / (KS * KS), ky = (kk / KS) % KS, kx = kk % KS;
-  const int b0 = blockIdx.y * NB;
+  const int b0 = by * NB;
   const int lane_off = valid ? bb * QCS + kz * QPS + ky * QRS + kx : 0;
   float acc[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) acc[a] = 0.f;
 
   const int tiles = d.tiles_x * d.tiles_y * d.tiles_z;
-  const int first = blockIdx.x * d.items_per_wg;
+  const int first = bx * d.items_per_wg;
   const int last = min(first + d.items_per_wg, d.items);
   const size_t pplane = (size_t)d.hp * d.wp, qplane = (size_t)d.hq * d.wq;
 #pragma unroll 1
@@ -142,13 +141,40 @@ __global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p
     }
   }
   if (!valid || b0 + bb >= d.bc) return;
-  float* slab = slabs + (size_t)blockIdx.x * d.jtotal;
+  float* slab = slabs + (size_t)bx * d.jtotal;
   const int b = b0 + bb;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     const int o = d.out_mode == 0 ? (a * d.bc + b) * K3 + kk : (b * A + a) * K3 + (K3 - 1 - kk);
     slab[o] = acc[a];
   }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p, const float* __restrict__ q,
+                                                     float* __restrict__ slabs, WgDims d) {
+  __shared__ float lds[C::LDSF];
+  wgrad_tiled_body<C>(p, q, slabs, d, blockIdx.x, blockIdx.y, lds);
+}
+
+// up1's and conv0's weight gradients (the two small transposed convolutions of the narrow trunk) in one launch:
+// each is latency-bound on part of the chip, together they cost the longer of the two.  Same bodies, same slabs.
+struct WgTiled2 {
+  const float* p[2];
+  const float* q[2];
+  float* slabs[2];
+  WgDims d[2];
+  int32_t nx[2], ny[2];
+};
+
+template <class C0, class C1>
+__global__ __launch_bounds__(C0::NT) void wgrad_tiled2_kernel(WgTiled2 m) {
+  static_assert(C0::NT == C1::NT, "one workgroup size");
+  __shared__ float lds[C0::LDSF > C1::LDSF ? C0::LDSF : C1::LDSF];
+  int bid = blockIdx.x;
+  if (bid < m.nx[0] * m.ny[0]) { wgrad_tiled_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid % m.nx[0], bid / m.nx[0], lds); return; }
+  bid -= m.nx[0] * m.ny[0];
+  wgrad_tiled_body<C1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid % m.nx[1], bid / m.nx[1], lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -653,6 +679,34 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
   }
   NVF_LAUNCH_CHECK();
   return rc;
+}
+
+// job 0: up1 (p = X [B,16,8^3], q = dY [B,8,19^3]); job 1: conv0 (p = X [B,8,4^3], q = dY [B,16,8^3]); both k 5,
+// stride 2, out_mode 0.  slabs[j] holds up to 512 slabs of 16000 floats; nslabs[j] = number written.
+extern "C" int nvf_wgrad_up1_conv0_partial(const float* const* ps, const float* const* qs, float* const* slabs,
+                                           int batch, int* nslabs, void* stream) {
+  if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
+  using C0 = WCfg<16, 5, 2, 4, 8, 4, 2, 0>; using C1 = WCfg<8, 5, 2, 4, 4, 4, 4, 0>;
+  WgTiled2 m{};
+  const int geo[2][6] = {{8, 8, 19, 0, 16, 8}, {4, 16, 8, 2, 8, 16}};   // wp, bc, wq, pad, a, b
+  for (int j = 0; j < 2; ++j) {
+    if (!ps[j] || !qs[j] || !slabs[j]) return NVF_EINVAL;
+    WgDims d{};
+    d.batch = batch; d.bc = geo[j][1]; d.dp = d.hp = d.wp = geo[j][0]; d.dq = d.hq = d.wq = geo[j][2]; d.pad = geo[j][3];
+    d.out_mode = 0; d.jtotal = geo[j][4] * geo[j][5] * 125;
+    const int tx = j == 0 ? C0::TX : C1::TX, ty = j == 0 ? C0::TY : C1::TY, tz = j == 0 ? C0::TZ : C1::TZ;
+    const int nb = j == 0 ? C0::NB : C1::NB;
+    d.tiles_x = d.wp / tx; d.tiles_y = d.hp / ty; d.tiles_z = d.dp / tz;
+    d.items = batch * d.tiles_x * d.tiles_y * d.tiles_z;
+    int n = d.items < kMaxSlabs ? d.items : kMaxSlabs;
+    d.items_per_wg = (d.items + n - 1) / n;
+    n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+    m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j]; m.d[j] = d; m.nx[j] = n; m.ny[j] = (d.bc + nb - 1) / nb;
+    nslabs[j] = n;
+  }
+  wgrad_tiled2_kernel<C0, C1><<<m.nx[0] * m.ny[0] + m.nx[1] * m.ny[1], C0::NT, 0, nvf_stream(stream)>>>(m);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 extern "C" int nvf_wgrad(const float* p, const float* q, float* dw, void* workspace, size_t workspace_bytes, int batch,

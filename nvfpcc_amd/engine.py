@@ -334,11 +334,16 @@ class TrainEngine:
         else:
             side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
         g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
-        side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"])
+        if not wg3:
+            side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"])
         if ev_t0 is not None:
             main.wait_event(ev_t0)
         g1 = self._dx_convT(Ls["up1"], g2, a["y1"], mask=a["y1"], addend=t0)
-        side_wgrad(self._wgrad_convT, Ls["conv0"], g1, a["h0"])
+        if wg3:                                      # up1 and conv0 weight gradients in one launch
+            self._wg.add_up1_conv0([a["y1"], a["h0"]], [g2, g1], [Ls["up1"].gk, Ls["conv0"].gk])
+            self._bias_jobs += [(g2, Ls["up1"].gb), (g1, Ls["conv0"].gb)]
+        else:
+            side_wgrad(self._wgrad_convT, Ls["conv0"], g1, a["h0"])
         ig = net.reconstructor.activation
         gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
         gamma_view = None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape)

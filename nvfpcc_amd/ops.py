@@ -356,6 +356,29 @@ class WgradBatch:
         for h in range(3):
             self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
 
+    def _grouped(self, fn, what, ps, qs, outs, jt, max_slabs):
+        import ctypes
+        _f32(*ps, *qs, *outs)
+        n = len(jt)
+        sizes = [(max_slabs * j * 4 + 255) // 256 * 256 for j in jt]
+        if self.offset + sum(sizes) > self.ws.numel():
+            if self.jobs:
+                self.finish()
+            self._retired.append(self.ws)
+            self.ws = torch.empty(max(sum(sizes), 2 * self.ws.numel()), dtype=torch.uint8, device=self.device)
+        bases = []
+        for sz in sizes:
+            bases.append(self.ws.data_ptr() + self.offset)
+            self.offset += sz
+        nsl = (ctypes.c_int * n)()
+        check(fn(_parr(ps), _parr(qs), (ctypes.c_void_p * n)(*bases), ps[0].shape[0], nsl, _stream()), what)
+        for h in range(n):
+            self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
+
+    def add_up1_conv0(self, ps, qs, outs):
+        """up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch, two reduction jobs."""
+        self._grouped(lib().nvf_wgrad_up1_conv0_partial, "nvf_wgrad_up1_conv0_partial", ps, qs, outs, (16000, 16000), 512)
+
     def add_heads3(self, dls, xs, outs, max_slabs=512):
         """Weight gradients of the three classifier heads: one partial-sum launch, three reduction jobs."""
         import ctypes

@@ -167,6 +167,14 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     assert torch.equal(outs[0], ops.wgrad(g5, y4, 4, 1, 0, out_mode=0))
     assert torch.equal(outs[1], ops.wgrad(y3, g4, 5, 2, 0, out_mode=0))
     assert torch.equal(outs[2], ops.wgrad(g3, y2, 4, 1, 0, out_mode=0))
+    # ... and so do up1 + conv0
+    y1, g2 = R(B, 16, 8, 8, 8), R(B, 8, 19, 19, 19)
+    h0, g1 = R(B, 8, 4, 4, 4), R(B, 16, 8, 8, 8)
+    outs2 = [torch.empty(16, 8, 5, 5, 5, device=g5.device), torch.empty(8, 16, 5, 5, 5, device=g5.device)]
+    wg.add_up1_conv0([y1, h0], [g2, g1], outs2)
+    wg.finish()
+    assert torch.equal(outs2[0], ops.wgrad(y1, g2, 5, 2, 0, out_mode=0))
+    assert torch.equal(outs2[1], ops.wgrad(h0, g1, 5, 2, 2, out_mode=0))
 
 
 @pytest.mark.parametrize("mode,c", [("train", 3), ("eval", 8)])
