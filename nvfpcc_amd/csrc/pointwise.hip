@@ -171,7 +171,9 @@ __global__ __launch_bounds__(kGdnThreads) void gdn_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma_hat,
                                                               const float* __restrict__ dy, float* __restrict__ dx,
                                                               float* __restrict__ slabs, int batch, int c, int spatial,
-                                                              int inverse, int vox_per_wg) {
+                                                              int inverse, int vox_per_wg,
+                                                              float* __restrict__ dbeta_hat,
+                                                              float* __restrict__ dgamma_hat) {
   extern __shared__ float sm[];             // ts[c][T+1], xs[c][T+1]
   const int T = kGdnThreads, LD = T + 1;
   float* ts = sm;
@@ -237,6 +239,22 @@ __global__ __launch_bounds__(kGdnThreads) void gdn_bwd_kernel(const float* __res
     __syncthreads();
   }
   int slot = 0;
+  if (gridDim.x == 1) {
+    // a single workgroup holds the complete sums: finish here (what gdn_bwd_final does for one slab: 0 + s = s)
+    for (int p = tid; p < ncol; p += T, ++slot) {
+      const float sv = 0.f + own[slot];
+      if (p < c) {
+        const float h = beta_hat[p];
+        const float g = sv * 2.f * fmaxf(h, NVF_BETA_BOUND);
+        dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+      } else {
+        const float h = gamma_hat[p - c];
+        const float g = sv * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
+        dgamma_hat[p - c] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+      }
+    }
+    return;
+  }
   for (int p = tid; p < ncol; p += T, ++slot) slabs[(size_t)blockIdx.x * ncol + p] = own[slot];
 }
 
@@ -274,9 +292,10 @@ extern "C" int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* g
   size_t lds = (size_t)2 * c * (kGdnThreads + 1) * sizeof(float);
   hipStream_t s = nvf_stream(stream);
   gdn_bwd_kernel<<<nslab, kGdnThreads, lds, s>>>(x, beta_hat, gamma_hat, dy, dx, (float*)workspace, batch, c, spatial,
-                                                 inverse, (int)per);
-  gdn_bwd_final<<<NVF_GRID(c + c * c, 64), 64, 0, s>>>((const float*)workspace, beta_hat, gamma_hat, dbeta_hat,
-                                                       dgamma_hat, nslab, c);
+                                                 inverse, (int)per, dbeta_hat, dgamma_hat);
+  if (nslab > 1)      // one workgroup (the latent GDN of a mini-batch) finishes the parameter gradients itself
+    gdn_bwd_final<<<NVF_GRID(c + c * c, 64), 64, 0, s>>>((const float*)workspace, beta_hat, gamma_hat, dbeta_hat,
+                                                         dgamma_hat, nslab, c);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

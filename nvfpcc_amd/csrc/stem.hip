@@ -316,29 +316,32 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
 }
 
 // IGDN parameter gradients from the slabs: fixed-order sum, re-parametrisation chain rule, LowerBound rule
-__global__ void stem_gdn_final(const float* __restrict__ slabs, const float* __restrict__ beta_hat,
-                               const float* __restrict__ gamma_hat, float* __restrict__ dbeta_hat,
-                               float* __restrict__ dgamma_hat, int nslab) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= kStemNcol) return;
-  float s = 0.f;
-  for (int g = 0; g < nslab; ++g) s += slabs[(size_t)g * kStemNcol + p];
-  if (p < C0) {
-    const float h = beta_hat[p];
-    const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
-    dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
-  } else {
-    const float h = gamma_hat[p - C0];
-    const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
-    dgamma_hat[p - C0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+// Both finals of the stem backward in one launch: the last workgroup turns the IGDN slabs into parameter gradients
+// (fixed-order sum, re-parametrisation chain rule, LowerBound rule), the others add up0's weight-gradient slabs.
+__global__ __launch_bounds__(256) void stem_finals(const float* __restrict__ slab_gdn, const float* __restrict__ beta_hat,
+                                                   const float* __restrict__ gamma_hat, float* __restrict__ dbeta_hat,
+                                                   float* __restrict__ dgamma_hat, const float* __restrict__ slab_w,
+                                                   float* __restrict__ dw, int nslab, int jtotal) {
+  if (blockIdx.x == gridDim.x - 1) {
+    const int p = threadIdx.x;
+    if (p >= kStemNcol) return;
+    float s = 0.f;
+    for (int g = 0; g < nslab; ++g) s += slab_gdn[(size_t)g * kStemNcol + p];
+    if (p < C0) {
+      const float h = beta_hat[p];
+      const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
+      dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+    } else {
+      const float h = gamma_hat[p - C0];
+      const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
+      dgamma_hat[p - C0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+    }
+    return;
   }
-}
-
-__global__ void stem_w_final(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= jtotal) return;
   float s = 0.f;
-  for (int g = 0; g < nslab; ++g) s += slabs[(size_t)g * jtotal + j];
+  for (int g = 0; g < nslab; ++g) s += slab_w[(size_t)g * jtotal + j];
   dw[j] = s;
 }
 
@@ -364,9 +367,10 @@ extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, c
   stem_bwd_kernel<<<nslab, 512, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn, slab_w,
                                         batch, ch, want_w);
   if (want_w) {
-    stem_gdn_final<<<(kStemNcol + 63) / 64, 64, 0, s>>>(slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab);
     const int jtotal = ch * C0 * 125;
-    stem_w_final<<<(jtotal + 255) / 256, 256, 0, s>>>(slab_w, dw_up0, nslab, jtotal);
+    static_assert(kStemNcol <= 256, "one workgroup covers the IGDN columns");
+    stem_finals<<<(jtotal + 255) / 256 + 1, 256, 0, s>>>(slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, slab_w,
+                                                         dw_up0, nslab, jtotal);
   }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
