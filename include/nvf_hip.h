@@ -203,6 +203,13 @@ size_t nvf_multi_channel_sum_workspace(int total_channels);
 int nvf_multi_channel_sum(const float* const* xs, float* const* outs, const int* channels, const int* spatials,
                           int ntensors, int batch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* nvf_wgrad_reduce_multi and the partial pass of nvf_multi_channel_sum in one launch (independent work), then the
+ * bias sums' final pass; same results as the two separate calls */
+int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws, const int* nslabs,
+                                    const int* jtotals, int n, const float* const* xs, float* const* outs,
+                                    const int* channels, const int* spatials, int ntensors, int batch,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- GDN / IGDN (gdn_3d.py:72-95, 137-159; LowerBound gdn_3d.py:13-29) ----------
  * beta = max(beta_hat, beta_bound)^2 - 2^-36, gamma = max(gamma_hat, 2^-18)^2 - 2^-36;
  * norm[c] = sqrt(beta[c] + sum_j gamma[c][j] x[j]^2); y = x / norm (GDN) or x * norm (IGDN).

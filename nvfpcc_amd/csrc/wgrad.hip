@@ -735,14 +735,13 @@ struct WgReduceMulti {
 };
 
 // same arithmetic as wgrad_reduce (16 interleaved slices in ascending slab order, then slices 0..15)
-__global__ __launch_bounds__(1024) void wgrad_reduce_multi(WgReduceMulti d) {
-  __shared__ float part[16][64];
+__device__ __forceinline__ void wgrad_reduce_multi_body(const WgReduceMulti& d, int bid, float (*part)[64]) {
   int t = 0;
-  while (t + 1 < d.n && (int)blockIdx.x >= d.blk_base[t + 1]) ++t;
+  while (t + 1 < d.n && bid >= d.blk_base[t + 1]) ++t;
   const float* slabs = d.slabs[t];
   const int nslab = d.nslab[t], jtotal = d.jtotal[t];
   const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int j = ((int)blockIdx.x - d.blk_base[t]) * 64 + jl;
+  const int j = (bid - d.blk_base[t]) * 64 + jl;
   // four independent partial sums keep four loads in flight; the order (4 strided chains, then a fixed tree) is
   // the same in wgrad_reduce and wgrad_reduce_multi
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -765,6 +764,11 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi(WgReduceMulti d) {
     for (int k = 1; k < 16; ++k) v += part[k][jl];
     d.dw[t][j] = v;
   }
+}
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi(WgReduceMulti d) {
+  __shared__ float part[16][64];
+  wgrad_reduce_multi_body(d, blockIdx.x, part);
 }
 
 extern "C" int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const int* nslabs,
@@ -847,9 +851,11 @@ struct MultiSumDesc {
   int32_t ntensors, batch, total_channels, nchunk;
 };
 
-__global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
-  __shared__ float red[16];
-  const int gch = blockIdx.x, g = blockIdx.y;       // g: group of consecutive batch entries
+// `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
+// workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
+template <int T>
+__device__ __forceinline__ void multi_channel_sum_partial_body(const MultiSumDesc& d, float* __restrict__ part, int gch,
+                                                               int g, float* red) {
   int t = 0;
   while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
   const int ch = gch - d.chan_base[t], c = d.c[t], spatial = d.spatial[t];
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d,
   const int n_lo = g * per, n_hi = min(n_lo + per, d.batch);
   const float* x = d.x[t];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int n = n_lo; n < n_hi; ++n) {
+  for (int n = n_lo; n < n_hi && (int)threadIdx.x < T; ++n) {
     const float* row = x + ((size_t)n * c + ch) * spatial;     // one contiguous row per (n, channel)
     // rows of 35^3 or 19^3 floats start at any 4-byte phase: a scalar head up to the next 16-byte boundary, then
     // aligned float4s (four per thread in flight), then a scalar tail
@@ -867,12 +873,12 @@ __global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d,
     const float4* r4 = (const float4*)(row + head);
     const int n4 = body >> 2;
     int i = threadIdx.x;
-    for (; i + 3 * (int)blockDim.x < n4; i += 4 * blockDim.x) {
-      const float4 a = r4[i], b4 = r4[i + blockDim.x], c4 = r4[i + 2 * blockDim.x], d4 = r4[i + 3 * blockDim.x];
+    for (; i + 3 * (int)T < n4; i += 4 * T) {
+      const float4 a = r4[i], b4 = r4[i + T], c4 = r4[i + 2 * T], d4 = r4[i + 3 * T];
       s0 += (a.x + b4.x) + (c4.x + d4.x); s1 += (a.y + b4.y) + (c4.y + d4.y);
       s2 += (a.z + b4.z) + (c4.z + d4.z); s3 += (a.w + b4.w) + (c4.w + d4.w);
     }
-    for (; i < n4; i += blockDim.x) {
+    for (; i < n4; i += T) {
       const float4 v = r4[i];
       s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
@@ -881,6 +887,21 @@ __global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d,
   }
   const float s = nvf_block_sum((s0 + s1) + (s2 + s3), red);
   if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
+}
+
+__global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
+  __shared__ float red[16];
+  multi_channel_sum_partial_body<256>(d, part, blockIdx.x, blockIdx.y, red);
+}
+
+// the slab reduction of all weight gradients and the partial bias sums are independent: one launch
+__global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, int r_blocks, MultiSumDesc m,
+                                                              float* __restrict__ part) {
+  __shared__ float sm[16][64];
+  const int bid = blockIdx.x;
+  if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, sm); return; }
+  const int q = bid - r_blocks;
+  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
 }
 
 __global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part) {
@@ -922,3 +943,43 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
+
+// nvf_wgrad_reduce_multi and the partial pass of nvf_multi_channel_sum in ONE launch (they are independent), then the
+// final pass of the bias sums: the tail of a backward pass in two launches instead of three.  Results are those of
+// the two separate calls, bit for bit.
+extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws, const int* nslabs,
+                                               const int* jtotals, int n, const float* const* xs, float* const* outs,
+                                               const int* channels, const int* spatials, int ntensors, int batch,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!slabs || !dws || !nslabs || !jtotals || n <= 0 || n > 16) return NVF_EINVAL;
+  if (!xs || !outs || !channels || !spatials || ntensors <= 0 || ntensors > 12 || batch <= 0 || !workspace)
+    return NVF_EINVAL;
+  WgReduceMulti r{};
+  int base = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (nslabs[i] == 0) continue;
+    if (!slabs[i] || !dws[i] || nslabs[i] < 0 || jtotals[i] <= 0) return NVF_EINVAL;
+    r.slabs[m] = slabs[i]; r.dw[m] = dws[i]; r.nslab[m] = nslabs[i]; r.jtotal[m] = jtotals[i];
+    r.blk_base[m] = base;
+    base += (jtotals[i] + 63) / 64;
+    ++m;
+  }
+  r.blk_base[m] = base;
+  r.n = m;
+  MultiSumDesc d{};
+  int cb = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    if (!xs[i] || !outs[i] || channels[i] <= 0 || spatials[i] <= 0) return NVF_EINVAL;
+    d.x[i] = xs[i]; d.out[i] = outs[i]; d.c[i] = channels[i]; d.spatial[i] = spatials[i]; d.chan_base[i] = cb;
+    cb += channels[i];
+  }
+  d.ntensors = ntensors; d.batch = batch; d.total_channels = cb;
+  d.nchunk = batch < kSumChunks ? batch : kSumChunks;
+  if (workspace_bytes < nvf_multi_channel_sum_workspace(cb)) return NVF_EWORKSPACE;
+  hipStream_t s = nvf_stream(stream);
+  wgrad_reduce_and_sums<<<base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace);
+  multi_channel_sum_final<<<(cb + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+

@@ -381,9 +381,8 @@ class TrainEngine:
         kernels = [Ls[n].mod.kernel for n in TRUNK]
         self._fork()
         with self._on_side():
-            if want_w:
-                self._wg.finish()
-                ops.multi_channel_sum([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
+            if want_w:     # slab reduction of every weight gradient + all bias sums
+                self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
                 ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
                                       g_host=g_net * self.rate_grad_scale)
             else:

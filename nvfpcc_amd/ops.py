@@ -402,6 +402,27 @@ class WgradBatch:
         for h in range(3):
             self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], cs[h] * 27))
 
+    def finish_with_sums(self, tensors, outs):
+        """finish() and multi_channel_sum(tensors, outs) with the reduction and the partial bias sums in one launch."""
+        import ctypes
+        jobs = self.jobs
+        if not jobs or len(jobs) > 16 or not tensors:
+            self.finish()
+            if tensors:
+                multi_channel_sum(tensors, outs)
+            return
+        self.jobs, self.offset = [], 0
+        _f32(*tensors)
+        _f32(*outs)
+        n, nt = len(jobs), len(tensors)
+        total = sum(t.shape[1] for t in tensors)
+        ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum")
+        check(lib().nvf_wgrad_reduce_multi_and_sums(
+            (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
+            (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n,
+            _parr(tensors), _parr(outs), _iarr([t.shape[1] for t in tensors]), _iarr([t[0, 0].numel() for t in tensors]),
+            nt, tensors[0].shape[0], _ptr(ws), ws.numel(), _stream()), "nvf_wgrad_reduce_multi_and_sums")
+
     def finish(self):
         import ctypes
         jobs, self.jobs, self.offset = self.jobs, [], 0
