@@ -30,7 +30,7 @@ struct HCfg {
 // C channels of the x tile (with a one-voxel halo, zero outside the tensor) -> LDS [c][IZ][IY][RS]
 template <int CH, int S, int IZ, int IY, int RS, int NT>
 __device__ __forceinline__ void head_stage(const float* __restrict__ xb, float* xs, int tid, int z0, int y0) {
-  constexpr int XG = S / 4, ITEMS = CH * IZ * IY * XG, U = 8;
+  constexpr int XG = S / 4, ITEMS = CH * IZ * IY * XG, U = 16;
 #pragma unroll 1
   for (int i0 = tid; i0 < ITEMS; i0 += NT * U) {
     float4 v[U];
