@@ -16,6 +16,7 @@
 // writes one partial slab and a second kernel adds the slabs in a fixed order, so the
 // result is reproducible run to run (no float atomics).
 #include "nvf_common.h"
+#include <cstdlib>
 
 static const int kMaxSlabs = 512;
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
@@ -226,15 +227,24 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
   const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
   const int first = bx * d.items_per_wg;
   const int last = min(first + d.items_per_wg, d.items);
-  // Tile staging through registers: ALL global loads of an item (dY: aligned float4 rows; X: 35- or 19-float rows,
-  // element by element) are issued before any is waited for, and the next item's loads are in flight while this
-  // item's MFMAs issue.  The zero padding of the LDS image (u = 0, u > W, xx >= WQ) is written once.
+  // Tile staging through registers: ALL global loads of an item are issued before any is waited for, and the next
+  // item's loads are in flight while this item's MFMAs issue.  dY: aligned float4 rows.  X: for one (channel, plane)
+  // the TY + 3 rows of W + 3 words are CONTIGUOUS in memory, so the tile is NSEG = 8 (TZ + 3) segments of SEG words;
+  // thread t copies word t (+256 ..) of every segment: the global address is a per-item scalar base plus a
+  // compile-time segment offset plus t, the LDS address a per-thread constant plus a compile-time offset -- no
+  // per-element index arithmetic.  The zero padding of the LDS image (u = 0, u > W, xx >= WQ) is written once.
   constexpr int RX = (TZ + 3) * (TY + 3);                 // X rows per channel
   constexpr int NG4 = 8 * TZ * TY * (W / 4);              // float4 items of the dY tile
-  constexpr int NXE = 8 * RX * (W + 3);                   // elements of the X tile
-  constexpr int UG = (NG4 + 255) / 256, UX = (NXE + 255) / 256;
+  constexpr int SEG = (TY + 3) * (W + 3), PPS = (SEG + 255) / 256, NSEG = 8 * (TZ + 3);
+  constexpr int UG = (NG4 + 255) / 256, UX = NSEG * PPS;
   float4 gv[UG];
   float xv[UX];
+  int xlo[PPS];                                           // LDS word of this thread's element inside a segment
+#pragma unroll
+  for (int part = 0; part < PPS; ++part) {
+    const int e = tid + part * 256;
+    xlo[part] = (e / (W + 3)) * XRS + e % (W + 3);
+  }
   auto load = [&](int item) {
     const int n = item / tiles, t = item % tiles;
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
@@ -246,12 +256,12 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
       gv[u] = i < NG4 ? *(const float4*)(gn + (((size_t)c * W + z0 + zz) * W + y0 + yy) * W + 4 * xq)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float* xn = x + (size_t)n * 8 * WQ * WQ * WQ;
+    const float* xt = x + (((size_t)n * 8 * WQ + z0) * WQ + y0) * WQ;      // wave-uniform
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-      const int e = tid + u * 256;
-      const int xx = e % (W + 3), r = e / (W + 3), yy = r % (TY + 3), t2 = r / (TY + 3), zz = t2 % (TZ + 3), c = t2 / (TZ + 3);
-      xv[u] = e < NXE ? xn[(((size_t)c * WQ + z0 + zz) * WQ + y0 + yy) * WQ + xx] : 0.f;
+      const int seg = u / PPS, part = u % PPS, c = seg / (TZ + 3), zz = seg % (TZ + 3);
+      const int e = tid + part * 256;
+      xv[u] = e < SEG ? xt[(c * WQ + zz) * WQ * WQ + e] : 0.f;
     }
   };
   auto store = [&]() {
@@ -266,11 +276,8 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
     }
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-      const int e = tid + u * 256;
-      if (e < NXE) {
-        const int xx = e % (W + 3), r = e / (W + 3), c = r / RX;
-        ldsX[c * XCS + (r - c * RX) * XRS + xx] = xv[u];
-      }
+      const int seg = u / PPS, part = u % PPS, c = seg / (TZ + 3), zz = seg % (TZ + 3);
+      if (tid + part * 256 < SEG) ldsX[c * XCS + zz * (TY + 3) * XRS + xlo[part]] = xv[u];
     }
   };
   for (int i = tid; i < C::LDSF; i += 256) lds[i] = 0.f;
@@ -281,11 +288,11 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
     (void)y0; (void)z0;
     __syncthreads();                                        // zero fill done / previous item no longer being read
-    store();
+    if (d.pad != 1 || item == first) store();
     __syncthreads();
-    if (item + 1 < last) load(item + 1);
+    if (item + 1 < last && d.pad != 1) load(item + 1);
 #pragma unroll 1
-    for (int row = wave; row < TZ * TY; row += 4) {
+    for (int row = wave; row < (d.pad == 2 ? 0 : TZ * TY); row += 4) {
       const int zz = row / TY, yy = row % TY;
       const float* pa = ldsG + laneA + row * GRS;
       const float* pb = ldsX + laneB + (zz * (TY + 3) + yy) * XRS;
@@ -347,6 +354,7 @@ static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* s
   int nslab = d.items < 256 ? d.items : 256;
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+  d.pad = getenv("NVF_WG_DBG") ? atoi(getenv("NVF_WG_DBG")) : 0;  // EXPERIMENT
   wgrad_k4_mfma<C><<<nslab, 256, 0, s>>>(g, x, slabs, d);
   if (defer_nslab) *defer_nslab = nslab;
   else wgrad_reduce<<<(4096 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
@@ -372,8 +380,10 @@ struct TWCfg {
   static constexpr int mod32(int v, int r) { return v + ((r - v % 32) + 32) % 32; }
   static constexpr int GCS = mod32(GZ * GY * GRS, 8), XCS = mod32(TZ * TY * XRS, 8);
   static constexpr int GOFF = 0, XOFF = 8 * GCS, LDSF = 8 * GCS + 8 * XCS;
-  static constexpr int NGE = 8 * GZ * GY * WG, NXE = 8 * TZ * TY * W;     // elements to load per item
-  static constexpr int UG = (NGE + 255) / 256, UX = (NXE + 255) / 256;
+  static constexpr int NXE = 8 * TZ * TY * W;                             // x elements to load per item
+  // g tile: for one (channel, plane) the GY rows of 35 words are contiguous: NSEG segments of SEG words
+  static constexpr int SEG = GY * WG, PPS = (SEG + 255) / 256, NSEG = 8 * GZ;
+  static constexpr int UG = NSEG * PPS, UX = (NXE + 255) / 256;
   static_assert(LDSF * 4 <= 160 * 1024, "LDS");
 };
 
@@ -388,23 +398,37 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 4, ch = (lane & 15) >> 1, sh = lane & 1;
   const int laneA = ch * XCS + kk - sh + 1;                  // x[ci = ch, ix0 + kk - sA], u = ix + 1
-  const int laneB = ch * GCS + 2 * kk + sh;                  // g[co = ch, 2 (ix0 + kk) + sB]
-  constexpr int NTW = 7;                                     // (kz, ky) pairs per wave: t = wave + 4 i
-  f32x4 acc1[NTW], acc2[NTW];
+  // 40 tiles: per kz, ty = 0..4 are the (kz, ky = ty) tiles with kx = 2 sA + sB; ty = 5..7 hold kx = 4 for the
+  // rows ky = 2 (ty - 5) + sB (sA = 0 rows only).  Wave w owns tiles j = w + 4 i, i < 10 -- the same instruction
+  // stream for every wave, the per-lane LDS word of tile i sits in boff[i].
+  constexpr int NTW = 10;
+  f32x4 acc[NTW];
+  int boff[NTW];
 #pragma unroll
-  for (int i = 0; i < NTW; ++i) { acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < NTW; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int j = wave + 4 * i, kz = j >> 3, ty = j & 7;
+    boff[i] = ty < 5 ? ch * GCS + 2 * kk + sh + (kz * GY + ty) * GRS
+                     : ch * GCS + 2 * kk + 4 + (kz * GY + 2 * (ty - 5) + sh) * GRS;
+  }
   const int tiles_y = W / TY, tiles_z = W / TZ, tiles = tiles_y * tiles_z;
   const int first = bx * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
   float gv[UG], xv[UX];
+  int glo[C::PPS];                                           // LDS word of this thread's element inside a g segment
+#pragma unroll
+  for (int part = 0; part < C::PPS; ++part) {
+    const int e = tid + part * 256;
+    glo[part] = (e / WG) * GRS + e % WG;
+  }
   auto load = [&](int item) {
     const int n = item / tiles, t = item % tiles;
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
-    const float* gn = g + (size_t)n * 8 * WG * WG * WG;
+    const float* gt = g + (((size_t)n * 8 * WG + 2 * z0) * WG + 2 * y0) * WG;       // wave-uniform
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
-      const int e = tid + u * 256;
-      const int xx = e % WG, r = e / WG, yy = r % GY, t2 = r / GY, zz = t2 % GZ, c = t2 / GZ;
-      gv[u] = e < C::NGE ? gn[(((size_t)c * WG + 2 * z0 + zz) * WG + 2 * y0 + yy) * WG + xx] : 0.f;
+      const int seg = u / C::PPS, part = u % C::PPS, c = seg / GZ, zz = seg % GZ;
+      const int e = tid + part * 256;
+      gv[u] = e < C::SEG ? gt[(c * WG + zz) * WG * WG + e] : 0.f;
     }
     const float* xn = x + (size_t)n * 8 * W * W * W;
 #pragma unroll
@@ -417,11 +441,8 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
-      const int e = tid + u * 256;
-      if (e < C::NGE) {
-        const int xx = e % WG, r = e / WG, c = r / (GZ * GY);
-        ldsG[c * GCS + (r - c * GZ * GY) * GRS + xx] = gv[u];
-      }
+      const int seg = u / C::PPS, part = u % C::PPS, c = seg / GZ, zz = seg % GZ;
+      if (tid + part * 256 < C::SEG) ldsG[c * GCS + zz * GY * GRS + glo[part]] = gv[u];
     }
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
@@ -437,26 +458,36 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
 #pragma unroll 1
   for (int item = first; item < last; ++item) {
     __syncthreads();
-    store();
+    if (d.pad != 1 || item == first) store();
     __syncthreads();
-    if (item + 1 < last) load(item + 1);
-#pragma unroll 1
-    for (int r = 0; r < TZ * TY; ++r) {
-      const int zl = r / TY, yl = r % TY;
-      const float* pa = ldsX + laneA + r * XRS;
-      const float* pb = ldsG + laneB + ((2 * zl) * GY + 2 * yl) * GRS;
-#pragma unroll 1
-      for (int xg = 0; xg < W / 4 + 1; ++xg) {               // the rows shifted by sA = 1 need ix = 15 from a fifth group
-        const float a = pa[4 * xg];
+    if (item + 1 < last && d.pad != 1) load(item + 1);
+    if (d.pad != 2) {
+      // 20 steps (row r, x group xg); the operands of step s + 1 are fetched while the 10 MFMAs of step s issue.
+      // The rows shifted by sA = 1 need ix = 15 from a fifth x group.
+      constexpr int NXG = W / 4 + 1, NSTEP = TZ * TY * NXG;
+      const float* pa = ldsX + laneA;
+      auto a_off = [](int st) { return (st / NXG) * XRS + 4 * (st % NXG); };
+      auto b_off = [](int st) {
+        const int r = st / NXG, zl = r / TY, yl = r % TY;
+        return ((2 * zl) * GY + 2 * yl) * GRS + 8 * (st % NXG);
+      };
+      float a_cur = pa[a_off(0)], b_cur[NTW];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-          const int t = wave + 4 * i;                        // wave-uniform; t < 25
-          if (t < 25) {
-            const int kz = t / 5, ky = t % 5;
-            const float* q = pb + (kz * GY + ky) * GRS + 8 * xg;
-            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, q[0], acc1[i], 0, 0, 0);
-            acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, q[2], acc2[i], 0, 0, 0);
-          }
+      for (int i = 0; i < NTW; ++i) b_cur[i] = ldsG[boff[i] + b_off(0)];
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        float a_nxt = 0.f, b_nxt[NTW];
+        if (st + 1 < NSTEP) {
+          a_nxt = pa[a_off(st + 1)];
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) b_nxt[i] = ldsG[boff[i] + b_off(st + 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[i], acc[i], 0, 0, 0);
+        if (st + 1 < NSTEP) {
+          a_cur = a_nxt;
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) b_cur[i] = b_nxt[i];
         }
       }
     }
@@ -466,15 +497,13 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
   const int co = (lane & 15) >> 1, sB = lane & 1;
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
-    const int t = wave + 4 * i;
-    if (t < 25) {
+    const int j = wave + 4 * i, kz = j >> 3, ty = j & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * (lane >> 4) + r, ci = m >> 1, sA = m & 1;
-        float* o = slab + (ci * 8 + co) * 125 + t * 5;
-        o[2 * sA + sB] = acc1[i][r];
-        if (sA == 1 && sB == 0) o[4] = acc2[i][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * (lane >> 4) + r, ci = m >> 1, sA = m & 1;
+      float* o = slab + (ci * 8 + co) * 125 + kz * 25;
+      if (ty < 5) o[ty * 5 + 2 * sA + sB] = acc[i][r];
+      else if (sA == 0 && 2 * (ty - 5) + sB < 5) o[(2 * (ty - 5) + sB) * 5 + 4] = acc[i][r];
     }
   }
 }
@@ -524,7 +553,8 @@ extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* cons
     m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j];
     WgDims d{};
     d.batch = batch; d.bc = 8; d.items = items[j];
-    int n = items[j] < 256 ? items[j] : 256;
+    static const int cap = getenv("NVF_WG3_CAP") ? atoi(getenv("NVF_WG3_CAP")) : 256;
+    int n = items[j] < cap ? items[j] : cap;
     d.items_per_wg = (items[j] + n - 1) / n;
     n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
     m.d[j] = d; m.n[j] = n; nslabs[j] = n;
@@ -541,6 +571,7 @@ static int launch_wgrad_s2k5(const float* x, const float* g, float* dw, float* s
   int nslab = d.items < 256 ? d.items : 256;                 // one workgroup per CU
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+  d.pad = getenv("NVF_WG_DBG") ? atoi(getenv("NVF_WG_DBG")) : 0;  // EXPERIMENT
   wgrad_s2k5_mfma<C><<<nslab, 256, 0, s>>>(x, g, slabs, d);
   if (defer_nslab) *defer_nslab = nslab;
   else wgrad_reduce<<<(8000 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 8000, accumulate);
