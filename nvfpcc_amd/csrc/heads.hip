@@ -13,6 +13,7 @@
 //   * give each thread four consecutive x outputs, so one row segment (a b128 plus two b32 LDS
 //     reads) feeds 12 FMAs per input channel.
 #include "nvf_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -56,6 +57,20 @@ __device__ __forceinline__ void head_stage(const float* __restrict__ xb, float* 
   }
 }
 
+// Six consecutive words x-1 .. x+4 of a staged row for the thread that owns x .. x+3 (xg = its float4 group, threads of
+// a row are consecutive lanes): ONE aligned ds_read_b128; the two halo words come from the neighbour lanes by DPP (the
+// row ends are the zero padding).  Scalar LDS reads at a lane stride of four words would hit 8 of the 32 banks.
+typedef float hf4 __attribute__((ext_vector_type(4)));
+template <int XG>
+__device__ __forceinline__ void head_row6(const float* row, int xg, float (&v)[6]) {
+  const hf4 m = *(const hf4*)(row + 4);
+  const int left = __builtin_amdgcn_update_dpp(0, __float_as_int(m.w), 0x111, 0xf, 0xf, true);    // row_shr:1
+  const int right = __builtin_amdgcn_update_dpp(0, __float_as_int(m.x), 0x101, 0xf, 0xf, true);   // row_shl:1
+  v[0] = xg == 0 ? 0.f : __int_as_float(left);
+  v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
+  v[5] = xg == XG - 1 ? 0.f : __int_as_float(right);
+}
+
 // ---- forward: p = act(bias + sum_{c,k} x[c, o + k - 1] w[c][k]) -----------------------------------------------
 template <class H>
 struct HFwdSmem { static constexpr int WORDS = H::C * H::IZ * H::IY * H::RS + H::C * 9 * 4; };
@@ -72,21 +87,22 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const
   constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
   const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
+  const int dbg = act >> 8; act &= 255;
   for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
-  head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
+  if (dbg != 1) head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
   __syncthreads();
   if (tid >= H::NACT) return;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int c = 0; c < C; ++c)
+  for (int c = 0; c < (dbg == 2 ? 0 : C); ++c)
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const float* row = xs + ((size_t)(c * IZ + tz + kz) * IY + ty + ky) * RS + 4 * xg;
-        const float4 m = *(const float4*)(row + 4);
-        const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+        float v[6];
+        head_row6<XG>(row, xg, v);
         const float4 wv = *(const float4*)(ws + (c * 9 + kz * 3 + ky) * 4);
         const float wk[3] = {wv.x, wv.y, wv.z};
 #pragma unroll
@@ -151,8 +167,8 @@ __device__ __forceinline__ void head_bwd_data_body(const float* __restrict__ dl,
 #pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
       const float* row = ds + ((size_t)(tz + kz) * IY + ty + ky) * RS + 4 * xg;
-      const float4 m = *(const float4*)(row + 4);
-      const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+      float v[6];
+      head_row6<XG>(row, xg, v);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const float* wr = ws + ((kz * 3 + ky) * 3 + kx) * C;
@@ -258,8 +274,8 @@ __device__ __forceinline__ void head_wgrad_body(const float* __restrict__ dl, co
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const float* row = xs + ((size_t)(c * IZ + tz + kz) * IY + ty + ky) * RS + 4 * xq;
-            const float4 m = *(const float4*)(row + 4);
-            const float v[6] = {row[3], m.x, m.y, m.z, m.w, row[8]};
+            float v[6];
+            head_row6<XG>(row, xq, v);
 #pragma unroll
             for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -414,7 +430,7 @@ extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, co
     m.a[h] = xs[h]; m.w[h] = ws[h]; m.bias[h] = biases[h]; m.out[h] = ps[h];
   }
   m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
-  m.act = act;
+  m.act = act | ((getenv("NVF_HEAD_DBG") ? atoi(getenv("NVF_HEAD_DBG")) : 0) << 8);  // EXPERIMENT
   heads3_fwd_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
