@@ -60,28 +60,27 @@ struct TMCfg {
   static_assert((XS + AS) * 4 <= 160 * 1024, "LDS");
 };
 
+// Persistent workgroups: the A fragments are fetched once per workgroup; a workgroup then walks the items
+// (batch element, cell plane cz, column split) w, w + G, w + 2 G ... with the next item's three input planes already
+// in registers while this item's MFMAs issue (two workgroups share a CU and fill each other's barriers).
 template <class T>
 __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int act) {
+                                                       const float* __restrict__ bias, float* __restrict__ y, int act,
+                                                       int items) {
   constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
                 NG = T::NG, NOUT = 2 * NIN + 3;
   __shared__ __attribute__((aligned(16))) float xs[T::XS];
   __shared__ __attribute__((aligned(16))) float as[T::AS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x % T::NSPLIT, cz = (blockIdx.x / T::NSPLIT) % NCELL, b = blockIdx.x / (T::NSPLIT * NCELL);
-  // ---- stage: every global load of the workgroup (A fragments, the three input planes cz-2 .. cz of every
-  // channel) is issued before anything is waited for; the image is zeroed while they are in flight
+  // ---- stage: every global load (A fragments, the three input planes cz-2 .. cz of every channel of the first
+  // item) is issued before anything is waited for; the image is zeroed while they are in flight
   constexpr int NA4 = (T::AS / 4 + 255) / 256;                 // float4 A loads per thread
   constexpr int ITEMS = CIN * 3 * NIN * NIN / 4;               // float4 input loads (rows are NIN = 8 or 16 floats)
   constexpr int NX4 = (ITEMS + 255) / 256;
-  float4 av[NA4], xv[NX4];
-#pragma unroll
-  for (int u = 0; u < NA4; ++u) {
-    const int i = tid + u * 256;
-    av[u] = i < T::AS / 4 ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  {
+  float4 xv[NX4];
+  auto load_x = [&](int item) {
+    const int cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
     const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
@@ -92,88 +91,109 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
       xv[u] = ok ? *(const float4*)(xb + (((size_t)c * NIN + zi) * NIN + iy) * NIN + 4 * xq)
                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  }
-  for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_x = [&]() {                                       // planes outside the input are written as zeros
 #pragma unroll
-  for (int u = 0; u < NA4; ++u) {
-    const int i = tid + u * 256;
-    if (i < T::AS / 4) ((float4*)as)[i] = av[u];
-  }
-  __syncthreads();
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * 256;
+      if (i < ITEMS) {
+        const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
+        float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + 4 * xq + 2;
+        dst[0] = xv[u].x; dst[1] = xv[u].y; dst[2] = xv[u].z; dst[3] = xv[u].w;
+      }
+    }
+  };
+  {
+    float4 av[NA4];
 #pragma unroll
-  for (int u = 0; u < NX4; ++u) {
-    const int i = tid + u * 256;
-    if (i < ITEMS) {
-      const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
-      float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + 4 * xq + 2;
-      dst[0] = xv[u].x; dst[1] = xv[u].y; dst[2] = xv[u].z; dst[3] = xv[u].w;
+    for (int u = 0; u < NA4; ++u) {
+      const int i = tid + u * 256;
+      av[u] = i < T::AS / 4 ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if ((int)blockIdx.x < items) load_x(blockIdx.x);
+    for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NA4; ++u) {
+      const int i = tid + u * 256;
+      if (i < T::AS / 4) ((float4*)as)[i] = av[u];
     }
   }
-  __syncthreads();
   const int j = lane & 15, kq = lane >> 4;
-  f32x4 acc[NCT][2][2];
+  const size_t cstride = (size_t)NOUT * NOUT * NOUT;
+  // ---- epilogue of one item: lane holds rows i = 4 kq + r -> co = 2 kq + (r >> 1), ex = r & 1 of cell p
+  auto epilogue = [&](int item, const f32x4 (&res)[NCT][2][2]) {
+    const int split = item % T::NSPLIT, cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
 #pragma unroll
-  for (int c = 0; c < NCT; ++c)
+    for (int c = 0; c < NCT; ++c) {
+      const int tl = split * T::CPW + c * T::NW + wave;
+      const int p = 16 * tl + j;
+      if (tl >= NPT || p >= NCELL * NCELL) continue;
+      const int cy = p / NCELL, cx = p % NCELL;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[c][e >> 1][e & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int tl[NCT];
-  int colbase[NCT];
+      for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
-  for (int c = 0; c < NCT; ++c) {
-    tl[c] = split * T::CPW + c * T::NW + wave;                 // wave-uniform
-    // cell p = 16 tl + j reads plane word (cy - jy + 2) NCELL + cx - jx + 2 = p + 2 NCELL + 2 - jy NCELL - jx
-    // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
-    colbase[c] = kq * CS + 16 * min(tl[c], NPT - 1) + j + 2 * NCELL + 2;
-  }
+        for (int ey = 0; ey < 2; ++ey) {
+          const int oz = 2 * cz + ez, oy = 2 * cy + ey;
+          if (oz >= NOUT || oy >= NOUT) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 2 * kq + (r >> 1), ox = 2 * cx + (r & 1);
+            if (ox < NOUT)
+              y[((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
+                  nvf_act(res[c][ez][ey][r] + (bias ? bias[co] : 0.f), act);
+          }
+        }
+    }
+  };
 #pragma unroll 1
-  for (int g = 0; g < NG; ++g) {
-    const float* xg = xs + g * 4 * CS;
-    const float* ag = as + g * kAPerGroup * 64 + lane;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int split = item % T::NSPLIT;
+    __syncthreads();                                           // zero fill done / the previous item's reads done
+    store_x();
+    __syncthreads();
+    if (item + (int)gridDim.x < items) load_x(item + gridDim.x);
+    f32x4 acc[NCT][2][2];
 #pragma unroll
-    for (int jy = 0; jy < 3; ++jy)
+    for (int c = 0; c < NCT; ++c)
 #pragma unroll
-      for (int jx = 0; jx < 3; ++jx)
+      for (int e = 0; e < 4; ++e) acc[c][e >> 1][e & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int colbase[NCT];
 #pragma unroll
-        for (int jz = 0; jz < 3; ++jz) {
-          float a[2][2];
+    for (int c = 0; c < NCT; ++c) {
+      const int tl = split * T::CPW + c * T::NW + wave;          // wave-uniform
+      // cell p = 16 tl + j reads plane word (cy - jy + 2) NCELL + cx - jx + 2 = p + 2 NCELL + 2 - jy NCELL - jx
+      // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
+      colbase[c] = kq * CS + 16 * min(tl, NPT - 1) + j + 2 * NCELL + 2;
+    }
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      const float* xg = xs + g * 4 * CS;
+      const float* ag = as + g * kAPerGroup * 64 + lane;
 #pragma unroll
-          for (int ez = 0; ez < 2; ++ez)
+      for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
-            for (int ey = 0; ey < 2; ++ey)
-              a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey) ? ag[a_index(ez, ey, jz, jy, jx) * 64] : 0.f;
+        for (int jx = 0; jx < 3; ++jx)
 #pragma unroll
-          for (int c = 0; c < NCT; ++c) {
-            const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // input plane cz - jz
+          for (int jz = 0; jz < 3; ++jz) {
+            float a[2][2];
 #pragma unroll
             for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
               for (int ey = 0; ey < 2; ++ey)
-                if (jz <= 2 - ez && jy <= 2 - ey)
-                  acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
+                a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey) ? ag[a_index(ez, ey, jz, jy, jx) * 64] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+              const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // input plane cz - jz
+#pragma unroll
+              for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+                for (int ey = 0; ey < 2; ++ey)
+                  if (jz <= 2 - ez && jy <= 2 - ey)
+                    acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
+            }
           }
-        }
-  }
-  // ---- epilogue: lane holds rows i = 4 kq + r -> co = 2 kq + (r >> 1), ex = r & 1 of cell p
-  const size_t cstride = (size_t)NOUT * NOUT * NOUT;
-#pragma unroll
-  for (int c = 0; c < NCT; ++c) {
-    const int p = 16 * tl[c] + j;
-    if (tl[c] >= NPT || p >= NCELL * NCELL) continue;
-    const int cy = p / NCELL, cx = p % NCELL;
-#pragma unroll
-    for (int ez = 0; ez < 2; ++ez)
-#pragma unroll
-      for (int ey = 0; ey < 2; ++ey) {
-        const int oz = 2 * cz + ez, oy = 2 * cy + ey;
-        if (oz >= NOUT || oy >= NOUT) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = 2 * kq + (r >> 1), ox = 2 * cx + (r & 1);
-          if (ox < NOUT)
-            y[((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
-                nvf_act(acc[c][ez][ey][r] + (bias ? bias[co] : 0.f), act);
-        }
-      }
+    }
+    epilogue(item, acc);
   }
 }
 
@@ -200,7 +220,9 @@ extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const floa
 #define NVF_TM(VAR, CI, NIN, NCT, NSPLIT)                                                              \
   if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
     using T = TMCfg<CI, NIN, NCT, NSPLIT>;                                                             \
-    convT_k5s2_mfma<T><<<batch * T::NCELL * NSPLIT, 256, 0, s>>>(x, wp, bias, y, act);                 \
+    const int items = batch * T::NCELL * NSPLIT;                                                       \
+    constexpr int cap = 512;                               /* two resident workgroups per CU */        \
+    convT_k5s2_mfma<T><<<items < cap ? items : cap, 256, 0, s>>>(x, wp, bias, y, act, items);          \
     rc = NVF_OK;                                                                                       \
   }
   NVF_TM(0, 8, 16, 2, 3)     // up2: 21 column tiles per cell plane, 8 per workgroup

@@ -72,7 +72,9 @@ struct WCfg {
   static constexpr int QRS = mod32(QX, KS % 32);              // row stride
   static constexpr int QPS = mod32(QY * QRS, (KS * KS) % 32); // plane stride
   static constexpr int QCS = QZ * QPS;                        // channel stride
-  static constexpr int LDSF = NB * QCS;
+  static constexpr int PT = A * TZ * TY * TX;                  // the p tile [a][iz][iy][ix], read back as broadcasts
+  static constexpr int POFF = (NB * QCS + 3) / 4 * 4;
+  static constexpr int LDSF = POFF + PT;
   static_assert(TX % 4 == 0, "p rows are read four at a time");
   static_assert(NT <= 1024, "workgroup size");
   static_assert(LDSF * 4 <= 160 * 1024, "LDS");
@@ -116,13 +118,21 @@ __device__ __forceinline__ void wgrad_tiled_body(const float* __restrict__ p, co
           const int yy = r % QY, t2 = r / QY, zz = t2 % QZ, c = t2 / QZ;
           return c * QCS + zz * QPS + yy * QRS + xx;
         });
-    __syncthreads();
+    // the p tile goes through LDS as well: every lane needs the same p values, and fetching them with scalar loads
+    // in the tap loop is a chain of exposed memory latencies (one per row)
     const float* pn = p + (size_t)n * A * d.dp * pplane;
+    float* pl = lds + C::POFF;
+    for (int i = tid; i < C::PT / 4; i += NT) {
+      const int xq = i % (TX / 4), r = i / (TX / 4), iy = r % TY, t2 = r / TY, iz = t2 % TZ, a = t2 / TZ;
+      *(float4*)(pl + 4 * i) =
+          *(const float4*)(pn + ((size_t)a * d.dp + z0 + iz) * pplane + (size_t)(y0 + iy) * d.wp + x0 + 4 * xq);
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int iz = 0; iz < TZ; ++iz) {
 #pragma unroll 1
       for (int iy = 0; iy < TY; ++iy) {
-        const float* prow = pn + ((size_t)(z0 + iz) * d.hp + (y0 + iy)) * d.wp + x0;  // wave-uniform
+        const float* prow = pl + (iz * TY + iy) * TX;                                  // wave-uniform LDS address
         const float* qrow = lds + lane_off + iz * S * QPS + iy * S * QRS;
 #pragma unroll C::IXU
         for (int ix = 0; ix < TX; ix += 4) {
@@ -131,7 +141,7 @@ __device__ __forceinline__ void wgrad_tiled_body(const float* __restrict__ p, co
           for (int j = 0; j < 4; ++j) qv[j] = qrow[(ix + j) * S];
 #pragma unroll
           for (int a = 0; a < A; ++a) {
-            const float4 pv = *(const float4*)(prow + (size_t)a * d.dp * pplane + ix);  // scalar load
+            const float4 pv = *(const float4*)(prow + a * TZ * TY * TX + ix);           // broadcast ds_read_b128
             acc[a] = fmaf(pv.x, qv[0], acc[a]);
             acc[a] = fmaf(pv.y, qv[1], acc[a]);
             acc[a] = fmaf(pv.z, qv[2], acc[a]);
@@ -154,7 +164,7 @@ __device__ __forceinline__ void wgrad_tiled_body(const float* __restrict__ p, co
 template <class C>
 __global__ __launch_bounds__(C::NT) void wgrad_tiled(const float* __restrict__ p, const float* __restrict__ q,
                                                      float* __restrict__ slabs, WgDims d) {
-  __shared__ float lds[C::LDSF];
+  __shared__ __attribute__((aligned(16))) float lds[C::LDSF];
   wgrad_tiled_body<C>(p, q, slabs, d, blockIdx.x, blockIdx.y, lds);
 }
 
@@ -171,7 +181,7 @@ struct WgTiled2 {
 template <class C0, class C1>
 __global__ __launch_bounds__(C0::NT) void wgrad_tiled2_kernel(WgTiled2 m) {
   static_assert(C0::NT == C1::NT, "one workgroup size");
-  __shared__ float lds[C0::LDSF > C1::LDSF ? C0::LDSF : C1::LDSF];
+  __shared__ __attribute__((aligned(16))) float lds[C0::LDSF > C1::LDSF ? C0::LDSF : C1::LDSF];
   int bid = blockIdx.x;
   if (bid < m.nx[0] * m.ny[0]) { wgrad_tiled_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid % m.nx[0], bid / m.nx[0], lds); return; }
   bid -= m.nx[0] * m.ny[0];
