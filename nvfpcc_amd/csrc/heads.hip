@@ -13,7 +13,6 @@
 //   * give each thread four consecutive x outputs, so one row segment (a b128 plus two b32 LDS
 //     reads) feeds 12 FMAs per input channel.
 #include "nvf_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -87,15 +86,14 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const
   constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
   const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
-  const int dbg = act >> 8; act &= 255;
   for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
-  if (dbg != 1) head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
+  head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
   __syncthreads();
   if (tid >= H::NACT) return;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int c = 0; c < (dbg == 2 ? 0 : C); ++c)
+  for (int c = 0; c < C; ++c)
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
@@ -430,7 +428,7 @@ extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, co
     m.a[h] = xs[h]; m.w[h] = ws[h]; m.bias[h] = biases[h]; m.out[h] = ps[h];
   }
   m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
-  m.act = act | ((getenv("NVF_HEAD_DBG") ? atoi(getenv("NVF_HEAD_DBG")) : 0) << 8);  // EXPERIMENT
+  m.act = act;
   heads3_fwd_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
   NVF_LAUNCH_CHECK();
   return NVF_OK;

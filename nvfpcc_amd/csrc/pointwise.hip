@@ -571,18 +571,23 @@ __global__ void weight_rate_batch_final(WeightRateBatch b, const float* __restri
                                         const float* __restrict__ sigma, float* __restrict__ bits,
                                         float* __restrict__ dsigma, float* __restrict__ dmu,
                                         const float* __restrict__ g_dev, float g_host) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lanes take the chunk partials 64 apart (ascending), then a fixed-order wave sum
+  const int lane = threadIdx.x;
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
   float acc_s = 0.f, acc_m = 0.f;
   for (int l = 0; l < b.nlayers; ++l) {
     float tb = 0.f;
-    for (int wg = b.first_wg[l]; wg < b.first_wg[l + 1]; ++wg) {
+    for (int wg = b.first_wg[l] + lane; wg < b.first_wg[l + 1]; wg += 64) {
       tb += part[3 * wg];
       acc_s += part[3 * wg + 1];
       acc_m += part[3 * wg + 2];
     }
-    bits[l] = tb;
+    tb = nvf_wave_sum(tb);
+    if (lane == 0) bits[l] = tb;
   }
+  acc_s = nvf_wave_sum(acc_s);
+  acc_m = nvf_wave_sum(acc_m);
+  if (lane != 0) return;
   const float sraw = sigma[0];
   const float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
   if (dsigma) dsigma[0] = g * acc_s * sgn;
@@ -608,7 +613,7 @@ extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* 
   }
   b.nlayers = nlayers;
   long chunk = (total + 255) / 256;          // <= ~256 + nlayers workgroups
-  if (chunk < 1024) chunk = 1024;
+  if (chunk < 256) chunk = 256;              // at least one element per thread
   b.chunk = (int)chunk;
   int wg = 0;
   for (int i = 0; i < nlayers; ++i) {
@@ -688,6 +693,25 @@ struct FocalMulti {
   int nwg[3];
 };
 
+__device__ __forceinline__ float focal_elem(float pv, float gv, float dv, bool has_dist, float a1, float a0, float beta,
+                                            int chain_sigmoid, float& dp) {
+  const bool occ = gv != 0.f;
+  const float F = occ ? pv : 1.f - pv;
+  const float at = occ ? a1 : a0;
+  float w = 1.f;
+  if (has_dist) w = dv + (occ ? beta : 0.f);
+  const float Fc = fmaxf(F, 1e-9f);
+  const float om = 1.f - Fc;
+  const float lg = logf(Fc);
+  float d = 0.f;
+  if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
+  const float dd = occ ? d : -d;
+  dp = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
+  return -1.f * at * (om * om) * w * lg;
+}
+
+// every thread takes float4 groups (all loads of a group in flight together); a thread's terms are added in index
+// order, the block sum is the fixed-order nvf_block_sum
 __global__ __launch_bounds__(256) void focal_multi_kernel(FocalMulti m, float* __restrict__ part, int chain_sigmoid) {
   __shared__ float red[16];
   const int t = blockIdx.y;
@@ -698,24 +722,23 @@ __global__ __launch_bounds__(256) void focal_multi_kernel(FocalMulti m, float* _
   float* dp = m.dp[t];
   const float a1 = m.alpha[t], a0 = 1.f - m.alpha[t], beta = m.beta[t];
   float s = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m.n[t]; i += (long)m.nwg[t] * blockDim.x) {
-    float pv = p[i], gv = gt[i];
-    bool occ = gv != 0.f;
-    float F = occ ? pv : 1.f - pv;
-    float at = occ ? a1 : a0;
-    float w = 1.f;
-    if (dist) w = dist[i] + (occ ? beta : 0.f);
-    float Fc = fmaxf(F, 1e-9f);
-    float om = 1.f - Fc;
-    float lg = logf(Fc);
-    s += -1.f * at * (om * om) * w * lg;
-    if (dp) {
-      float d = 0.f;
-      if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
-      float dd = occ ? d : -d;
-      dp[i] = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
-    }
+  const long n4 = m.n[t] >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)m.nwg[t] * blockDim.x) {
+    const float4 pv = ((const float4*)p)[i], gv = ((const float4*)gt)[i];
+    const float4 dv = dist ? ((const float4*)dist)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    s += focal_elem(pv.x, gv.x, dv.x, dist != nullptr, a1, a0, beta, chain_sigmoid, o.x);
+    s += focal_elem(pv.y, gv.y, dv.y, dist != nullptr, a1, a0, beta, chain_sigmoid, o.y);
+    s += focal_elem(pv.z, gv.z, dv.z, dist != nullptr, a1, a0, beta, chain_sigmoid, o.z);
+    s += focal_elem(pv.w, gv.w, dv.w, dist != nullptr, a1, a0, beta, chain_sigmoid, o.w);
+    if (dp) ((float4*)dp)[i] = o;
   }
+  if (blockIdx.x == 0)                                         // tail (n not a multiple of four)
+    for (long i = 4 * n4 + threadIdx.x; i < m.n[t]; i += blockDim.x) {
+      float o;
+      s += focal_elem(p[i], gt[i], dist ? dist[i] : 0.f, dist != nullptr, a1, a0, beta, chain_sigmoid, o);
+      if (dp) dp[i] = o;
+    }
   float tot = nvf_block_sum(s, red);
   if (threadIdx.x == 0) part[t * kLossMaxWG + blockIdx.x] = tot;
 }
@@ -742,7 +765,9 @@ extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* 
     if (!ps[t] || !gts[t] || ns[t] <= 0) return NVF_EINVAL;
     m.p[t] = ps[t]; m.gt[t] = gts[t]; m.dist[t] = dists ? dists[t] : nullptr; m.dp[t] = dps ? dps[t] : nullptr;
     m.alpha[t] = alphas[t]; m.beta[t] = betas ? betas[t] : 0.f; m.n[t] = (long)ns[t];
-    int nwg = (int)((ns[t] + 256 * 8 - 1) / (256 * 8));
+    if ((((uintptr_t)ps[t] | (uintptr_t)gts[t] | (uintptr_t)m.dist[t] | (uintptr_t)m.dp[t]) & 15) != 0)
+      return NVF_EINVAL;                                        // float4 access
+    int nwg = (int)((ns[t] + 256 * 4 - 1) / (256 * 4));        // one float4 group per thread up to kLossMaxWG groups
     if (nwg > kLossMaxWG) nwg = kLossMaxWG;
     m.nwg[t] = nwg;
     if (nwg > maxwg) maxwg = nwg;

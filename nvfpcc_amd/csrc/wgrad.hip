@@ -16,7 +16,6 @@
 // writes one partial slab and a second kernel adds the slabs in a fixed order, so the
 // result is reproducible run to run (no float atomics).
 #include "nvf_common.h"
-#include <cstdlib>
 
 static const int kMaxSlabs = 512;
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
@@ -298,11 +297,11 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
     (void)y0; (void)z0;
     __syncthreads();                                        // zero fill done / previous item no longer being read
-    if (d.pad != 1 || item == first) store();
+    store();
     __syncthreads();
-    if (item + 1 < last && d.pad != 1) load(item + 1);
+    if (item + 1 < last) load(item + 1);
 #pragma unroll 1
-    for (int row = wave; row < (d.pad == 2 ? 0 : TZ * TY); row += 4) {
+    for (int row = wave; row < TZ * TY; row += 4) {
       const int zz = row / TY, yy = row % TY;
       const float* pa = ldsG + laneA + row * GRS;
       const float* pb = ldsX + laneB + (zz * (TY + 3) + yy) * XRS;
@@ -364,7 +363,6 @@ static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* s
   int nslab = d.items < 256 ? d.items : 256;
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
-  d.pad = getenv("NVF_WG_DBG") ? atoi(getenv("NVF_WG_DBG")) : 0;  // EXPERIMENT
   wgrad_k4_mfma<C><<<nslab, 256, 0, s>>>(g, x, slabs, d);
   if (defer_nslab) *defer_nslab = nslab;
   else wgrad_reduce<<<(4096 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 4096, accumulate);
@@ -468,10 +466,10 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
 #pragma unroll 1
   for (int item = first; item < last; ++item) {
     __syncthreads();
-    if (d.pad != 1 || item == first) store();
+    store();
     __syncthreads();
-    if (item + 1 < last && d.pad != 1) load(item + 1);
-    if (d.pad != 2) {
+    if (item + 1 < last) load(item + 1);
+    {
       // 20 steps (row r, x group xg); the operands of step s + 1 are fetched while the 10 MFMAs of step s issue.
       // The rows shifted by sA = 1 need ix = 15 from a fifth x group.
       constexpr int NXG = W / 4 + 1, NSTEP = TZ * TY * NXG;
@@ -563,7 +561,10 @@ extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* cons
     m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j];
     WgDims d{};
     d.batch = batch; d.bc = 8; d.items = items[j];
-    static const int cap = getenv("NVF_WG3_CAP") ? atoi(getenv("NVF_WG3_CAP")) : 256;
+    // slabs (= workgroups) per job: two workgroups share a CU, so conv2 (the longest) gets one per CU and the other
+    // two half of that -- fewer slabs to add up afterwards, same launch time
+    constexpr int caps[3] = {256, 128, 128};
+    const int cap = caps[j];
     int n = items[j] < cap ? items[j] : cap;
     d.items_per_wg = (items[j] + n - 1) / n;
     n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
@@ -581,7 +582,6 @@ static int launch_wgrad_s2k5(const float* x, const float* g, float* dw, float* s
   int nslab = d.items < 256 ? d.items : 256;                 // one workgroup per CU
   d.items_per_wg = (d.items + nslab - 1) / nslab;
   nslab = (d.items + d.items_per_wg - 1) / d.items_per_wg;
-  d.pad = getenv("NVF_WG_DBG") ? atoi(getenv("NVF_WG_DBG")) : 0;  // EXPERIMENT
   wgrad_s2k5_mfma<C><<<nslab, 256, 0, s>>>(x, g, slabs, d);
   if (defer_nslab) *defer_nslab = nslab;
   else wgrad_reduce<<<(8000 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 8000, accumulate);

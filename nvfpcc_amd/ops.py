@@ -340,7 +340,7 @@ class WgradBatch:
         _f32(*ps, *qs, *outs)
         B = ps[0].shape[0]
         jt = (4096, 8000, 4096)
-        sizes = [(1024 * j * 4 + 255) // 256 * 256 for j in jt]
+        sizes = [(256 * j * 4 + 255) // 256 * 256 for j in jt]
         if self.offset + sum(sizes) > self.ws.numel():
             if self.jobs:
                 self.finish()

@@ -447,6 +447,32 @@ def test_focal_losses_match_reference_goldens(ops, golden_dir):
         np.testing.assert_allclose(m[4:6], G[name + "/sse1"], rtol=1e-5)
 
 
+def test_three_focal_terms_in_one_launch(ops, golden_dir):
+    """nvf_focal_loss_multi (float4 groups) against the single-term kernel and the reference goldens: the gradients
+    are elementwise and must be identical, the sums agree to fp32 summation-order tolerance."""
+    import os
+    from tests.golden_inputs import loss_case_inputs
+    G = np.load(os.path.join(golden_dir, "loss.npz"))
+    for name, (p, gt, dist) in loss_case_inputs().items():
+        for chain in (False, True):
+            out = torch.empty(4, device="cuda")
+            dps = ops.focal_loss_multi([(dev(p), dev(gt), dev(dist), 0.9, 1.0), (dev(p), dev(gt), None, 0.85, 0.0)],
+                                       out, chain_sigmoid=chain)
+            s1, d1 = ops.focal_loss(dev(p), dev(gt), dev(dist), 0.9, beta=1.0, want_grad=True, chain_sigmoid=chain)
+            s0, d0 = ops.focal_loss(dev(p), dev(gt), None, 0.85, want_grad=True, chain_sigmoid=chain)
+            assert torch.equal(dps[0], d1) and torch.equal(dps[1], d0), name
+            for got, ref in ((out[0].item(), float(G[name + "/surf"])), (out[1].item(), float(G[name + "/focal"]))):
+                assert abs(got - ref) <= 2e-5 * max(abs(ref), 1.0), name
+    # a length that is not a multiple of four goes through the scalar tail
+    n = 4 * 1000 + 3
+    p = torch.rand(n + 1, device="cuda")[:n].contiguous()
+    gt = (torch.rand(n, device="cuda") > 0.7).float()
+    out = torch.empty(4, device="cuda")
+    dps = ops.focal_loss_multi([(p, gt, None, 0.85, 0.0)], out, chain_sigmoid=False)
+    s0, d0 = ops.focal_loss(p, gt, None, 0.85, want_grad=True)
+    assert torch.equal(dps[0], d0) and abs(out[0].item() - s0.item()) <= 2e-5 * max(abs(s0.item()), 1.0)
+
+
 def test_small_elementwise(ops):
     g = gen(60)
     p = torch.rand(3, 1, 8, 8, 8, generator=g)
