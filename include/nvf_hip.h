@@ -258,6 +258,17 @@ int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const 
                           const float* sigma, const float* mu, float* bits, float* dsigma, float* dmu,
                           const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- deferred final passes ------------------------------------------------------
+ * nvf_focal_loss_multi, nvf_multi_channel_sum / nvf_wgrad_reduce_multi_and_sums and nvf_weight_rate_batch end with a
+ * tiny launch that adds per-workgroup partial sums in a fixed order.  Between nvf_finals_begin() and
+ * nvf_finals_flush(stream) those final passes (at most one of each kind; further ones are launched as usual) are
+ * queued and flush runs them in ONE launch on `stream`: their outputs (the loss terms, the bias gradients, the
+ * weight-rate bits and d/dsigma, d/dmu) exist only after the flush.  Same device code: identical results.  Used by
+ * the training step, where nothing reads those outputs before the optimiser (NVFPCC.py:161-223). */
+void nvf_finals_begin(void);
+int nvf_finals_flush(void* stream);
+void nvf_finals_cancel(void);   /* drop the queue without launching (error paths) */
+
 /* workspace (bytes) for the two-stage reductions of nvf_focal_loss / nvf_metrics */
 size_t nvf_reduce_workspace(void);
 

@@ -54,6 +54,9 @@ PROTOTYPES = {
     "nvf_multi_channel_sum_workspace": (Z, [I]),
     "nvf_multi_channel_sum": (I, [P, P, P, P, I, I, P, Z, P]),
     "nvf_wgrad_reduce_multi_and_sums": (I, [P, P, P, P, I, P, P, P, P, I, I, P, Z, P]),
+    "nvf_finals_begin": (None, []),
+    "nvf_finals_flush": (I, [P]),
+    "nvf_finals_cancel": (None, []),
     "nvf_gdn_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "nvf_gdn_bwd_workspace": (Z, [I]),
     "nvf_gdn_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),

@@ -1,0 +1,91 @@
+// Deferred "final" passes.  Several reductions of a training step are two launches: workgroups write partial sums,
+// then one tiny launch adds them in a fixed order (the focal terms, the bias-gradient channel sums, the weight-rate
+// term).  Every launch of a dependent chain costs ~5 us on this GPU whatever it does, and nothing inside the step
+// reads those results, so between nvf_finals_begin() and nvf_finals_flush() the final passes are queued instead of
+// launched and flush runs all of them in ONE launch.  Same device code either way: results are identical.
+#pragma once
+#include "nvf_common.h"
+
+static const int kLossMaxWG = 1024;
+
+// the three focal terms of the objective (main output + two heads, NVFPCC.py:166-184)
+struct FocalMulti {
+  const float* p[3];
+  const float* gt[3];
+  const float* dist[3];
+  float* dp[3];
+  float alpha[3], beta[3];
+  long n[3];
+  int nwg[3];
+};
+
+// per-channel sums of up to 12 tensors [batch, c, spatial] (the bias gradients)
+struct MultiSumDesc {
+  const float* x[12];
+  float* out[12];
+  int32_t c[12], spatial[12], chan_base[12];
+  int32_t ntensors, batch, total_channels, nchunk;
+};
+
+// rate term of all quantised kernels of the decoder
+struct WeightRateBatch {
+  const float* kernel[8];
+  float* dk[8];
+  int32_t n[8];
+  int32_t first_wg[9];   // workgroups [first_wg[l], first_wg[l+1]) belong to layer l
+  int32_t nlayers, chunk;
+};
+
+// one wave per loss term: lanes take the partials 64 apart (ascending), then a fixed-order wave sum
+__device__ __forceinline__ void focal_multi_final_body(const FocalMulti& m, const float* __restrict__ part,
+                                                       float* __restrict__ loss, int nterm, int tid) {
+  const int t = tid >> 6, lane = tid & 63;
+  if (t >= nterm) return;
+  float s = 0.f;
+  for (int g = lane; g < m.nwg[t]; g += 64) s += part[t * kLossMaxWG + g];
+  s = nvf_wave_sum(s);
+  if (lane == 0) loss[t] = s;
+}
+
+__device__ __forceinline__ void multi_channel_sum_final_body(const MultiSumDesc& d, const float* __restrict__ part,
+                                                             int gch) {
+  if (gch >= d.total_channels) return;
+  int t = 0;
+  while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
+  float s = 0.f;
+  for (int g = 0; g < d.nchunk; ++g) s += part[(size_t)g * d.total_channels + gch];
+  d.out[t][gch - d.chan_base[t]] = s;
+}
+
+// one wave: lanes take the chunk partials 64 apart (ascending), then a fixed-order wave sum
+__device__ __forceinline__ void weight_rate_batch_final_body(const WeightRateBatch& b, const float* __restrict__ part,
+                                                             const float* __restrict__ sigma, float* __restrict__ bits,
+                                                             float* __restrict__ dsigma, float* __restrict__ dmu,
+                                                             const float* __restrict__ g_dev, float g_host, int lane) {
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  float acc_s = 0.f, acc_m = 0.f;
+  for (int l = 0; l < b.nlayers; ++l) {
+    float tb = 0.f;
+    for (int wg = b.first_wg[l] + lane; wg < b.first_wg[l + 1]; wg += 64) {
+      tb += part[3 * wg];
+      acc_s += part[3 * wg + 1];
+      acc_m += part[3 * wg + 2];
+    }
+    tb = nvf_wave_sum(tb);
+    if (lane == 0) bits[l] = tb;
+  }
+  acc_s = nvf_wave_sum(acc_s);
+  acc_m = nvf_wave_sum(acc_m);
+  if (lane != 0) return;
+  const float sraw = sigma[0];
+  const float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
+  if (dsigma) dsigma[0] = g * acc_s * sgn;
+  if (dmu) dmu[0] = g * acc_m;
+}
+
+// Queue (finals.hip).  A push returns false when nothing is being deferred or a job of that kind is already waiting:
+// the caller then launches its own final pass as usual.
+bool nvf_finals_push_focal(const FocalMulti& m, const float* part, float* loss, int nterm);
+bool nvf_finals_push_sums(const MultiSumDesc& d, const float* part);
+bool nvf_finals_push_rate(const WeightRateBatch& b, const float* part, const float* sigma, float* bits, float* dsigma,
+                          float* dmu, const float* g_dev, float g_host);

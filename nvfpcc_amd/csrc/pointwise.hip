@@ -4,6 +4,7 @@
 // data with the gradient fused into the forward where the caller wants it, and fixed-order
 // two-stage reductions instead of float atomics so results are reproducible.
 #include "nvf_common.h"
+#include "finals.h"
 
 #define NVF_GRID(n, bs) ((unsigned)(((n) + (bs)-1) / (bs)))
 
@@ -526,13 +527,6 @@ extern "C" int nvf_weight_rate(const float* kernel, int n, const float* sigma, c
 // all quantised kernels of the decoder in two launches: workgroups own fixed chunks of one layer each and
 // write (bits, dsigma, dmu) partials; one workgroup then adds the partials in chunk order (reproducible).
 // dk is ADDED to the weight gradients already in place.
-struct WeightRateBatch {
-  const float* kernel[8];
-  float* dk[8];
-  int32_t n[8];
-  int32_t first_wg[9];   // workgroups [first_wg[l], first_wg[l+1]) belong to layer l
-  int32_t nlayers, chunk;
-};
 
 __global__ __launch_bounds__(256) void weight_rate_batch_kernel(WeightRateBatch b, const float* __restrict__ sigma,
                                                                 const float* __restrict__ mu,
@@ -571,27 +565,7 @@ __global__ void weight_rate_batch_final(WeightRateBatch b, const float* __restri
                                         const float* __restrict__ sigma, float* __restrict__ bits,
                                         float* __restrict__ dsigma, float* __restrict__ dmu,
                                         const float* __restrict__ g_dev, float g_host) {
-  // one wave: lanes take the chunk partials 64 apart (ascending), then a fixed-order wave sum
-  const int lane = threadIdx.x;
-  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
-  float acc_s = 0.f, acc_m = 0.f;
-  for (int l = 0; l < b.nlayers; ++l) {
-    float tb = 0.f;
-    for (int wg = b.first_wg[l] + lane; wg < b.first_wg[l + 1]; wg += 64) {
-      tb += part[3 * wg];
-      acc_s += part[3 * wg + 1];
-      acc_m += part[3 * wg + 2];
-    }
-    tb = nvf_wave_sum(tb);
-    if (lane == 0) bits[l] = tb;
-  }
-  acc_s = nvf_wave_sum(acc_s);
-  acc_m = nvf_wave_sum(acc_m);
-  if (lane != 0) return;
-  const float sraw = sigma[0];
-  const float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
-  if (dsigma) dsigma[0] = g * acc_s * sgn;
-  if (dmu) dmu[0] = g * acc_m;
+  weight_rate_batch_final_body(b, part, sigma, bits, dsigma, dmu, g_dev, g_host, threadIdx.x);
 }
 
 extern "C" size_t nvf_weight_rate_batch_workspace(void) { return (size_t)3 * 512 * sizeof(float); }
@@ -624,7 +598,8 @@ extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* 
   if (wg > 512) return NVF_EINVAL;
   hipStream_t s = nvf_stream(stream);
   weight_rate_batch_kernel<<<wg, 256, 0, s>>>(b, sigma, mu, (float*)workspace, g_dev, g_host);
-  weight_rate_batch_final<<<1, 64, 0, s>>>(b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host);
+  if (!nvf_finals_push_rate(b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host))
+    weight_rate_batch_final<<<1, 64, 0, s>>>(b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -632,7 +607,6 @@ extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* 
 // ---------------------------------------------------------------------------
 // focal losses fused with their gradient (utils/loss.py:61-72, 94-111)
 // ---------------------------------------------------------------------------
-static const int kLossMaxWG = 1024;
 
 __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ p, const float* __restrict__ gt,
                                                     const float* __restrict__ dist, float alpha, float beta,
@@ -683,15 +657,6 @@ extern "C" int nvf_focal_loss(const float* p, const float* gt, const float* dist
 }
 
 // the three focal terms of the objective (main output + two heads, NVFPCC.py:166-184) in one launch pair
-struct FocalMulti {
-  const float* p[3];
-  const float* gt[3];
-  const float* dist[3];
-  float* dp[3];
-  float alpha[3], beta[3];
-  long n[3];
-  int nwg[3];
-};
 
 __device__ __forceinline__ float focal_elem(float pv, float gv, float dv, bool has_dist, float a1, float a0, float beta,
                                             int chain_sigmoid, float& dp) {
@@ -743,14 +708,8 @@ __global__ __launch_bounds__(256) void focal_multi_kernel(FocalMulti m, float* _
   if (threadIdx.x == 0) part[t * kLossMaxWG + blockIdx.x] = tot;
 }
 
-// one wave per loss term: lanes take the partials 64 apart (ascending), then a fixed-order wave sum
 __global__ void focal_multi_final(FocalMulti m, const float* __restrict__ part, float* __restrict__ loss, int nterm) {
-  const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (t >= nterm) return;
-  float s = 0.f;
-  for (int g = lane; g < m.nwg[t]; g += 64) s += part[t * kLossMaxWG + g];
-  s = nvf_wave_sum(s);
-  if (lane == 0) loss[t] = s;
+  focal_multi_final_body(m, part, loss, nterm, threadIdx.x);
 }
 
 extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const float* const* dists,
@@ -774,7 +733,8 @@ extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* 
   }
   hipStream_t s = nvf_stream(stream);
   focal_multi_kernel<<<dim3(maxwg, nterm), 256, 0, s>>>(m, (float*)workspace, chain_sigmoid);
-  focal_multi_final<<<1, 64 * nterm, 0, s>>>(m, (const float*)workspace, loss, nterm);
+  if (!nvf_finals_push_focal(m, (const float*)workspace, loss, nterm))
+    focal_multi_final<<<1, 64 * nterm, 0, s>>>(m, (const float*)workspace, loss, nterm);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

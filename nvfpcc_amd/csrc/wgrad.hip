@@ -16,6 +16,7 @@
 // writes one partial slab and a second kernel adds the slabs in a fixed order, so the
 // result is reproducible run to run (no float atomics).
 #include "nvf_common.h"
+#include "finals.h"
 
 static const int kMaxSlabs = 512;
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
@@ -885,12 +886,6 @@ extern "C" int nvf_channel_sum(const float* x, float* out, void* workspace, size
 // ---------------------------------------------------------------------------
 // all bias gradients of a backward pass in two launches: out_i[c] = sum_{n,s} x_i[n,c,s] for up to 12 tensors
 // ---------------------------------------------------------------------------
-struct MultiSumDesc {
-  const float* x[12];
-  float* out[12];
-  int32_t c[12], spatial[12], chan_base[12];
-  int32_t ntensors, batch, total_channels, nchunk;
-};
 
 // `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
 // workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
@@ -946,13 +941,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
 }
 
 __global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part) {
-  const int gch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gch >= d.total_channels) return;
-  int t = 0;
-  while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
-  float s = 0.f;
-  for (int g = 0; g < d.nchunk; ++g) s += part[(size_t)g * d.total_channels + gch];
-  d.out[t][gch - d.chan_base[t]] = s;
+  multi_channel_sum_final_body(d, part, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 extern "C" size_t nvf_multi_channel_sum_workspace(int total_channels) {
@@ -980,7 +969,8 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
   if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
   multi_channel_sum_partial<<<dim3(base, d.nchunk), 256, 0, s>>>(d, (float*)workspace);
-  multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
+  if (!nvf_finals_push_sums(d, (const float*)workspace))
+    multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -1019,7 +1009,8 @@ extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float*
   if (workspace_bytes < nvf_multi_channel_sum_workspace(cb)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
   wgrad_reduce_and_sums<<<base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace);
-  multi_channel_sum_final<<<(cb + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
+  if (!nvf_finals_push_sums(d, (const float*)workspace))
+    multi_channel_sum_final<<<(cb + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -271,7 +271,14 @@ class TrainEngine:
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)
 
-    def backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
+    def backward(self, *args, **kw):
+        try:
+            return self._backward(*args, **kw)
+        except BaseException:
+            ops.finals_cancel()            # never leave the library queueing final passes
+            raise
+
+    def _backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
         """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g.
 
         Main stream: the backward-data chain.  Side stream: head backward-data (t0, t1), every weight gradient,
@@ -284,6 +291,11 @@ class TrainEngine:
             self._wg = ops.WgradBatch(self.dev)    # partial sums now, ONE reduction launch for all ten gradients
         loss = torch.empty(4, device=self.dev)   # [main, head0, head1, unused]
         nbits = torch.empty(7, device=self.dev)
+        # the one-block final passes of the focal terms, the bias sums and the weight rate feed nothing inside the
+        # step: queue them and run all three in one launch at the end (single-stream schedule only)
+        defer = want_w and not self.overlap
+        if defer:
+            ops.finals_begin()
         dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
                                               (a["p1"], gt16, None, 0.85, 0.0)], loss)
         ev_t1 = ev_t0 = None
@@ -387,6 +399,8 @@ class TrainEngine:
                                       g_host=g_net * self.rate_grad_scale)
             else:
                 ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
+            if defer:
+                ops.finals_flush()
         if self.overlap:
             main.wait_stream(self.side)      # join: nothing below (Adam, frees) may pass the side work
         self.last = {"loss_terms": loss, "latent_bits": a["lbits"], "net_bits": nbits, "n_pts": n_pts}

@@ -529,6 +529,21 @@ def weight_rate(kernel, sigma, mu, bits_out=None, dk=None, dsigma=None, dmu=None
     return bits
 
 
+def finals_begin():
+    """Queue the final passes of focal_loss_multi / WgradBatch.finish_with_sums / weight_rate_batch (their outputs
+    exist only after finals_flush); see include/nvf_hip.h."""
+    lib().nvf_finals_begin()
+
+
+def finals_cancel():
+    lib().nvf_finals_cancel()
+
+
+def finals_flush():
+    """Run the queued final passes in one launch on the current stream."""
+    check(lib().nvf_finals_flush(_stream()), "nvf_finals_flush")
+
+
 def weight_rate_batch(kernels, dks, sigma, mu, bits, dsigma=None, dmu=None, g_dev=None, g_host=1.0):
     """bits[l] for every kernel; dks[l] (or None) += g dbits/dk; dsigma/dmu overwritten with the layer sum."""
     import ctypes

@@ -473,6 +473,42 @@ def test_three_focal_terms_in_one_launch(ops, golden_dir):
     assert torch.equal(dps[0], d0) and abs(out[0].item() - s0.item()) <= 2e-5 * max(abs(s0.item()), 1.0)
 
 
+def test_deferred_final_passes_equal_immediate_ones(ops):
+    """finals_begin / finals_flush: the focal, bias-sum and weight-rate final passes queued into one launch give
+    bit for bit what the separate launches give; nothing is written before the flush."""
+    torch.manual_seed(3)
+    B = 4
+    p = torch.rand(B, 1, 16, 16, 16, device="cuda")
+    gt = (torch.rand_like(p) > 0.8).float()
+    dist = torch.rand_like(p)
+    xs = [torch.randn(B, 8, 12, 12, 12, device="cuda"), torch.randn(B, 16, 5, 5, 5, device="cuda")]
+    ks = [torch.randn(8, 8, 4, 4, 4, device="cuda") * 0.2, torch.randn(16, 8, 5, 5, 5, device="cuda") * 0.2]
+    sigma, mu = torch.tensor([0.3], device="cuda"), torch.tensor([0.01], device="cuda")
+
+    def run(defer):
+        loss = torch.full((4,), -7.0, device="cuda")
+        outs = [torch.full((x.shape[1],), -7.0, device="cuda") for x in xs]
+        dks = [torch.zeros_like(k) for k in ks]
+        bits = torch.full((2,), -7.0, device="cuda")
+        ds, dm = torch.full((1,), -7.0, device="cuda"), torch.full((1,), -7.0, device="cuda")
+        if defer:
+            ops.finals_begin()
+        dps = ops.focal_loss_multi([(p, gt, dist, 0.9, 1.0), (p, gt, None, 0.85, 0.0)], loss)
+        ops.multi_channel_sum(xs, outs)
+        ops.weight_rate_batch(ks, dks, sigma, mu, bits, ds, dm, g_host=0.5)
+        if defer:
+            torch.cuda.synchronize()
+            assert loss[0].item() == -7.0 and bits[0].item() == -7.0 and outs[0][0].item() == -7.0
+            ops.finals_flush()
+        torch.cuda.synchronize()
+        return [loss[:2].clone(), *outs, bits, ds, dm, *dps, *dks]
+
+    for got, ref in zip(run(True), run(False)):
+        assert torch.equal(got, ref)
+    # outside begin/flush nothing is queued, and a flush with an empty queue launches nothing
+    ops.finals_flush()
+
+
 def test_small_elementwise(ops):
     g = gen(60)
     p = torch.rand(3, 1, 8, 8, 8, generator=g)
