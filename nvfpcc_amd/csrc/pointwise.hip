@@ -74,14 +74,15 @@ struct NvfLayerDesc {
   int32_t nbias, pad_;
 };
 
-__global__ void prepare_weights_kernel(const NvfLayerDesc* __restrict__ table, int q, uint64_t seed, uint64_t step,
-                                       const uint64_t* __restrict__ step_dev) {
-  const NvfLayerDesc d = table[blockIdx.y];
+__device__ __forceinline__ void prepare_weights_body(const NvfLayerDesc* __restrict__ table, int q, uint64_t seed,
+                                                     uint64_t step, const uint64_t* __restrict__ step_dev, int layer,
+                                                     int bx, int nbx) {
+  const NvfLayerDesc d = table[layer];
   const int n = d.dim0 * d.dim1 * d.k3;
   const int qq = d.quantised ? q : 0;
   const uint64_t st = step + (step_dev ? step_dev[0] : 0ull);
   const uint64_t sid = (st << 8) | (uint64_t)d.layer_id;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + d.nbias; i += gridDim.x * blockDim.x) {
+  for (int i = bx * blockDim.x + threadIdx.x; i < n + d.nbias; i += nbx * blockDim.x) {
     if (i < n) {
       float k = d.kernel[i];
       if (qq == 1) k = k + (nvf_uniform01(seed, sid, (uint64_t)i) - 0.5f) * 0.0625f;
@@ -100,6 +101,11 @@ __global__ void prepare_weights_kernel(const NvfLayerDesc* __restrict__ table, i
       d.b_eff[j] = d.b[j] + d.b_init[j];
     }
   }
+}
+
+__global__ void prepare_weights_kernel(const NvfLayerDesc* __restrict__ table, int q, uint64_t seed, uint64_t step,
+                                       const uint64_t* __restrict__ step_dev) {
+  prepare_weights_body(table, q, seed, step, step_dev, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 extern "C" size_t nvf_layer_desc_size(void) { return sizeof(NvfLayerDesc); }
@@ -924,8 +930,8 @@ struct GatherMulti {
   int32_t n;
 };
 
-__global__ void gather_rows_multi_kernel(GatherMulti g, const int64_t* __restrict__ idx, int rows) {
-  const int t = blockIdx.y;
+__device__ __forceinline__ void gather_rows_multi_body(const GatherMulti& g, const int64_t* __restrict__ idx, int rows,
+                                                       int t, int bx, int nbx) {
   if (t >= g.n) return;
   const int width = g.width[t];
   const long total = (long)rows * width;
@@ -934,23 +940,26 @@ __global__ void gather_rows_multi_kernel(GatherMulti g, const int64_t* __restric
   if ((width & 3) == 0) {
     const long total4 = total >> 2;
     const int w4 = width >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total4; i += (long)nbx * blockDim.x) {
       const long r = i / w4;
       const int c = (int)(i - r * w4);
       ((float4*)dst)[i] = ((const float4*)src)[idx[r] * w4 + c];
     }
   } else {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)nbx * blockDim.x) {
       const long r = i / width;
       dst[i] = src[idx[r] * width + (i - r * width)];
     }
   }
 }
 
-extern "C" int nvf_gather_rows_multi(const float* const* srcs, float* const* dsts, const int* widths, int n,
-                                     const int64_t* idx, int rows, void* stream) {
-  if (!srcs || !dsts || !widths || !idx || n <= 0 || n > 6 || rows <= 0) return NVF_EINVAL;
-  GatherMulti g{};
+__global__ void gather_rows_multi_kernel(GatherMulti g, const int64_t* __restrict__ idx, int rows) {
+  gather_rows_multi_body(g, idx, rows, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+static int gather_multi_desc(const float* const* srcs, float* const* dsts, const int* widths, int n, int rows,
+                             GatherMulti& g, long& wg) {
+  if (!srcs || !dsts || !widths || n <= 0 || n > 6 || rows <= 0) return NVF_EINVAL;
   long biggest = 0;
   for (int t = 0; t < n; ++t) {
     if (!srcs[t] || !dsts[t] || widths[t] <= 0) return NVF_EINVAL;
@@ -958,10 +967,44 @@ extern "C" int nvf_gather_rows_multi(const float* const* srcs, float* const* dst
     if ((long)rows * widths[t] > biggest) biggest = (long)rows * widths[t];
   }
   g.n = n;
-  long wg = (biggest / 4 + 255) / 256;
+  wg = (biggest / 4 + 255) / 256;
   if (wg > 1024) wg = 1024;
   if (wg < 1) wg = 1;
+  return NVF_OK;
+}
+
+extern "C" int nvf_gather_rows_multi(const float* const* srcs, float* const* dsts, const int* widths, int n,
+                                     const int64_t* idx, int rows, void* stream) {
+  if (!idx) return NVF_EINVAL;
+  GatherMulti g{};
+  long wg = 0;
+  const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
+  if (rc != NVF_OK) return rc;
   gather_rows_multi_kernel<<<dim3((unsigned)wg, n), 256, 0, nvf_stream(stream)>>>(g, idx, rows);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// The first two launches of a training step -- the effective weights of every layer and the gather of the
+// mini-batch rows -- are independent: one launch.  Workgroups [0, 16 nlayers) prepare the weights, the rest gather.
+__global__ void prepare_and_gather_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q, uint64_t seed,
+                                          uint64_t step, const uint64_t* __restrict__ step_dev, GatherMulti g,
+                                          const int64_t* __restrict__ idx, int rows, int gwg) {
+  const int bid = blockIdx.x, np = 16 * nlayers;
+  if (bid < np) { prepare_weights_body(table, q, seed, step, step_dev, bid >> 4, bid & 15, 16); return; }
+  gather_rows_multi_body(g, idx, rows, (bid - np) / gwg, (bid - np) % gwg, gwg);
+}
+
+extern "C" int nvf_prepare_weights_and_gather(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
+                                              const uint64_t* step_dev, const float* const* srcs, float* const* dsts,
+                                              const int* widths, int n, const int64_t* idx, int rows, void* stream) {
+  if (!table_dev || nlayers <= 0 || !idx) return NVF_EINVAL;
+  GatherMulti g{};
+  long wg = 0;
+  const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
+  if (rc != NVF_OK) return rc;
+  prepare_and_gather_kernel<<<16 * nlayers + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
+      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, g, idx, rows, (int)wg);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

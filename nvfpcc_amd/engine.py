@@ -174,6 +174,22 @@ class TrainEngine:
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.dev)
         self.nlayers = len(mods)
 
+    def batch_and_prepare(self, idx_dev, q):
+        """_batch(idx_dev) and prepare_weights(q) with their first launches (row gather, effective weights) as one."""
+        import ctypes
+        srcs = [self.gt, self.dist, self.gt16, self.gt8, self.emb]
+        n, rows = len(srcs), idx_dev.numel()
+        dsts = [torch.empty((rows,) + tuple(s.shape[1:]), device=s.device) for s in srcs]
+        sd = self._step_dev
+        check(lib().nvf_prepare_weights_and_gather(
+            self.table.data_ptr(), self.nlayers, int(q), self.seed, 0 if sd is not None else self.noise_step,
+            None if sd is None else sd.data_ptr(), (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
+            (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_int * n)(*[s[0].numel() for s in srcs]), n,
+            idx_dev.data_ptr(), rows, torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights_and_gather")
+        if self._mfma_jobs:
+            ops.pack_mfma_all(self._mfma_jobs)
+        return dsts
+
     def prepare_weights(self, q):
         sd = self._step_dev
         check(lib().nvf_prepare_weights(self.table.data_ptr(), self.nlayers, int(q), self.seed,
@@ -422,8 +438,7 @@ class TrainEngine:
             self.noise_step += 1
         if n_pts is None:
             n_pts = float(self.counts[idx_host].sum())
-        gt, dist, gt16, gt8, e = self._batch(idx_dev)
-        self.prepare_weights(q)
+        gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q)
         a = self.forward(e, "train", idx_dev)
         self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False)
         if self.grad_hook is not None:
@@ -501,8 +516,7 @@ class GraphedTrainStep:
 
     def _body(self):
         eng = self.eng
-        gt, dist, gt16, gt8, e = eng._batch(self.idx)
-        eng.prepare_weights(self.q)
+        gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q)
         a = eng.forward(e, "train", self.idx)
         eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False)
         self.out = a
