@@ -318,11 +318,14 @@ int nvf_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int r
 int nvf_gather_rows_multi(const float* const* srcs, float* const* dsts, const int* widths, int n,
                           const int64_t* idx, int rows, void* stream);
 
-/* nvf_prepare_weights and nvf_gather_rows_multi (independent: the first two launches of a training step,
- * NVFPCC.py:149-160) in ONE launch; same results as the two calls. */
-int nvf_prepare_weights_and_gather(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
-                                   const uint64_t* step_dev, const float* const* srcs, float* const* dsts,
-                                   const int* widths, int n, const int64_t* idx, int rows, void* stream);
+/* The head of a training step (NVFPCC.py:149-160) in ONE launch: nvf_prepare_weights, nvf_pack_mfma_all and
+ * nvf_gather_rows_multi.  Pack job j packs layout pack_bwd[j] (0: w_fwd, 1: w_bwd) of layer-table row pack_layers[j]
+ * (kinds / c0s / c1s as in nvf_pack_mfma_all; npack may be 0); a packed element recomputes its effective weight from
+ * the raw kernel, so nothing in the launch waits for anything else.  Same results as the three calls, bit for bit. */
+int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                  float* const* pack_dsts, const int* pack_kinds, const int* pack_c0s, const int* pack_c1s,
+                  const int* pack_layers, const int* pack_bwd, int npack, const float* const* srcs,
+                  float* const* dsts, const int* widths, int n, const int64_t* idx, int rows, void* stream);
 
 /* U[0,1) floats, Philox4x32-10 keyed by (seed, stream_id), counter = element index */
 int nvf_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);

@@ -77,7 +77,7 @@ PROTOTYPES = {
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
     "nvf_gather_rows_multi": (I, [P, P, P, I, P, I, P]),
-    "nvf_prepare_weights_and_gather": (I, [P, I, I, U, U, P, P, P, P, I, P, I, P]),
+    "nvf_step_head": (I, [P, I, I, U, U, P, P, P, P, P, P, P, I, P, P, P, I, P, I, P]),
     "nvf_uniform": (I, [P, L, U, U, P]),
     "nvf_nearest_dist2": (I, [P, P, P, P, P, P, I, P]),
     "nvf_threshold_count": (I, [P, F, P, I, I, P]),

@@ -452,14 +452,12 @@ extern "C" int nvf_heads3_bwd_data(const float* const* dls, const float* const* 
 }
 
 // partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)
-extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* const* xs, float* const* slabs,
-                                        const int* cs, const int* ss, int batch, int max_slabs, int* nslabs,
-                                        void* stream) {
-  if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
-  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
-  using H0 = HWCfg<16, 8, 4, 8, 4>; using H1 = HWCfg<8, 16, 4, 4, 2>; using H2 = HWCfg<8, 32, 2, 8, 2>;
+template <class H2>
+static int launch_heads3_wgrad(const float* const* dls, const float* const* xs, float* const* slabs, int batch,
+                               int max_slabs, int* nslabs, void* stream) {
+  using H0 = HWCfg<16, 8, 4, 8, 4>; using H1 = HWCfg<8, 16, 4, 4, 2>;
   Heads3 m{};
-  const int items[3] = {batch * (8 / 4) * (8 / 8), batch * (16 / 4) * (16 / 4), batch * (32 / 2) * (32 / 8)};
+  const int items[3] = {batch * (8 / 4) * (8 / 8), batch * (16 / 4) * (16 / 4), batch * (32 / H2::TZ) * (32 / H2::TY)};
   for (int h = 0; h < 3; ++h) {
     if (!dls[h] || !xs[h] || !slabs[h]) return NVF_EINVAL;
     m.a[h] = dls[h]; m.w[h] = xs[h]; m.out[h] = slabs[h];
@@ -473,5 +471,15 @@ extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* co
   heads3_wgrad_kernel<H0, H1, H2><<<grid, 256, 0, nvf_stream(stream)>>>(m);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
+}
+
+extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* const* xs, float* const* slabs,
+                                        const int* cs, const int* ss, int batch, int max_slabs, int* nslabs,
+                                        void* stream) {
+  if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
+  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
+  // the big head in 2 x 8-row tiles: larger tiles (4 x 8, 2 x 16, 8 x 8) re-read less halo but were 10-30 % slower --
+  // the kernel is bound by how many staging round trips are in flight, not by bytes
+  return launch_heads3_wgrad<HWCfg<8, 32, 2, 8, 2>>(dls, xs, slabs, batch, max_slabs, nslabs, stream);
 }
 

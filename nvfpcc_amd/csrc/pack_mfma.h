@@ -1,0 +1,70 @@
+// Device side of nvf_pack_mfma_all, shared with the one-launch head of the training step (pointwise.hip): all MFMA
+// A-fragment packings of a step.  `src(job, i)` yields element i of the job's source weight layout.
+#pragma once
+#include "nvf_common.h"
+
+struct PackJobs {
+  const float* src[8];
+  float* dst[8];
+  int32_t kind[8], c0[8], c1[8], total[8];
+  int32_t layer[8], bwd[8];      // step head only: row of the layer table and which layout (0 w_fwd, 1 w_bwd) src is
+  int32_t n;
+};
+
+template <class Src>
+__device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int bx, int nbx, Src src) {
+  float* __restrict__ wp = m.dst[job];
+  const int kind = m.kind[job], total = m.total[job];
+  for (int idx = bx * blockDim.x + threadIdx.x; idx < total; idx += nbx * blockDim.x) {
+    int r = idx;
+    const int lane = r % 64; r /= 64;
+    const int i = lane & 15, k = lane >> 4;
+    float v = 0.f;
+    if (kind == 0 || kind == 2) {                    // 4^3 conv, 8 output channels: [g][ty][tx][tz][lane]
+      const int KEZ = kind == 2 ? 5 : 4, KEX = kind == 0 ? 5 : 4;
+      const int tz = r % KEZ; r /= KEZ;
+      const int tx = r % KEX; r /= KEX;
+      const int ty = r % 4, g = r / 4;
+      const int cog = i >> 1, s = i & 1, ci = 4 * g + k;
+      const int kz = kind == 2 ? tz - s : tz, kx = kind == 0 ? tx - s : tx;
+      if (kz >= 0 && kz < 4 && kx >= 0 && kx < 4) v = src(job, (ci * 64 + (kz * 4 + ty) * 4 + kx) * 8 + cog);
+    } else if (kind == 10) {                         // transposed conv forward: [g][75 class/tap fragments][lane]
+      int f = r % 75;
+      const int g = r / 75;
+      int ez = 0, ey = 0;
+      if (f >= 63) { ez = 1; ey = 1; f -= 63; }
+      else if (f >= 45) { ez = 1; f -= 45; }
+      else if (f >= 27) { ey = 1; f -= 27; }
+      const int jx = f % 3, jy = (f / 3) % (3 - ey), jz = f / (3 * (3 - ey));
+      const int co = i >> 1, ex = i & 1, ci = 4 * g + k;
+      const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
+      if (kx < 5) v = src(job, (ci * 125 + (kz * 5 + ky) * 5 + kx) * 8 + co);
+    } else {                                         // stride-2 gather (transposed conv backward-data)
+      const int cog = m.c1[job], pair = cog == 8, KEX = pair ? 7 : 5;
+      const int tx = r % KEX; r /= KEX;
+      const int ky = r % 5; r /= 5;
+      const int kz = r % 5, g = r / 5;
+      const int ch = 4 * g + k;
+      const int co = pair ? i >> 1 : i, kx = pair ? tx - 2 * (i & 1) : tx;
+      if (kx >= 0 && kx < 5) v = src(job, (ch * 125 + (kz * 5 + ky) * 5 + kx) * cog + co);
+    }
+    wp[idx] = v;
+  }
+}
+
+// kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
+// 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog).  Fills m (sources optional: the step head derives them).
+static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
+                                 const int* c1s, int n, PackJobs& m) {
+  if (!dsts || !kinds || !c0s || !c1s || n <= 0 || n > 8) return NVF_EINVAL;
+  for (int j = 0; j < n; ++j) {
+    if (!dsts[j] || c0s[j] <= 0 || c0s[j] % 4) return NVF_EINVAL;
+    m.src[j] = srcs ? srcs[j] : nullptr; m.dst[j] = dsts[j]; m.kind[j] = kinds[j]; m.c0[j] = c0s[j]; m.c1[j] = c1s[j];
+    if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
+    else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
+    else if (kinds[j] == 20 && (c1s[j] == 8 || c1s[j] == 16)) m.total[j] = (c0s[j] / 4) * 25 * (c1s[j] == 8 ? 7 : 5) * 64;
+    else return NVF_EINVAL;
+  }
+  m.n = n;
+  return NVF_OK;
+}

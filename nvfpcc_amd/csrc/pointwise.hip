@@ -5,6 +5,7 @@
 // two-stage reductions instead of float atomics so results are reproducible.
 #include "nvf_common.h"
 #include "finals.h"
+#include "pack_mfma.h"
 
 #define NVF_GRID(n, bs) ((unsigned)(((n) + (bs)-1) / (bs)))
 
@@ -74,6 +75,15 @@ struct NvfLayerDesc {
   int32_t nbias, pad_;
 };
 
+// w_eff of element i of a layer's kernel: f_q(kernel) + kernel_init (q = 1: uniform noise of one quantisation step,
+// q = 2: rounding to 1/16)
+__device__ __forceinline__ float effective_weight(const NvfLayerDesc& d, int i, int qq, uint64_t seed, uint64_t sid) {
+  float k = d.kernel[i];
+  if (qq == 1) k = k + (nvf_uniform01(seed, sid, (uint64_t)i) - 0.5f) * 0.0625f;
+  else if (qq == 2) k = rintf(k * 16.f) / 16.f;
+  return k + d.kernel_init[i];
+}
+
 __device__ __forceinline__ void prepare_weights_body(const NvfLayerDesc* __restrict__ table, int q, uint64_t seed,
                                                      uint64_t step, const uint64_t* __restrict__ step_dev, int layer,
                                                      int bx, int nbx) {
@@ -84,10 +94,7 @@ __device__ __forceinline__ void prepare_weights_body(const NvfLayerDesc* __restr
   const uint64_t sid = (st << 8) | (uint64_t)d.layer_id;
   for (int i = bx * blockDim.x + threadIdx.x; i < n + d.nbias; i += nbx * blockDim.x) {
     if (i < n) {
-      float k = d.kernel[i];
-      if (qq == 1) k = k + (nvf_uniform01(seed, sid, (uint64_t)i) - 0.5f) * 0.0625f;
-      else if (qq == 2) k = rintf(k * 16.f) / 16.f;
-      const float w = k + d.kernel_init[i];
+      const float w = effective_weight(d, i, qq, seed, sid);
       const int t = i % d.k3, i1 = (i / d.k3) % d.dim1, i0 = i / (d.k3 * d.dim1);
       if (d.kind == 0) {  // i0 = co, i1 = ci
         if (d.w_fwd) d.w_fwd[(i1 * d.k3 + t) * d.dim0 + i0] = w;
@@ -985,26 +992,68 @@ extern "C" int nvf_gather_rows_multi(const float* const* srcs, float* const* dst
   return NVF_OK;
 }
 
-// The first two launches of a training step -- the effective weights of every layer and the gather of the
-// mini-batch rows -- are independent: one launch.  Workgroups [0, 16 nlayers) prepare the weights, the rest gather.
-__global__ void prepare_and_gather_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q, uint64_t seed,
-                                          uint64_t step, const uint64_t* __restrict__ step_dev, GatherMulti g,
-                                          const int64_t* __restrict__ idx, int rows, int gwg) {
-  const int bid = blockIdx.x, np = 16 * nlayers;
-  if (bid < np) { prepare_weights_body(table, q, seed, step, step_dev, bid >> 4, bid & 15, 16); return; }
-  gather_rows_multi_body(g, idx, rows, (bid - np) / gwg, (bid - np) % gwg, gwg);
+// The head of a training step in ONE launch: the effective weights of every layer (nvf_prepare_weights), the gather
+// of the mini-batch rows (nvf_gather_rows_multi) and the matrix-core weight packings (nvf_pack_mfma_all).  The
+// packings do not wait for the prepared layouts: a packed element recomputes its effective weight from the raw
+// kernel (same arithmetic, same noise index), so the three parts are independent.  Workgroups [0, 16 nlayers)
+// prepare, the next 16 npack pack, the rest gather.  Results are those of the three calls, bit for bit.
+__device__ __forceinline__ int layout_to_kernel_index(const NvfLayerDesc& d, int bwd, int si) {
+  int i0, i1, t;
+  if (d.kind == 0) {                    // conv [cout = i0][cin = i1][k]
+    if (!bwd) { i0 = si % d.dim0; t = (si / d.dim0) % d.k3; i1 = si / (d.dim0 * d.k3); }
+    else { i1 = si % d.dim1; t = d.k3 - 1 - (si / d.dim1) % d.k3; i0 = si / (d.dim1 * d.k3); }
+  } else {                              // convT [cin = i0][cout = i1][k]
+    if (!bwd) { i1 = si % d.dim1; t = (si / d.dim1) % d.k3; i0 = si / (d.dim1 * d.k3); }
+    else { i0 = si % d.dim0; t = (si / d.dim0) % d.k3; i1 = si / (d.dim0 * d.k3); }
+  }
+  return (i0 * d.dim1 + i1) * d.k3 + t;
 }
 
-extern "C" int nvf_prepare_weights_and_gather(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
-                                              const uint64_t* step_dev, const float* const* srcs, float* const* dsts,
-                                              const int* widths, int n, const int64_t* idx, int rows, void* stream) {
-  if (!table_dev || nlayers <= 0 || !idx) return NVF_EINVAL;
+__global__ void step_head_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q, uint64_t seed,
+                                 uint64_t step, const uint64_t* __restrict__ step_dev, PackJobs pk, GatherMulti g,
+                                 const int64_t* __restrict__ idx, int rows, int gwg) {
+  int bid = blockIdx.x;
+  if (bid < 16 * nlayers) { prepare_weights_body(table, q, seed, step, step_dev, bid >> 4, bid & 15, 16); return; }
+  bid -= 16 * nlayers;
+  if (bid < 16 * pk.n) {
+    const int job = bid >> 4;
+    const NvfLayerDesc d = table[pk.layer[job]];
+    const int qq = d.quantised ? q : 0, bwd = pk.bwd[job];
+    const uint64_t st = step + (step_dev ? step_dev[0] : 0ull);
+    const uint64_t sid = (st << 8) | (uint64_t)d.layer_id;
+    pack_mfma_body(pk, job, bid & 15, 16, [&](int, int si) {
+      return effective_weight(d, layout_to_kernel_index(d, bwd, si), qq, seed, sid);
+    });
+    return;
+  }
+  bid -= 16 * pk.n;
+  gather_rows_multi_body(g, idx, rows, bid / gwg, bid % gwg, gwg);
+}
+
+// pack_*: as nvf_pack_mfma_all without sources -- pack job j packs layout pack_bwd[j] (0 w_fwd, 1 w_bwd) of table row
+// pack_layers[j]; npack may be 0.
+extern "C" int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
+                             const uint64_t* step_dev, float* const* pack_dsts, const int* pack_kinds,
+                             const int* pack_c0s, const int* pack_c1s, const int* pack_layers, const int* pack_bwd,
+                             int npack, const float* const* srcs, float* const* dsts, const int* widths, int n,
+                             const int64_t* idx, int rows, void* stream) {
+  if (!table_dev || nlayers <= 0 || !idx || npack < 0) return NVF_EINVAL;
+  PackJobs pk{};
+  if (npack > 0) {
+    if (!pack_layers || !pack_bwd) return NVF_EINVAL;
+    const int rc = pack_jobs_desc(nullptr, pack_dsts, pack_kinds, pack_c0s, pack_c1s, npack, pk);
+    if (rc != NVF_OK) return rc;
+    for (int j = 0; j < npack; ++j) {
+      if (pack_layers[j] < 0 || pack_layers[j] >= nlayers) return NVF_EINVAL;
+      pk.layer[j] = pack_layers[j]; pk.bwd[j] = pack_bwd[j] ? 1 : 0;
+    }
+  }
   GatherMulti g{};
   long wg = 0;
   const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
   if (rc != NVF_OK) return rc;
-  prepare_and_gather_kernel<<<16 * nlayers + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
-      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, g, idx, rows, (int)wg);
+  step_head_kernel<<<16 * nlayers + 16 * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
+      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -165,29 +165,40 @@ class TrainEngine:
             t["quantised"] = 1 if name in TRUNK else 0
             t["layer_id"] = m.layer_id
             t["nbias"] = m.b.numel()
-        jobs = [(L.w_fwd, L.wp_f, 0, L.cin, 8) for L in self.layers.values() if L.wp_f is not None]
-        jobs += [(L.w_bwd, L.wp_b, L.bwd_pair, L.cout, 8) for L in self.layers.values() if L.wp_b is not None]
-        jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for L in self.layers.values() if L.wp_t is not None]
-        jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for L in self.layers.values() if L.wp_s is not None]
+        row = {name: i for i, (name, _, _) in enumerate(mods)}
+        named = list(self.layers.items())
+        jobs = [(L.w_fwd, L.wp_f, 0, L.cin, 8) for _, L in named if L.wp_f is not None]
+        meta = [(row[nm], 0) for nm, L in named if L.wp_f is not None]
+        jobs += [(L.w_bwd, L.wp_b, L.bwd_pair, L.cout, 8) for _, L in named if L.wp_b is not None]
+        meta += [(row[nm], 1) for nm, L in named if L.wp_b is not None]
+        jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for _, L in named if L.wp_t is not None]
+        meta += [(row[nm], 0) for nm, L in named if L.wp_t is not None]
+        jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for _, L in named if L.wp_s is not None]
+        meta += [(row[nm], 1) for nm, L in named if L.wp_s is not None]
         self._mfma_jobs = jobs
+        self._mfma_job_layers = meta           # (layer-table row, 0 = w_fwd / 1 = w_bwd) of each job's source
         self._table_host = table
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.dev)
         self.nlayers = len(mods)
 
     def batch_and_prepare(self, idx_dev, q):
-        """_batch(idx_dev) and prepare_weights(q) with their first launches (row gather, effective weights) as one."""
+        """_batch(idx_dev) and prepare_weights(q) -- row gather, effective weights, MFMA packings -- as ONE launch."""
         import ctypes
         srcs = [self.gt, self.dist, self.gt16, self.gt8, self.emb]
         n, rows = len(srcs), idx_dev.numel()
         dsts = [torch.empty((rows,) + tuple(s.shape[1:]), device=s.device) for s in srcs]
         sd = self._step_dev
-        check(lib().nvf_prepare_weights_and_gather(
+        jobs, meta = self._mfma_jobs, self._mfma_job_layers
+        npk = len(jobs)
+        iarr = lambda xs: (ctypes.c_int * max(len(xs), 1))(*xs)
+        check(lib().nvf_step_head(
             self.table.data_ptr(), self.nlayers, int(q), self.seed, 0 if sd is not None else self.noise_step,
-            None if sd is None else sd.data_ptr(), (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
+            None if sd is None else sd.data_ptr(),
+            (ctypes.c_void_p * max(npk, 1))(*[j[1].data_ptr() for j in jobs]), iarr([j[2] for j in jobs]),
+            iarr([j[3] for j in jobs]), iarr([j[4] for j in jobs]), iarr([m[0] for m in meta]),
+            iarr([m[1] for m in meta]), npk, (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
             (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_int * n)(*[s[0].numel() for s in srcs]), n,
-            idx_dev.data_ptr(), rows, torch.cuda.current_stream().cuda_stream), "nvf_prepare_weights_and_gather")
-        if self._mfma_jobs:
-            ops.pack_mfma_all(self._mfma_jobs)
+            idx_dev.data_ptr(), rows, torch.cuda.current_stream().cuda_stream), "nvf_step_head")
         return dsts
 
     def prepare_weights(self, q):

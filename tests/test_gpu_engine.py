@@ -154,3 +154,29 @@ def test_fused_stem_equals_the_per_layer_kernels(gpu):
     eng.fused_stem = False
     _, de2 = eng.latent_step(2, update=False)
     close(de, de2, tol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["S", "W"])
+def test_one_launch_step_head_equals_the_three_launches(tag, gpu):
+    """nvf_step_head (effective weights + MFMA packings + mini-batch gather in one launch; the packings recompute
+    their effective weights from the raw kernels) against nvf_gather_rows_multi + nvf_prepare_weights +
+    nvf_pack_mfma_all: every prepared layout, packed fragment array and gathered row, bit for bit, for every
+    quantisation mode."""
+    net, eng, gt, dist, emb = make(tag, gpu)
+    idx = torch.tensor([4, 1, 5, 1], device=gpu)
+    bufs = lambda: [t for L in eng.layers.values() for t in (L.w_fwd, L.w_bwd, L.b_eff, L.wp_f, L.wp_b, L.wp_t, L.wp_s)
+                    if t is not None]
+    for q in (0, 1, 2):
+        eng.noise_step = 7 + q
+        for t in bufs():
+            t.fill_(float("nan"))
+        rows_ref = eng._batch(idx)
+        eng.prepare_weights(q)
+        ref = [t.clone() for t in bufs()]
+        for t in bufs():
+            t.fill_(float("nan"))
+        rows = eng.batch_and_prepare(idx, q)
+        torch.cuda.synchronize()
+        assert len(ref) > 0 and all(torch.equal(a, b) for a, b in zip(bufs(), ref)), (tag, q)
+        assert all(torch.equal(a, b) for a, b in zip(rows, rows_ref))
+        assert not any(torch.isnan(t).any().item() for t in bufs())
