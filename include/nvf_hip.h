@@ -136,6 +136,16 @@ int nvf_heads3_fwd(const float* const* xs, const float* const* w_fwds, const flo
                    const int* cs, const int* ss, int batch, int act, void* stream);
 int nvf_heads3_bwd_data(const float* const* dlogits, const float* const* w_bwds, float* const* dxs,
                         const float* const* masks, const int* cs, const int* ss, int batch, void* stream);
+
+/* nvf_focal_loss_multi (chain_sigmoid) of the three heads and nvf_heads3_bwd_data in ONE launch (NVFPCC.py:166-184
+ * + the heads' backward-data): dls[h] = d term_h / d logit_h is computed while the tiles are staged, written for
+ * the weight gradient, and loss[slots[h]] = term_h (final pass deferred by nvf_finals_begin).  dists[h] may be
+ * NULL.  batch <= 32 (one loss partial per workgroup); otherwise NVF_EINVAL. */
+int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, const float* const* dists,
+                             const float* alphas, const float* betas, const int* slots, float* loss,
+                             float* const* dls, const float* const* wbs, float* const* dxs,
+                             const float* const* masks, const int* cs, const int* ss, int batch, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* partial sums only: slabs[h] receives nslabs[h] (<= max_slabs) slabs of cs[h] * 27 floats, to be added by
  * nvf_wgrad_reduce_multi */
 int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs, float* const* slabs, const int* cs,

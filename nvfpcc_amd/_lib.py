@@ -39,6 +39,7 @@ PROTOTYPES = {
     "nvf_pack_mfma_all": (I, [P, P, P, P, P, I, P]),
     "nvf_heads3_fwd": (I, [P, P, P, P, P, P, I, I, P]),
     "nvf_heads3_bwd_data": (I, [P, P, P, P, P, P, I, P]),
+    "nvf_heads3_loss_bwd_data": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P]),
     "nvf_heads3_wgrad_partial": (I, [P, P, P, P, P, I, I, P, P]),
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "nvf_stem_bwd_workspace": (Z, [I, I]),

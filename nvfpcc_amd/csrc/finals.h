@@ -36,6 +36,27 @@ struct WeightRateBatch {
   int32_t nlayers, chunk;
 };
 
+// one focal term (utils/loss.py:61-72, 94-111) and its gradient w.r.t. p (chain_sigmoid: w.r.t. the logit)
+// Contraction into FMAs is switched off: the function is inlined into several kernels and every one of them must
+// produce the same bits.  g scales the gradient (1 = as is).
+__device__ __forceinline__ float focal_elem(float pv, float gv, float dv, bool has_dist, float a1, float a0, float beta,
+                                            int chain_sigmoid, float& dp, float g = 1.f) {
+#pragma clang fp contract(off)
+  const bool occ = gv != 0.f;
+  const float F = occ ? pv : 1.f - pv;
+  const float at = occ ? a1 : a0;
+  float w = 1.f;
+  if (has_dist) w = dv + (occ ? beta : 0.f);
+  const float Fc = fmaxf(F, 1e-9f);
+  const float om = 1.f - Fc;
+  const float lg = logf(Fc);
+  float d = 0.f;
+  if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
+  const float dd = g * (occ ? d : -d);
+  dp = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
+  return -1.f * at * (om * om) * w * lg;
+}
+
 // one wave per loss term: lanes take the partials 64 apart (ascending), then a fixed-order wave sum
 __device__ __forceinline__ void focal_multi_final_body(const FocalMulti& m, const float* __restrict__ part,
                                                        float* __restrict__ loss, int nterm, int tid) {
@@ -86,6 +107,8 @@ __device__ __forceinline__ void weight_rate_batch_final_body(const WeightRateBat
 // Queue (finals.hip).  A push returns false when nothing is being deferred or a job of that kind is already waiting:
 // the caller then launches its own final pass as usual.
 bool nvf_finals_push_focal(const FocalMulti& m, const float* part, float* loss, int nterm);
+// queue the focal final pass or, when nothing is being deferred, launch it on `stream`
+int nvf_finals_run_focal(const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);
 bool nvf_finals_push_sums(const MultiSumDesc& d, const float* part);
 bool nvf_finals_push_rate(const WeightRateBatch& b, const float* part, const float* sigma, float* bits, float* dsigma,
                           float* dmu, const float* g_dev, float g_host);

@@ -59,6 +59,17 @@ bool nvf_finals_push_rate(const WeightRateBatch& b, const float* part, const flo
   return true;
 }
 
+__global__ void focal_final_kernel(FocalMulti m, const float* __restrict__ part, float* __restrict__ loss, int nterm) {
+  focal_multi_final_body(m, part, loss, nterm, threadIdx.x);
+}
+
+int nvf_finals_run_focal(const FocalMulti& m, const float* part, float* loss, int nterm, void* stream) {
+  if (nvf_finals_push_focal(m, part, loss, nterm)) return NVF_OK;
+  focal_final_kernel<<<1, 64 * nterm, 0, nvf_stream(stream)>>>(m, part, loss, nterm);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 // Start queueing the final passes of nvf_focal_loss_multi, nvf_wgrad_reduce_multi_and_sums / nvf_multi_channel_sum
 // and nvf_weight_rate_batch (at most one of each kind; a second one is launched as usual).
 extern "C" void nvf_finals_begin(void) {

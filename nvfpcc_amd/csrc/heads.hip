@@ -13,6 +13,7 @@
 //   * give each thread four consecutive x outputs, so one row segment (a b128 plus two b32 LDS
 //     reads) feeds 12 FMAs per input channel.
 #include "nvf_common.h"
+#include "finals.h"
 
 namespace {
 
@@ -134,15 +135,75 @@ __global__ __launch_bounds__(H::NT) void head_fwd_kernel(const float* __restrict
   head_fwd_body<H>(x, w, bias, y, addend, mask, act, blockIdx.x, smem);
 }
 
+// Focal inputs of one head: the backward-data kernel can compute dlogit = d focal / d logit on the fly while it
+// stages its tile (the halo is recomputed, the tile's own voxels are also written to `dl` for the weight gradient
+// and summed into one loss partial per workgroup) -- the separate loss launch disappears.
+struct HeadLoss {
+  const float* p;
+  const float* gt;
+  const float* dist;       // or null
+  float* dl;               // [B, 1, S^3] out
+  float* part;             // loss partials of this term: one per workgroup
+  float alpha, beta;
+};
+
+template <int S, int TZ, int TY, int RS, int NT>
+__device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, float* red, int tid, int b, int z0, int y0,
+                                                int wg) {
+  constexpr int XG = S / 4, IZ = TZ + 2, IY = TY + 2, ITEMS = IZ * IY * XG;
+  const size_t vol = (size_t)S * S * S;
+  const float a1 = f.alpha, a0 = 1.f - f.alpha;
+  float s = 0.f;
+  constexpr int U = (ITEMS + NT - 1) / NT;                    // every load of the thread in flight before any is used
+  float4 pv[U], gv[U], dv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = tid + u * NT;
+    const int xq = i % XG, r = i / XG, yi = r % IY, zi = r / IY;
+    const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
+    const bool ok = i < ITEMS && gz >= 0 && gz < S && gy >= 0 && gy < S;
+    const size_t off = ok ? b * vol + ((size_t)gz * S + gy) * S + 4 * xq : 0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    pv[u] = ok ? *(const float4*)(f.p + off) : z4;
+    gv[u] = ok ? *(const float4*)(f.gt + off) : z4;
+    dv[u] = ok && f.dist ? *(const float4*)(f.dist + off) : z4;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = tid + u * NT;
+    if (i >= ITEMS) continue;
+    const int xq = i % XG, r = i / XG, yi = r % IY, zi = r / IY;
+    const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gz >= 0 && gz < S && gy >= 0 && gy < S) {
+      const size_t off = b * vol + ((size_t)gz * S + gy) * S + 4 * xq;
+      const float t0 = focal_elem(pv[u].x, gv[u].x, dv[u].x, f.dist != nullptr, a1, a0, f.beta, 1, o.x);
+      const float t1 = focal_elem(pv[u].y, gv[u].y, dv[u].y, f.dist != nullptr, a1, a0, f.beta, 1, o.y);
+      const float t2 = focal_elem(pv[u].z, gv[u].z, dv[u].z, f.dist != nullptr, a1, a0, f.beta, 1, o.z);
+      const float t3 = focal_elem(pv[u].w, gv[u].w, dv[u].w, f.dist != nullptr, a1, a0, f.beta, 1, o.w);
+      if (zi >= 1 && zi <= TZ && yi >= 1 && yi <= TY) {       // this tile's own voxels
+        *(float4*)(f.dl + off) = o;
+        s += (t0 + t1) + (t2 + t3);
+      }
+    }
+    float* row = ds + (size_t)r * RS;
+    *(float4*)(row + 4 + 4 * xq) = o;
+    if (xq == 0) row[3] = 0.f;
+    if (xq == XG - 1) row[S + 4] = 0.f;
+  }
+  const float tot = nvf_block_sum(s, red);
+  if (tid == 0) f.part[wg] = tot;
+}
+
 // ---- backward-data: dx[c, i] = sum_k' dl[i - 1 + k'] wb[k'][c]  (wb = w_bwd: taps flipped) ---------------------
 template <class H>
-struct HBwdSmem { static constexpr int WORDS = (H::IZ * H::IY * H::RS + 3) / 4 * 4 + 27 * H::C; };
+struct HBwdSmem { static constexpr int WORDS = (H::IZ * H::IY * H::RS + 3) / 4 * 4 + 27 * H::C + 16; };   // + block-sum scratch
 
 template <class H>
 __device__ __forceinline__ void head_bwd_data_body(const float* __restrict__ dl, const float* __restrict__ wb,
                                                    const float* __restrict__ bias, float* __restrict__ dx,
                                                    const float* __restrict__ addend, const float* __restrict__ mask,
-                                                   int act, int bid, float* smem) {
+                                                   int act, int bid, float* smem, const HeadLoss* loss = nullptr) {
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT;
   float* ds = smem;
   float* ws = smem + (IZ * IY * RS + 3) / 4 * 4;
@@ -151,7 +212,8 @@ __device__ __forceinline__ void head_bwd_data_body(const float* __restrict__ dl,
   const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
   for (int i = tid; i < 27 * C; i += NT) ws[i] = wb[i];
-  head_stage<1, S, IZ, IY, RS, NT>(dl + (size_t)b * S * S * S, ds, tid, z0, y0);
+  if (loss) head_stage_loss<S, TZ, TY, RS, NT>(*loss, ds, ws + 27 * C, tid, b, z0, y0, bid);
+  else head_stage<1, S, IZ, IY, RS, NT>(dl + (size_t)b * S * S * S, ds, tid, z0, y0);
   __syncthreads();
   if (tid >= H::NACT) return;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
@@ -449,6 +511,56 @@ extern "C" int nvf_heads3_bwd_data(const float* const* dls, const float* const* 
   heads3_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
+}
+
+struct Heads3Loss { HeadLoss h[3]; };
+
+template <class H0, class H1, class H2>
+__global__ __launch_bounds__(256) void heads3_loss_bwd_data_kernel(Heads3 m, Heads3Loss f) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax3(HBwdSmem<H0>::WORDS, HBwdSmem<H1>::WORDS, HBwdSmem<H2>::WORDS)];
+  const int bid = blockIdx.x;
+  if (bid < m.n[2]) head_bwd_data_body<H2>(nullptr, m.w[2], nullptr, m.out[2], nullptr, m.mask[2], 0, bid, smem, &f.h[2]);
+  else if (bid < m.n[2] + m.n[1])
+    head_bwd_data_body<H1>(nullptr, m.w[1], nullptr, m.out[1], nullptr, m.mask[1], 0, bid - m.n[2], smem, &f.h[1]);
+  else
+    head_bwd_data_body<H0>(nullptr, m.w[0], nullptr, m.out[0], nullptr, m.mask[0], 0, bid - m.n[2] - m.n[1], smem, &f.h[0]);
+}
+
+extern "C" size_t nvf_reduce_workspace(void);
+
+// The focal terms of the three heads (NVFPCC.py:166-184), their gradients w.r.t. the logits and the heads'
+// backward-data in ONE launch (+ the one-block final pass of the loss sums, which nvf_finals_begin defers):
+// dls[h] = d term_h / d logit_h (also consumed in place: dxs[h] is nvf_heads3_bwd_data of it), loss[slots[h]] = term_h.
+// Heads as in nvf_heads3_fwd; dists[h] may be NULL; batch * 32 workgroups of the big head must fit the reduction
+// workspace (batch <= 32), otherwise NVF_EINVAL and the caller uses nvf_focal_loss_multi + nvf_heads3_bwd_data.
+extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, const float* const* dists,
+                                        const float* alphas, const float* betas, const int* slots, float* loss,
+                                        float* const* dls, const float* const* wbs, float* const* dxs,
+                                        const float* const* masks, const int* cs, const int* ss, int batch,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs || !masks || !cs || !ss ||
+      !workspace || batch <= 0)
+    return NVF_EINVAL;
+  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  using H0 = HCfg<16, 8, 4, 8>; using H1 = HCfg<8, 16, 4, 4>; using H2 = HCfg<8, 32, 4, 8>;
+  Heads3 m{};
+  Heads3Loss f{};
+  FocalMulti fm{};
+  m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
+  for (int h = 0; h < 3; ++h) {
+    if (!ps[h] || !gts[h] || !dls[h] || !wbs[h] || !dxs[h] || slots[h] < 0 || slots[h] > 2 || m.n[h] > kLossMaxWG)
+      return NVF_EINVAL;
+    m.w[h] = wbs[h]; m.out[h] = dxs[h]; m.mask[h] = masks[h];
+    f.h[h].p = ps[h]; f.h[h].gt = gts[h]; f.h[h].dist = dists[h]; f.h[h].dl = dls[h];
+    f.h[h].part = (float*)workspace + slots[h] * kLossMaxWG;
+    f.h[h].alpha = alphas[h]; f.h[h].beta = betas[h];
+    fm.nwg[slots[h]] = m.n[h];
+  }
+  if (slots[0] == slots[1] || slots[0] == slots[2] || slots[1] == slots[2]) return NVF_EINVAL;
+  heads3_loss_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m, f);
+  NVF_LAUNCH_CHECK();
+  return nvf_finals_run_focal(fm, (const float*)workspace, loss, 3, stream);
 }
 
 // partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)

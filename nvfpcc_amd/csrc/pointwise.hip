@@ -631,22 +631,9 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ p,
   const float a1 = alpha, a0 = 1.f - alpha;  // fp32 "-alpha + 1" as the reference evaluates it
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float pv = p[i], gv = gt[i];
-    bool occ = gv != 0.f;
-    float F = occ ? pv : 1.f - pv;
-    float at = occ ? a1 : a0;
-    float w = 1.f;
-    if (dist) w = dist[i] + (occ ? beta : 0.f);
-    float Fc = fmaxf(F, 1e-9f);
-    float om = 1.f - Fc;
-    float lg = logf(Fc);
-    s += -1.f * at * (om * om) * w * lg;
-    if (dp) {
-      float d = 0.f;
-      if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
-      float dd = g * (occ ? d : -d);
-      dp[i] = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
-    }
+    float o;
+    s += focal_elem(p[i], gt[i], dist ? dist[i] : 0.f, dist != nullptr, a1, a0, beta, chain_sigmoid, o, g);
+    if (dp) dp[i] = o;
   }
   float t = nvf_block_sum(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
@@ -670,23 +657,6 @@ extern "C" int nvf_focal_loss(const float* p, const float* gt, const float* dist
 }
 
 // the three focal terms of the objective (main output + two heads, NVFPCC.py:166-184) in one launch pair
-
-__device__ __forceinline__ float focal_elem(float pv, float gv, float dv, bool has_dist, float a1, float a0, float beta,
-                                            int chain_sigmoid, float& dp) {
-  const bool occ = gv != 0.f;
-  const float F = occ ? pv : 1.f - pv;
-  const float at = occ ? a1 : a0;
-  float w = 1.f;
-  if (has_dist) w = dv + (occ ? beta : 0.f);
-  const float Fc = fmaxf(F, 1e-9f);
-  const float om = 1.f - Fc;
-  const float lg = logf(Fc);
-  float d = 0.f;
-  if (F >= 1e-9f) d = -at * w * (-2.f * om * lg + om * om / Fc);
-  const float dd = occ ? d : -d;
-  dp = chain_sigmoid ? dd * ((1.f - pv) * pv) : dd;
-  return -1.f * at * (om * om) * w * lg;
-}
 
 // every thread takes float4 groups (all loads of a group in flight together); a thread's terms are added in index
 // order, the block sum is the fixed-order nvf_block_sum

@@ -323,13 +323,20 @@ class TrainEngine:
         defer = want_w and not self.overlap
         if defer:
             ops.finals_begin()
-        dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
-                                              (a["p1"], gt16, None, 0.85, 0.0)], loss)
+        fused_loss = self.heads3 and a["e"].shape[0] <= 32 and _NAIVE_OFF()
+        if not fused_loss:
+            dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
+                                                  (a["p1"], gt16, None, 0.85, 0.0)], loss)
         ev_t1 = ev_t0 = None
         if self.heads3:
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
-            t0, t1, g5 = ops.heads3_bwd_data([dl0, dl1, dl2], [L.w_bwd for L in hl], [L.cin for L in hl],
-                                             [None, None, a["y5"]])
+            if fused_loss:      # the three focal terms, their logit gradients and the heads' backward-data: one launch
+                (dl0, dl1, dl2), (t0, t1, g5) = ops.heads3_loss_bwd_data(
+                    [a["p0"], a["p1"], a["p2"]], [gt8, gt16, gt], [None, None, dist], [0.85, 0.85, 0.9],
+                    [0.0, 0.0, 1.0], [1, 2, 0], loss, [L.w_bwd for L in hl], [L.cin for L in hl], [None, None, a["y5"]])
+            else:
+                t0, t1, g5 = ops.heads3_bwd_data([dl0, dl1, dl2], [L.w_bwd for L in hl], [L.cin for L in hl],
+                                                 [None, None, a["y5"]])
             if want_w:
                 self._wg.add_heads3([dl0, dl1, dl2], [a["y1"], a["y3"], a["y5"]], [L.gk for L in hl])
                 self._bias_jobs += [(dl2, hl[2].gb), (dl1, hl[1].gb), (dl0, hl[0].gb)]

@@ -509,6 +509,40 @@ def test_deferred_final_passes_equal_immediate_ones(ops):
     ops.finals_flush()
 
 
+def test_heads_loss_and_backward_data_in_one_launch(ops):
+    """nvf_heads3_loss_bwd_data against nvf_focal_loss_multi + nvf_heads3_bwd_data: the logit gradients and the
+    heads' input gradients are the same bits (same elementwise code, same stencil order); the three loss sums agree
+    to fp32 summation order."""
+    torch.manual_seed(11)
+    B = 3
+    shapes = [(16, 8), (8, 16), (8, 32)]
+    ps = [torch.rand(B, 1, s, s, s, device="cuda") for c, s in shapes]
+    ps[2][0, 0, :2] = 0.0                      # saturated probabilities hit the 1e-9 clamp
+    ps[1][1, 0, 3] = 1.0
+    gts = [(torch.rand(B, 1, s, s, s, device="cuda") > 0.75).float() for c, s in shapes]
+    dist = torch.rand(B, 1, 32, 32, 32, device="cuda")
+    ws = [torch.randn(1, c, 3, 3, 3, device="cuda") for c, s in shapes]
+    wbs = [ops.pack_conv_weight(w)[1] for w in ws]
+    mask = torch.randn(B, 8, 32, 32, 32, device="cuda")
+    cs = [c for c, s in shapes]
+    loss_ref = torch.empty(4, device="cuda")
+    dl2, dl0, dl1 = ops.focal_loss_multi([(ps[2], gts[2], dist, 0.9, 1.0), (ps[0], gts[0], None, 0.85, 0.0),
+                                          (ps[1], gts[1], None, 0.85, 0.0)], loss_ref)
+    dx_ref = ops.heads3_bwd_data([dl0, dl1, dl2], wbs, cs, [None, None, mask])
+    loss = torch.empty(4, device="cuda")
+    dls, dxs = ops.heads3_loss_bwd_data(ps, gts, [None, None, dist], [0.85, 0.85, 0.9], [0.0, 0.0, 1.0], [1, 2, 0],
+                                        loss, wbs, cs, [None, None, mask])
+    for got, ref in zip(dls, (dl0, dl1, dl2)):
+        assert torch.equal(got, ref)
+    for got, ref in zip(dxs, dx_ref):
+        assert torch.equal(got, ref)
+    np.testing.assert_allclose(loss[:3].cpu().numpy(), loss_ref[:3].cpu().numpy(), rtol=2e-6)
+    with pytest.raises(RuntimeError):          # one loss partial per workgroup: batch <= 32
+        big = [torch.rand(33, 1, s, s, s, device="cuda") for c, s in shapes]
+        ops.heads3_loss_bwd_data(big, big, [None, None, None], [0.85, 0.85, 0.9], [0.0, 0.0, 1.0], [1, 2, 0], loss,
+                                 wbs, cs, [None, None, None])
+
+
 def test_small_elementwise(ops):
     g = gen(60)
     p = torch.rand(3, 1, 8, 8, 8, generator=g)
