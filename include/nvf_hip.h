@@ -167,6 +167,15 @@ int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float*
                  float* dbeta_hat, float* dgamma_hat, float* dw_up0, void* workspace, size_t workspace_bytes,
                  int batch, int ch, int c0, int c1, void* stream);
 
+/* nvf_stem_bwd minus its final launch (training step): up0's weight-gradient slabs (*dw_slabs: *nslabs slabs of
+ * ch * c0 * 125 floats inside `workspace`) are left to the caller's slab reduction (nvf_wgrad_reduce_multi*), the
+ * IGDN parameter gradients to the deferred final passes (nvf_finals_begin; launched at once otherwise).  Same sums,
+ * same order as nvf_stem_bwd. */
+int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
+                         const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
+                         float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs, void* workspace,
+                         size_t workspace_bytes, int batch, int ch, int c0, int c1, void* stream);
+
 /* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
  * dw[a][b][k] (+)= sum_{n,i} p[n,a,i] * q[n,b, stride*i - pad + k]      (out_mode 0)
  * dw[b][a][K^3-1-k] (+)= same sum                                        (out_mode 1)

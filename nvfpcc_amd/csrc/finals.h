@@ -8,6 +8,10 @@
 
 static const int kLossMaxWG = 1024;
 
+// LowerBound floors of the GDN re-parametrisation (gdn_3d.py:40-60): beta = max(beta_hat, bound)^2 - pedestal
+#define NVF_BETA_BOUND 1.0000072759311445e-03f /* sqrt(1e-6 + 2^-36) */
+#define NVF_GAMMA_BOUND 3.814697265625e-06f   /* 2^-18 */
+
 // the three focal terms of the objective (main output + two heads, NVFPCC.py:166-184)
 struct FocalMulti {
   const float* p[3];
@@ -104,9 +108,38 @@ __device__ __forceinline__ void weight_rate_batch_final_body(const WeightRateBat
   if (dmu) dmu[0] = g * acc_m;
 }
 
+// IGDN parameter gradients of the fused stem from its slabs (column p: p < c0 is d beta_p, the rest d gamma): fixed-order
+// sum, re-parametrisation chain rule, LowerBound rule (gdn_3d.py:72-95 backward)
+struct StemGdnFinal {
+  const float* slab_gdn;
+  const float* beta_hat;
+  const float* gamma_hat;
+  float* dbeta_hat;
+  float* dgamma_hat;
+  int32_t nslab, c0;
+};
+
+__device__ __forceinline__ void stem_gdn_final_body(const StemGdnFinal& f, int p) {
+  const int ncol = f.c0 + f.c0 * f.c0;
+  if (p >= ncol) return;
+  float s = 0.f;
+  for (int g = 0; g < f.nslab; ++g) s += f.slab_gdn[(size_t)g * ncol + p];
+  if (p < f.c0) {
+    const float h = f.beta_hat[p];
+    const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
+    f.dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+  } else {
+    const float h = f.gamma_hat[p - f.c0];
+    const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
+    f.dgamma_hat[p - f.c0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+  }
+}
+
 // Queue (finals.hip).  A push returns false when nothing is being deferred or a job of that kind is already waiting:
 // the caller then launches its own final pass as usual.
 bool nvf_finals_push_focal(const FocalMulti& m, const float* part, float* loss, int nterm);
+// queue the stem's IGDN final pass or, when nothing is being deferred, launch it on `stream` (c0 + c0^2 <= 128)
+int nvf_finals_run_stem_gdn(const StemGdnFinal& f, void* stream);
 // queue the focal final pass or, when nothing is being deferred, launch it on `stream`
 int nvf_finals_run_focal(const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);
 bool nvf_finals_push_sums(const MultiSumDesc& d, const float* part);

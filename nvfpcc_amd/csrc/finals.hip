@@ -17,11 +17,12 @@ struct FinalsArgs {
   float* r_dmu;
   const float* r_gdev;
   float r_ghost;
-  int32_t f_nterm, has_f, has_s, has_r;
+  StemGdnFinal g;
+  int32_t f_nterm, has_f, has_s, has_r, has_g;
 };
 
-// workgroup 0: the focal terms (one wave each); workgroup 1: the weight-rate term (wave 0); workgroups 2..: 64 bias
-// channels each
+// workgroup 0: the focal terms (one wave each); workgroup 1: the weight-rate term (wave 0) and the stem's IGDN
+// parameter gradients (waves 1-2); workgroups 2..: 64 bias channels each
 __global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a) {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a) {
   } else if (blockIdx.x == 1) {
     if (a.has_r && tid < 64)
       weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost, tid);
+    if (a.has_g && tid >= 64) stem_gdn_final_body(a.g, tid - 64);
   } else if (a.has_s && tid < 64) {
     multi_channel_sum_final_body(a.s, a.s_part, ((int)blockIdx.x - 2) * 64 + tid);
   }
@@ -57,6 +59,19 @@ bool nvf_finals_push_rate(const WeightRateBatch& b, const float* part, const flo
   g_args.r = b; g_args.r_part = part; g_args.r_sigma = sigma; g_args.r_bits = bits; g_args.r_dsigma = dsigma;
   g_args.r_dmu = dmu; g_args.r_gdev = g_dev; g_args.r_ghost = g_host; g_args.has_r = 1;
   return true;
+}
+
+__global__ void stem_gdn_final_kernel(StemGdnFinal f) { stem_gdn_final_body(f, threadIdx.x); }
+
+int nvf_finals_run_stem_gdn(const StemGdnFinal& f, void* stream) {
+  if (f.c0 + f.c0 * f.c0 > 128) return NVF_EINVAL;
+  if (g_deferring && !g_args.has_g) {
+    g_args.g = f; g_args.has_g = 1;
+    return NVF_OK;
+  }
+  stem_gdn_final_kernel<<<1, 128, 0, nvf_stream(stream)>>>(f);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 __global__ void focal_final_kernel(FocalMulti m, const float* __restrict__ part, float* __restrict__ loss, int nterm) {
@@ -89,7 +104,7 @@ extern "C" int nvf_finals_flush(void* stream) {
   const FinalsArgs a = g_args;
   g_args = FinalsArgs{};
   g_deferring = false;
-  if (!a.has_f && !a.has_s && !a.has_r) return NVF_OK;
+  if (!a.has_f && !a.has_s && !a.has_r && !a.has_g) return NVF_OK;
   const int sum_blocks = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
   finals_kernel<<<2 + sum_blocks, 192, 0, nvf_stream(stream)>>>(a);
   NVF_LAUNCH_CHECK();

@@ -130,8 +130,6 @@ extern "C" int nvf_prepare_weights(const void* table_dev, int nlayers, int q, ui
 // GDN / IGDN (gdn_3d.py:72-95, 137-159)
 // ---------------------------------------------------------------------------
 #define NVF_PEDESTAL 1.4551915228366852e-11f  /* 2^-36 */
-#define NVF_BETA_BOUND 1.0000072759311445e-03f /* sqrt(1e-6 + 2^-36) */
-#define NVF_GAMMA_BOUND 3.814697265625e-06f   /* 2^-18 */
 
 __device__ __forceinline__ float gdn_beta(float bh) {
   float m = fmaxf(bh, NVF_BETA_BOUND);

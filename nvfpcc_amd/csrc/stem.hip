@@ -12,10 +12,9 @@
 // loads before use.  Accumulation orders equal those of the per-layer kernels (conv_direct.hip), so the forward
 // is bit-identical to the unfused path.
 #include "nvf_common.h"
+#include "finals.h"
 
 #define NVF_PEDESTAL 1.4551915228366852e-11f
-#define NVF_BETA_BOUND 1.0000072759311445e-03f
-#define NVF_GAMMA_BOUND 3.814697265625e-06f
 
 namespace {
 constexpr int C0 = 8, C1 = 16, MAXCH = 8;
@@ -374,4 +373,33 @@ extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, c
   }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
+}
+
+// nvf_stem_bwd without its final launch: up0's weight-gradient slabs are left to the caller's slab reduction
+// (*dw_slabs = nslabs slabs of ch * c0 * 125 floats inside `workspace`, to be added into dw_up0 by
+// nvf_wgrad_reduce_multi*), the IGDN parameter gradients go to the deferred final passes (nvf_finals_begin; launched
+// at once when nothing is being deferred).  Same sums in the same order as nvf_stem_bwd.
+extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
+                                    const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0,
+                                    float* dx0, float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs,
+                                    void* workspace, size_t workspace_bytes, int batch, int ch, int c0, int c1,
+                                    void* stream) {
+  if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0 || !dbeta_hat ||
+      !dgamma_hat || !dw_slabs || !nslabs)
+    return NVF_EINVAL;
+  if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
+  if (!workspace || workspace_bytes < nvf_stem_bwd_workspace(batch, ch)) return NVF_EWORKSPACE;
+  const int nslab = batch < kStemMaxSlabs ? batch : kStemMaxSlabs;
+  float* slab_gdn = (float*)workspace;
+  float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * kStemNcol;
+  float* part = slab_w + (size_t)kStemMaxSlabs * ch * C0 * 125;
+  hipStream_t s = nvf_stream(stream);
+  stem_bwd_dh_kernel<<<dim3(batch, 8), 256, 0, s>>>(g1, conv0_w_bwd, part);
+  stem_bwd_kernel<<<nslab, 512, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn, slab_w,
+                                        batch, ch, 1);
+  NVF_LAUNCH_CHECK();
+  *dw_slabs = slab_w;
+  *nslabs = nslab;
+  StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab, C0};
+  return nvf_finals_run_stem_gdn(f, stream);
 }

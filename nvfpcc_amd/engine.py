@@ -393,7 +393,12 @@ class TrainEngine:
         ig = net.reconstructor.activation
         gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
         gamma_view = None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape)
-        if self.fused_stem:
+        if self.fused_stem and defer:        # its final launch is shared with the slab reduction / the final passes
+            da0, dx0 = ops.stem_bwd_partial(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta,
+                                            ig.gamma, gview("reconstructor.activation.beta"), gamma_view,
+                                            Ls["up0"].gk, self._wg)
+            self._bias_jobs.append((da0, Ls["up0"].gb))
+        elif self.fused_stem:
             da0, dx0 = ops.stem_bwd(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta, ig.gamma,
                                     gview("reconstructor.activation.beta"), gamma_view,
                                     Ls["up0"].gk if want_w else None)

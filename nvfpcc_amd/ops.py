@@ -262,6 +262,24 @@ def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=
     return da0, dx0
 
 
+def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, wg):
+    """stem_bwd whose final launch is shared: up0's weight-gradient slabs become a job of the WgradBatch ``wg``
+    (dw_up0 exists after wg.finish*), the IGDN parameter gradients a deferred final pass.  Returns (da0, dx0)."""
+    import ctypes
+    _f32(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0)
+    B, ch = x0.shape[0], x0.shape[1]
+    da0 = torch.empty_like(a0)
+    dx0 = torch.empty_like(x0)
+    ws = workspace(lib().nvf_stem_bwd_workspace(B, ch), x0.device, "stem")
+    slabs, nsl = ctypes.c_void_p(), ctypes.c_int()
+    check(lib().nvf_stem_bwd_partial(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
+                                     _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
+                                     ctypes.byref(slabs), ctypes.byref(nsl), _ptr(ws), ws.numel(), B, ch, 8, 16,
+                                     _stream()), "nvf_stem_bwd_partial")
+    wg.jobs.append((slabs.value, dw_up0.data_ptr(), nsl.value, dw_up0.numel()))
+    return da0, dx0
+
+
 def wgrad(p, q, k, stride, pad, out_mode=0, out=None, accumulate=False):
     """dw[a][b][k] (out_mode 0) or dw[b][a][flip k] (out_mode 1) = sum p[n,a,i] q[n,b,stride*i-pad+k]."""
     _f32(p, q)
