@@ -229,6 +229,19 @@ int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws
                                     const int* channels, const int* spatials, int ntensors, int batch,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* The latent tail of a training step (backward of NVFPCC.py:186-196's latent generator on [batch, c <= 8, spatial]
+ * tensors): gradient of the latent rate (+ dx_addend) -> GDN backward -> 1x1x1 weight and bias gradients, i.e.
+ * nvf_latent_rate (want_grad) + nvf_gdn_bwd + nvf_wgrad + the bias sum.  Queued here, it runs as ONE workgroup of the
+ * next nvf_wgrad_reduce_multi_and_sums launch (every input must already be enqueued on that stream) instead of three
+ * dependent launches.  NVF_EINVAL while another tail is pending. */
+int nvf_latent_tail_queue(const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
+                          const float* dx_addend, float* dlat, float* dsigma, float* dmu, const float* g_dev,
+                          float g_host, int mode, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                          const float* h, const float* beta_hat, const float* gamma_hat, float* dh, float* dbeta_hat,
+                          float* dgamma_hat, const float* e, float* dw, float* db, int batch, int c, int spatial);
+int nvf_latent_tail_pending(void);
+void nvf_latent_tail_cancel(void);
+
 /* ---- GDN / IGDN (gdn_3d.py:72-95, 137-159; LowerBound gdn_3d.py:13-29) ----------
  * beta = max(beta_hat, beta_bound)^2 - 2^-36, gamma = max(gamma_hat, 2^-18)^2 - 2^-36;
  * norm[c] = sqrt(beta[c] + sum_j gamma[c][j] x[j]^2); y = x / norm (GDN) or x * norm (IGDN).

@@ -56,6 +56,9 @@ PROTOTYPES = {
     "nvf_multi_channel_sum_workspace": (Z, [I]),
     "nvf_multi_channel_sum": (I, [P, P, P, P, I, I, P, Z, P]),
     "nvf_wgrad_reduce_multi_and_sums": (I, [P, P, P, P, I, P, P, P, P, I, I, P, Z, P]),
+    "nvf_latent_tail_queue": (I, [P, P, P, P, P, P, P, P, P, F, I, U, U, P, P, P, P, P, P, P, P, P, P, I, I, I]),
+    "nvf_latent_tail_pending": (I, []),
+    "nvf_latent_tail_cancel": (None, []),
     "nvf_finals_begin": (None, []),
     "nvf_finals_flush": (I, [P]),
     "nvf_finals_cancel": (None, []),

@@ -1,0 +1,240 @@
+// Pieces of the latent path's backward pass shared by pointwise.hip (the stand-alone launches) and wgrad.hip (the
+// "latent tail": rate gradient -> GDN backward -> 1x1x1 weight gradient run by ONE workgroup inside the launch that
+// adds up the weight-gradient slabs, instead of three dependent ~5-10 us launches on [B, c <= 8, 2^3] tensors).
+#pragma once
+#include "nvf_common.h"
+#include "finals.h"
+
+// ---- GDN re-parametrisation (gdn_3d.py:40-60) ------------------------------------------------------------------
+#define NVF_PEDESTAL 1.4551915228366852e-11f  /* 2^-36 */
+
+__device__ __forceinline__ float gdn_beta(float bh) {
+  float m = fmaxf(bh, NVF_BETA_BOUND);
+  return m * m - NVF_PEDESTAL;
+}
+__device__ __forceinline__ float gdn_gamma(float gh) {
+  float m = fmaxf(gh, NVF_GAMMA_BOUND);
+  return m * m - NVF_PEDESTAL;
+}
+
+// ---- Gaussian rate helpers (network.py:145-161) ----------------------------------------------------------------
+__device__ __forceinline__ float std_cdf(float z) { return 0.5f * (1.f + erff(z / 1.41421356237309515f)); }
+__device__ __forceinline__ float std_pdf(float z) { return 0.3989422804014327f * expf(-0.5f * z * z); }
+
+struct RateTerm {
+  float bits, dv, dmu, dsig;  // value and derivatives w.r.t. v, mu, |sigma|
+};
+
+// gsign: sign of the gradient arriving at `bits` (LowerBound passes when like >= 1e-8 OR the
+// incoming gradient on `like` is negative; that gradient is gsign * (-1/(like ln2))).
+__device__ __forceinline__ RateTerm rate_term(float v, float mu, float sabs, float half, float gsign) {
+  const float inv_ln2 = 1.4426950408889634f;
+  float up = (v - mu + half) / sabs, lo = (v - mu - half) / sabs;
+  float like = std_cdf(up) - std_cdf(lo);
+  float cl = fmaxf(like, 1e-8f);
+  RateTerm r;
+  r.bits = -1.f * logf(cl) / 0.6931471805599453f;
+  float dbits_dlike = -inv_ln2 / cl;
+  bool pass = (like >= 1e-8f) || (gsign * dbits_dlike < 0.f);
+  if (!pass) dbits_dlike = 0.f;
+  float pu = std_pdf(up), pl = std_pdf(lo);
+  r.dv = dbits_dlike * (pu - pl) / sabs;
+  r.dmu = -r.dv;
+  r.dsig = dbits_dlike * (-(pu * up - pl * lo) / sabs);
+  return r;
+}
+
+// latent quantisation + rate: one workgroup (blockDim.x threads), channel-major loops (fixed order, block
+// reductions through red[16])
+__device__ __forceinline__ void latent_rate_body(const float* __restrict__ x, const float* __restrict__ u,
+                                                 const int64_t* __restrict__ block_ids, const float* __restrict__ sigma,
+                                                 const float* __restrict__ mu, float* __restrict__ x_rounded,
+                                                 float* __restrict__ bits, float* __restrict__ dx,
+                                                 const float* __restrict__ dx_addend, float* __restrict__ dsigma,
+                                                 float* __restrict__ dmu, const float* __restrict__ g_dev, float g_host,
+                                                 int batch, int c, int spatial, int mode, uint64_t seed, uint64_t step_in,
+                                                 const uint64_t* __restrict__ step_dev, float* red) {
+  const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
+  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+  float total_bits = 0.f;
+  for (int ch = 0; ch < c; ++ch) {
+    const float sraw = sigma[ch], sabs = fabsf(sraw), m = mu[ch];
+    float sb = 0.f, ss = 0.f, sm_ = 0.f;
+    for (long e = threadIdx.x; e < (long)batch * spatial; e += blockDim.x) {
+      long b = e / spatial;
+      int s = (int)(e % spatial);
+      long idx = (b * c + ch) * spatial + s;
+      float xv = x[idx];
+      float xr = rintf(xv);
+      if (x_rounded) x_rounded[idx] = xr;
+      float v = xr;
+      if (mode == 0) {
+        float uu;
+        if (u) {
+          uu = u[idx];
+        } else {
+          uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
+          uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + s));
+        }
+        v = xv + (uu - 0.5f);
+      }
+      RateTerm r = rate_term(v, m, sabs, 0.5f, gsign);
+      sb += r.bits;
+      ss += r.dsig;
+      sm_ += r.dmu;
+      if (dx) dx[idx] = (dx_addend ? dx_addend[idx] : 0.f) + g * r.dv;
+    }
+    float tb = nvf_block_sum(sb, red);
+    float tsg = nvf_block_sum(ss, red);
+    float tm = nvf_block_sum(sm_, red);
+    if (threadIdx.x == 0) {
+      total_bits += tb;
+      float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
+      if (dsigma) dsigma[ch] = g * tsg * sgn;
+      if (dmu) dmu[ch] = g * tm;
+    }
+  }
+  if (threadIdx.x == 0 && bits) bits[0] = total_bits;
+}
+
+// ---- the latent tail ---------------------------------------------------------------------------------------------
+struct LatentTail {
+  // rate of the latents (+ the decoder's gradient arriving at them): d lat
+  const float* lat;
+  const int64_t* block_ids;
+  const float* sigma;
+  const float* mu;
+  const float* dx_addend;
+  float* dlat;
+  float* dsigma;
+  float* dmu;
+  const float* g_dev;
+  const uint64_t* step_dev;
+  uint64_t seed, step;
+  // GDN of the latent generator (forward direction): d h, d beta_hat, d gamma_hat
+  const float* h;
+  const float* beta_hat;
+  const float* gamma_hat;
+  float* dh;
+  float* dbeta_hat;
+  float* dgamma_hat;
+  // 1x1x1 convolution of the latent generator: d kernel [c][c], d bias [c]
+  const float* e;
+  float* dw;
+  float* db;
+  float g_host;
+  int32_t batch, c, spatial, mode;
+};
+
+constexpr int kTailMaxC = 8, kTailGdnT = 128;
+constexpr int kTailLds = 2 * kTailMaxC * (kTailGdnT + 1) + 16;      // floats of LDS the tail needs
+
+// GDN backward of a tensor small enough for one workgroup: the arithmetic of gdn_bwd_kernel with gridDim.x == 1 (the
+// first kTailGdnT threads do the work, every thread takes part in the barriers)
+__device__ __forceinline__ void gdn_bwd_one_workgroup(const float* __restrict__ x, const float* __restrict__ beta_hat,
+                                                      const float* __restrict__ gamma_hat, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int batch, int c, int spatial, int inverse,
+                                                      float* __restrict__ dbeta_hat, float* __restrict__ dgamma_hat,
+                                                      float* sm) {
+  constexpr int T = kTailGdnT, LD = T + 1;
+  float* ts = sm;
+  float* xs = sm + c * LD;
+  const int tid = threadIdx.x;
+  const bool worker = tid < T;
+  const int ncol = c + c * c;
+  const long nvox = (long)batch * spatial;
+  float own = 0.f;                           // ncol <= 72 < T: at most one parameter column per thread
+  for (long base = 0; base < nvox; base += T) {
+    const long v = base + tid;
+    const bool live = worker && v < nvox;
+    const long b = live ? v / spatial : 0;
+    const int s = live ? (int)(v % spatial) : 0;
+    const float* xb = x + b * c * spatial + s;
+    const float* gb = dy + b * c * spatial + s;
+    if (worker)
+      for (int ch = 0; ch < c; ++ch) {
+        float t = 0.f, xsq = 0.f;
+        if (live) {
+          float acc = gdn_beta(beta_hat[ch]);
+          for (int j = 0; j < c; ++j) {
+            float xj = xb[(long)j * spatial];
+            acc = fmaf(gdn_gamma(gamma_hat[ch * c + j]), xj * xj, acc);
+          }
+          float nrm = sqrtf(acc);
+          float xv = xb[(long)ch * spatial], g = gb[(long)ch * spatial];
+          t = inverse ? g * xv / nrm : -g * xv / (nrm * nrm * nrm);
+          xsq = xv * xv;
+        }
+        ts[ch * LD + tid] = t;
+        xs[ch * LD + tid] = xsq;
+      }
+    __syncthreads();
+    if (live) {
+      for (int i = 0; i < c; ++i) {
+        float acc = gdn_beta(beta_hat[i]);
+        for (int j = 0; j < c; ++j) acc = fmaf(gdn_gamma(gamma_hat[i * c + j]), xs[j * LD + tid], acc);
+        float nrm = sqrtf(acc);
+        float mix = 0.f;
+        for (int ch = 0; ch < c; ++ch) mix = fmaf(ts[ch * LD + tid], gdn_gamma(gamma_hat[ch * c + i]), mix);
+        float xv = xb[(long)i * spatial], g = gb[(long)i * spatial];
+        dx[(b * c + i) * spatial + s] = (inverse ? g * nrm : g / nrm) + xv * mix;
+      }
+    }
+    if (worker && tid < ncol) {
+      const int p = tid;
+      float sum = 0.f;
+      if (p < c) {
+        for (int k = 0; k < T; ++k) sum += ts[p * LD + k];
+      } else {
+        int ch = (p - c) / c, j = (p - c) % c;
+        for (int k = 0; k < T; ++k) sum = fmaf(ts[ch * LD + k], xs[j * LD + k], sum);
+      }
+      own += 0.5f * sum;
+    }
+    __syncthreads();
+  }
+  if (worker && tid < ncol) {
+    const int p = tid;
+    const float sv = 0.f + own;
+    if (p < c) {
+      const float h = beta_hat[p];
+      const float g = sv * 2.f * fmaxf(h, NVF_BETA_BOUND);
+      dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+    } else {
+      const float h = gamma_hat[p - c];
+      const float g = sv * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
+      dgamma_hat[p - c] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+    }
+  }
+}
+
+// One workgroup (>= 192 threads, whole waves), lds = kTailLds floats.  Stage results travel through global memory
+// (they are outputs anyway); a fence + barrier separates the stages.
+__device__ __forceinline__ void latent_tail_body(const LatentTail& t, float* lds) {
+  float* red = lds + 2 * kTailMaxC * (kTailGdnT + 1);
+  latent_rate_body(t.lat, nullptr, t.block_ids, t.sigma, t.mu, nullptr, nullptr, t.dlat, t.dx_addend, t.dsigma, t.dmu,
+                   t.g_dev, t.g_host, t.batch, t.c, t.spatial, t.mode, t.seed, t.step, t.step_dev, red);
+  __threadfence();
+  __syncthreads();
+  gdn_bwd_one_workgroup(t.h, t.beta_hat, t.gamma_hat, t.dlat, t.dh, t.batch, t.c, t.spatial, 0, t.dbeta_hat,
+                        t.dgamma_hat, lds);
+  __threadfence();
+  __syncthreads();
+  // d kernel[a][b] = sum dh[n, a, pos] e[n, b, pos] (one wave per output, lanes 64 apart, fixed-order wave sum: the
+  // arithmetic of wgrad_naive), then d bias[a] = sum dh[n, a, pos]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+  const long total = (long)t.batch * t.spatial;
+  for (int j = wave; j < t.c * t.c + t.c; j += nwave) {
+    const bool bias = j >= t.c * t.c;
+    const int a = bias ? j - t.c * t.c : j / t.c, b = bias ? 0 : j % t.c;
+    float acc = 0.f;
+    for (long el = lane; el < total; el += 64) {
+      const long n = el / t.spatial, r = el - n * t.spatial;
+      const float pv = t.dh[(n * t.c + a) * t.spatial + r];
+      acc = bias ? acc + pv : fmaf(pv, t.e[(n * t.c + b) * t.spatial + r], acc);
+    }
+    acc = nvf_wave_sum(acc);
+    if (lane == 0) (bias ? t.db : t.dw)[bias ? a : j] = acc;
+  }
+}

@@ -6,6 +6,7 @@
 #include "nvf_common.h"
 #include "finals.h"
 #include "pack_mfma.h"
+#include "latent_tail.h"
 
 #define NVF_GRID(n, bs) ((unsigned)(((n) + (bs)-1) / (bs)))
 
@@ -129,17 +130,6 @@ extern "C" int nvf_prepare_weights(const void* table_dev, int nlayers, int q, ui
 // ---------------------------------------------------------------------------
 // GDN / IGDN (gdn_3d.py:72-95, 137-159)
 // ---------------------------------------------------------------------------
-#define NVF_PEDESTAL 1.4551915228366852e-11f  /* 2^-36 */
-
-__device__ __forceinline__ float gdn_beta(float bh) {
-  float m = fmaxf(bh, NVF_BETA_BOUND);
-  return m * m - NVF_PEDESTAL;
-}
-__device__ __forceinline__ float gdn_gamma(float gh) {
-  float m = fmaxf(gh, NVF_GAMMA_BOUND);
-  return m * m - NVF_PEDESTAL;
-}
-
 __global__ void gdn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ beta_hat,
                                const float* __restrict__ gamma_hat, float* __restrict__ y, int batch, int c,
                                int spatial, int inverse) {
@@ -315,32 +305,6 @@ extern "C" int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* g
 // ---------------------------------------------------------------------------
 // Gaussian rate helpers (network.py:145-161)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float std_cdf(float z) { return 0.5f * (1.f + erff(z / 1.41421356237309515f)); }
-__device__ __forceinline__ float std_pdf(float z) { return 0.3989422804014327f * expf(-0.5f * z * z); }
-
-struct RateTerm {
-  float bits, dv, dmu, dsig;  // value and derivatives w.r.t. v, mu, |sigma|
-};
-
-// gsign: sign of the gradient arriving at `bits` (LowerBound passes when like >= 1e-8 OR the
-// incoming gradient on `like` is negative; that gradient is gsign * (-1/(like ln2))).
-__device__ __forceinline__ RateTerm rate_term(float v, float mu, float sabs, float half, float gsign) {
-  const float inv_ln2 = 1.4426950408889634f;
-  float up = (v - mu + half) / sabs, lo = (v - mu - half) / sabs;
-  float like = std_cdf(up) - std_cdf(lo);
-  float cl = fmaxf(like, 1e-8f);
-  RateTerm r;
-  r.bits = -1.f * logf(cl) / 0.6931471805599453f;
-  float dbits_dlike = -inv_ln2 / cl;
-  bool pass = (like >= 1e-8f) || (gsign * dbits_dlike < 0.f);
-  if (!pass) dbits_dlike = 0.f;
-  float pu = std_pdf(up), pl = std_pdf(lo);
-  r.dv = dbits_dlike * (pu - pl) / sabs;
-  r.dmu = -r.dv;
-  r.dsig = dbits_dlike * (-(pu * up - pl * lo) / sabs);
-  return r;
-}
-
 // latent quantisation + rate: one workgroup, channel-major loops (fixed order, C + 1 block reductions)
 __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const int64_t* __restrict__ block_ids,
@@ -353,48 +317,8 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
                                                            int c, int spatial, int mode, uint64_t seed, uint64_t step_in,
                                                            const uint64_t* __restrict__ step_dev) {
   __shared__ float red[16];
-  const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
-  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
-  const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
-  float total_bits = 0.f;
-  for (int ch = 0; ch < c; ++ch) {
-    const float sraw = sigma[ch], sabs = fabsf(sraw), m = mu[ch];
-    float sb = 0.f, ss = 0.f, sm_ = 0.f;
-    for (long e = threadIdx.x; e < (long)batch * spatial; e += blockDim.x) {
-      long b = e / spatial;
-      int s = (int)(e % spatial);
-      long idx = (b * c + ch) * spatial + s;
-      float xv = x[idx];
-      float xr = rintf(xv);
-      if (x_rounded) x_rounded[idx] = xr;
-      float v = xr;
-      if (mode == 0) {
-        float uu;
-        if (u) {
-          uu = u[idx];
-        } else {
-          uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
-          uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + s));
-        }
-        v = xv + (uu - 0.5f);
-      }
-      RateTerm r = rate_term(v, m, sabs, 0.5f, gsign);
-      sb += r.bits;
-      ss += r.dsig;
-      sm_ += r.dmu;
-      if (dx) dx[idx] = (dx_addend ? dx_addend[idx] : 0.f) + g * r.dv;
-    }
-    float tb = nvf_block_sum(sb, red);
-    float tsg = nvf_block_sum(ss, red);
-    float tm = nvf_block_sum(sm_, red);
-    if (threadIdx.x == 0) {
-      total_bits += tb;
-      float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
-      if (dsigma) dsigma[ch] = g * tsg * sgn;
-      if (dmu) dmu[ch] = g * tm;
-    }
-  }
-  if (threadIdx.x == 0 && bits) bits[0] = total_bits;
+  latent_rate_body(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dx_addend, dsigma, dmu, g_dev, g_host, batch, c,
+                   spatial, mode, seed, step_in, step_dev, red);
 }
 
 extern "C" int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma,

@@ -17,6 +17,7 @@
 // result is reproducible run to run (no float atomics).
 #include "nvf_common.h"
 #include "finals.h"
+#include "latent_tail.h"
 
 static const int kMaxSlabs = 512;
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
@@ -940,6 +941,51 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
   multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
 }
 
+// ... and with the latent tail (latent_tail.h) as one more workgroup, the first one dispatched
+__global__ __launch_bounds__(1024) void wgrad_reduce_sums_tail(WgReduceMulti r, int r_blocks, MultiSumDesc m,
+                                                               float* __restrict__ part, LatentTail t) {
+  __shared__ float sm[kTailLds > 16 * 64 ? kTailLds : 16 * 64];
+  if (blockIdx.x == 0) { latent_tail_body(t, sm); return; }
+  const int bid = blockIdx.x - 1;
+  if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, (float(*)[64])sm); return; }
+  const int q = bid - r_blocks;
+  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, sm);
+}
+
+namespace {
+LatentTail g_tail{};
+bool g_tail_pending = false;
+}  // namespace
+
+// Queue the latent tail of a training step (NVFPCC.py:186-196 backward of the latent generator): the gradient of the
+// latent rate (+ dx_addend, the decoder's gradient) -> GDN backward -> 1x1x1 weight and bias gradients, on
+// [batch, c <= 8, spatial] tensors.  It runs as one workgroup of the NEXT nvf_wgrad_reduce_multi_and_sums launch on
+// the same stream (all of its inputs must already be enqueued there); results = nvf_latent_rate + nvf_gdn_bwd +
+// nvf_wgrad (+ the bias sum, whose summation order differs from nvf_multi_channel_sum).
+extern "C" int nvf_latent_tail_queue(const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
+                                     const float* dx_addend, float* dlat, float* dsigma, float* dmu,
+                                     const float* g_dev, float g_host, int mode, uint64_t seed, uint64_t step,
+                                     const uint64_t* step_dev, const float* h, const float* beta_hat,
+                                     const float* gamma_hat, float* dh, float* dbeta_hat, float* dgamma_hat,
+                                     const float* e, float* dw, float* db, int batch, int c, int spatial) {
+  if (!lat || !sigma || !mu || !dlat || !dsigma || !dmu || !h || !beta_hat || !gamma_hat || !dh || !dbeta_hat ||
+      !dgamma_hat || !e || !dw || !db)
+    return NVF_EINVAL;
+  if (batch <= 0 || c <= 0 || c > kTailMaxC || spatial <= 0 || (mode != 0 && mode != 1) || g_tail_pending)
+    return NVF_EINVAL;
+  LatentTail t{};
+  t.lat = lat; t.block_ids = block_ids; t.sigma = sigma; t.mu = mu; t.dx_addend = dx_addend; t.dlat = dlat;
+  t.dsigma = dsigma; t.dmu = dmu; t.g_dev = g_dev; t.step_dev = step_dev; t.seed = seed; t.step = step;
+  t.h = h; t.beta_hat = beta_hat; t.gamma_hat = gamma_hat; t.dh = dh; t.dbeta_hat = dbeta_hat; t.dgamma_hat = dgamma_hat;
+  t.e = e; t.dw = dw; t.db = db; t.g_host = g_host; t.batch = batch; t.c = c; t.spatial = spatial; t.mode = mode;
+  g_tail = t;
+  g_tail_pending = true;
+  return NVF_OK;
+}
+
+extern "C" int nvf_latent_tail_pending(void) { return g_tail_pending ? 1 : 0; }
+extern "C" void nvf_latent_tail_cancel(void) { g_tail_pending = false; }
+
 __global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part) {
   multi_channel_sum_final_body(d, part, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -1008,7 +1054,12 @@ extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float*
   d.nchunk = batch < kSumChunks ? batch : kSumChunks;
   if (workspace_bytes < nvf_multi_channel_sum_workspace(cb)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  wgrad_reduce_and_sums<<<base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace);
+  if (g_tail_pending) {
+    g_tail_pending = false;
+    wgrad_reduce_sums_tail<<<1 + base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace, g_tail);
+  } else {
+    wgrad_reduce_and_sums<<<base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace);
+  }
   if (!nvf_finals_push_sums(d, (const float*)workspace))
     multi_channel_sum_final<<<(cb + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();

@@ -414,16 +414,30 @@ class TrainEngine:
         ec = net.entropy_coder
         sd = self._step_dev
         g_lat = self.lmbda * self.w1 / n_pts if self._g_lat_dev is None else 1.0
-        _, _, dlat, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
-                                           block_ids=block_ids, want_grad=True, g_host=g_lat, g_dev=self._g_lat_dev,
-                                           seed=self.seed, step=0 if sd is not None else self.noise_step, step_dev=sd,
-                                           dx_addend=dx0,
-                                           dsigma_out=gview("entropy_coder.sigma"), dmu_out=gview("entropy_coder.mu"))
         g2m = net.latent_gen.gdn_2
-        dh, _, _ = ops.gdn_bwd(a["h"], g2m.beta, g2m.gamma, dlat, False, gview("latent_gen.gdn_2.beta"),
-                               None if not want_w else self._g("latent_gen.gdn_2.gamma").view(g2m.gamma.shape))
-        side_wgrad(self._wgrad_conv, Ls["latent"], dh, a["e"])
-        de = self._dx_conv(Ls["latent"], dh, a["e"]) if want_emb else None
+        tail = defer and not want_emb and a["e"].shape[1] <= 8 and _NAIVE_OFF()
+        if tail:
+            # three dependent launches on [B, ch, 2^3] tensors -> one workgroup of the slab-reduction launch below;
+            # dlat / dh / dx0 stay referenced until that launch has been enqueued
+            dlat, dh = torch.empty_like(a["lat"]), torch.empty_like(a["h"])
+            ops.latent_tail_queue(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode, block_ids, dx0, dlat,
+                                  gview("entropy_coder.sigma"), gview("entropy_coder.mu"), self._g_lat_dev, g_lat,
+                                  self.seed, 0 if sd is not None else self.noise_step, sd, a["h"], g2m.beta, g2m.gamma,
+                                  dh, gview("latent_gen.gdn_2.beta"),
+                                  self._g("latent_gen.gdn_2.gamma").view(g2m.gamma.shape), a["e"], Ls["latent"].gk,
+                                  Ls["latent"].gb)
+            de = None
+        else:
+            _, _, dlat, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
+                                               block_ids=block_ids, want_grad=True, g_host=g_lat,
+                                               g_dev=self._g_lat_dev, seed=self.seed,
+                                               step=0 if sd is not None else self.noise_step, step_dev=sd,
+                                               dx_addend=dx0, dsigma_out=gview("entropy_coder.sigma"),
+                                               dmu_out=gview("entropy_coder.mu"))
+            dh, _, _ = ops.gdn_bwd(a["h"], g2m.beta, g2m.gamma, dlat, False, gview("latent_gen.gdn_2.beta"),
+                                   None if not want_w else self._g("latent_gen.gdn_2.gamma").view(g2m.gamma.shape))
+            side_wgrad(self._wgrad_conv, Ls["latent"], dh, a["e"])
+            de = self._dx_conv(Ls["latent"], dh, a["e"]) if want_emb else None
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
         # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model

@@ -564,6 +564,21 @@ def weight_rate(kernel, sigma, mu, bits_out=None, dk=None, dsigma=None, dmu=None
     return bits
 
 
+def latent_tail_queue(lat, sigma, mu, mode, block_ids, dx_addend, dlat, dsigma, dmu, g_dev, g_host, seed, step, step_dev,
+                      h, beta_hat, gamma_hat, dh, dbeta_hat, dgamma_hat, e, dw, db):
+    """latent_rate (gradient) -> gdn_bwd -> 1x1x1 weight / bias gradient as one workgroup of the next
+    WgradBatch.finish_with_sums launch on this stream (see include/nvf_hip.h).  Outputs are written in place; the
+    caller keeps every tensor alive until that launch has been enqueued."""
+    _f32(lat, sigma, mu, dx_addend, dlat, dsigma, dmu, g_dev, h, beta_hat, gamma_hat, dh, dbeta_hat, dgamma_hat, e, dw, db)
+    _chk(block_ids)
+    B, c = lat.shape[0], lat.shape[1]
+    check(lib().nvf_latent_tail_queue(_ptr(lat), _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(dx_addend), _ptr(dlat),
+                                      _ptr(dsigma), _ptr(dmu), _ptr(g_dev), float(g_host),
+                                      0 if mode == "train" else 1, int(seed), int(step), _ptr(step_dev), _ptr(h),
+                                      _ptr(beta_hat), _ptr(gamma_hat), _ptr(dh), _ptr(dbeta_hat), _ptr(dgamma_hat),
+                                      _ptr(e), _ptr(dw), _ptr(db), B, c, lat[0, 0].numel()), "nvf_latent_tail_queue")
+
+
 def finals_begin():
     """Queue the final passes of focal_loss_multi / WgradBatch.finish_with_sums / weight_rate_batch (their outputs
     exist only after finals_flush); see include/nvf_hip.h."""
@@ -572,6 +587,7 @@ def finals_begin():
 
 def finals_cancel():
     lib().nvf_finals_cancel()
+    lib().nvf_latent_tail_cancel()
 
 
 def finals_flush():

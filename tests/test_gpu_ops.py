@@ -543,6 +543,48 @@ def test_heads_loss_and_backward_data_in_one_launch(ops):
                                  wbs, cs, [None, None, None])
 
 
+@pytest.mark.parametrize("c,B", [(3, 16), (8, 5), (3, 40)])
+def test_latent_tail_inside_the_slab_reduction_launch(ops, c, B):
+    """nvf_latent_tail_queue (one workgroup of the nvf_wgrad_reduce_multi_and_sums launch) against nvf_latent_rate +
+    nvf_gdn_bwd + nvf_wgrad: every gradient bit for bit (same arithmetic, same order); the bias gradient to fp32
+    summation order.  40 blocks x 8 voxels = three 128-voxel chunks of the GDN stage."""
+    torch.manual_seed(5 + c)
+    dev_ = "cuda"
+    lat = torch.randn(B, c, 2, 2, 2, device=dev_) * 3
+    h = torch.randn(B, c, 2, 2, 2, device=dev_)
+    e = torch.randn(B, c, 2, 2, 2, device=dev_)
+    dx0 = torch.randn(B, c, 2, 2, 2, device=dev_) * 0.1
+    sigma, mu = torch.rand(c, device=dev_) + 0.5, torch.randn(c, device=dev_) * 0.1
+    beta, gamma = torch.rand(c, device=dev_) + 0.5, torch.rand(c, c, device=dev_) * 0.2
+    ids = torch.arange(B, device=dev_) * 3 + 1
+    g_dev = torch.tensor([0.37], device=dev_)
+    for mode in ("train", "eval"):
+        _, _, dlat_r, ds_r, dm_r = ops.latent_rate(lat, sigma, mu, mode, block_ids=ids, want_grad=True, g_dev=g_dev,
+                                                   g_host=1.5, seed=9, step=4, dx_addend=dx0)
+        dh_r, db_r, dg_r = ops.gdn_bwd(h, beta, gamma, dlat_r, False)
+        dw_r = ops.wgrad(dh_r, e, 1, 1, 0)
+        bias_r = dh_r.sum(dim=(0, 2, 3, 4))
+        # the tail rides on a slab reduction: give it one real weight-gradient job and one bias-sum job
+        p, q = torch.randn(B, 8, 16, 16, 16, device=dev_), torch.randn(B, 8, 19, 19, 19, device=dev_)
+        dw_other_r = ops.wgrad(p, q, 4, 1, 0)
+        wb = ops.WgradBatch(torch.device(dev_))
+        dw_other, pb = torch.empty_like(dw_other_r), torch.empty(8, device=dev_)
+        wb.add(p, q, 4, 1, 0, 0, dw_other)
+        dlat, dh = torch.full_like(lat, float("nan")), torch.full_like(h, float("nan"))
+        ds, dm = torch.empty(c, device=dev_), torch.empty(c, device=dev_)
+        dbeta, dgamma = torch.empty_like(beta), torch.empty_like(gamma)
+        dw, dbias = torch.empty(c, c, 1, 1, 1, device=dev_), torch.empty(c, device=dev_)
+        ops.latent_tail_queue(lat, sigma, mu, mode, ids, dx0, dlat, ds, dm, g_dev, 1.5, 9, 4, None, h, beta, gamma, dh,
+                              dbeta, dgamma, e, dw, dbias)
+        wb.finish_with_sums([p], [pb])
+        torch.cuda.synchronize()
+        for got, ref in ((dlat, dlat_r), (ds, ds_r), (dm, dm_r), (dh, dh_r), (dbeta, db_r), (dgamma, dg_r), (dw, dw_r),
+                         (dw_other, dw_other_r)):
+            assert torch.equal(got, ref), mode
+        np.testing.assert_allclose(dbias.cpu().numpy(), bias_r.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(pb.cpu().numpy(), p.sum(dim=(0, 2, 3, 4)).cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
 def test_small_elementwise(ops):
     g = gen(60)
     p = torch.rand(3, 1, 8, 8, 8, generator=g)
