@@ -201,7 +201,7 @@ int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const i
 
 /* the three matrix-core weight gradients of the narrow trunk in one launch (partial sums only): job 0 = conv2
  * (p = dY [B,8,32^3], q = X [B,8,35^3]), job 1 = up2 (p = X [B,8,16^3], q = dY [B,8,35^3]), job 2 = conv1
- * (p = dY [B,8,16^3], q = X [B,8,19^3]); slabs[j] holds 256 slabs of 4096 / 8000 / 4096 floats, nslabs[j] = number
+ * (p = dY [B,8,16^3], q = X [B,8,19^3]); slabs[j] holds 512 slabs of 4096 / 8000 / 4096 floats, nslabs[j] = number
  * written.  Same kernels and results as three nvf_wgrad_partial calls; two workgroups share a CU. */
 int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                             int* nslabs, void* stream);
@@ -210,6 +210,14 @@ int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, floa
  * q = dY [B,8,19^3]), job 1 = conv0 (p = X [B,8,4^3], q = dY [B,16,8^3]); slabs[j]: up to 512 slabs of 16000 floats */
 int nvf_wgrad_up1_conv0_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                                 int* nslabs, void* stream);
+
+/* the five weight gradients of the narrow trunk above the stem in ONE launch (partial sums): jobs 0-2 as
+ * nvf_wgrad_mfma3_partial (conv2, up2, conv1), jobs 3-4 as nvf_wgrad_up1_conv0_partial (up1, conv0): the two small VALU
+ * jobs fill the slots the short matrix-core workgroups leave while conv2's are still running.  slabs[0..2]: 512 slabs of
+ * 4096 / 8000 / 4096 floats, slabs[3..4]: up to 512 slabs of 16000 floats; nslabs[5].  Results identical to the two
+ * separate launches.  Like nvf_wgrad_mfma3_partial it carries a queued latent tail as its first workgroup. */
+int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                             int* nslabs, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */
@@ -232,8 +240,9 @@ int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws
 /* The latent tail of a training step (backward of NVFPCC.py:186-196's latent generator on [batch, c <= 8, spatial]
  * tensors): gradient of the latent rate (+ dx_addend) -> GDN backward -> 1x1x1 weight and bias gradients, i.e.
  * nvf_latent_rate (want_grad) + nvf_gdn_bwd + nvf_wgrad + the bias sum.  Queued here, it runs as ONE workgroup of the
- * next nvf_wgrad_reduce_multi_and_sums launch (every input must already be enqueued on that stream) instead of three
- * dependent launches.  NVF_EINVAL while another tail is pending. */
+ * next nvf_wgrad_mfma3_partial or nvf_wgrad_reduce_multi_and_sums launch, whichever comes first (every input must
+ * already be enqueued on that stream), instead of three dependent launches.  NVF_EINVAL while another tail is
+ * pending. */
 int nvf_latent_tail_queue(const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
                           const float* dx_addend, float* dlat, float* dsigma, float* dmu, const float* g_dev,
                           float g_host, int mode, uint64_t seed, uint64_t step, const uint64_t* step_dev,

@@ -44,8 +44,10 @@ __device__ __forceinline__ RateTerm rate_term(float v, float mu, float sabs, flo
   return r;
 }
 
-// latent quantisation + rate: one workgroup (blockDim.x threads), channel-major loops (fixed order, block
-// reductions through red[16])
+// latent quantisation + rate: one workgroup, channel-major loops (fixed order).  The arithmetic is that of a
+// 1024-thread workgroup whatever blockDim.x is (a divisor of 1024, whole waves): real wave w plays the virtual waves
+// w, w + nw, ..., each virtual wave's sum goes to red[], thread 0 adds them in wave order.  red: 48 floats.
+constexpr int kRateVT = 1024;
 __device__ __forceinline__ void latent_rate_body(const float* __restrict__ x, const float* __restrict__ u,
                                                  const int64_t* __restrict__ block_ids, const float* __restrict__ sigma,
                                                  const float* __restrict__ mu, float* __restrict__ x_rounded,
@@ -57,43 +59,54 @@ __device__ __forceinline__ void latent_rate_body(const float* __restrict__ x, co
   const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
   const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  constexpr int NVW = kRateVT / 64;
   float total_bits = 0.f;
   for (int ch = 0; ch < c; ++ch) {
     const float sraw = sigma[ch], sabs = fabsf(sraw), m = mu[ch];
-    float sb = 0.f, ss = 0.f, sm_ = 0.f;
-    for (long e = threadIdx.x; e < (long)batch * spatial; e += blockDim.x) {
-      long b = e / spatial;
-      int s = (int)(e % spatial);
-      long idx = (b * c + ch) * spatial + s;
-      float xv = x[idx];
-      float xr = rintf(xv);
-      if (x_rounded) x_rounded[idx] = xr;
-      float v = xr;
-      if (mode == 0) {
-        float uu;
-        if (u) {
-          uu = u[idx];
-        } else {
-          uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
-          uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + s));
+    for (int vw = wave; vw < NVW; vw += nw) {
+      float sb = 0.f, ss = 0.f, sm_ = 0.f;
+      for (long e = vw * 64 + lane; e < (long)batch * spatial; e += kRateVT) {
+        long b = e / spatial;
+        int s = (int)(e % spatial);
+        long idx = (b * c + ch) * spatial + s;
+        float xv = x[idx];
+        float xr = rintf(xv);
+        if (x_rounded) x_rounded[idx] = xr;
+        float v = xr;
+        if (mode == 0) {
+          float uu;
+          if (u) {
+            uu = u[idx];
+          } else {
+            uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
+            uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + s));
+          }
+          v = xv + (uu - 0.5f);
         }
-        v = xv + (uu - 0.5f);
+        RateTerm r = rate_term(v, m, sabs, 0.5f, gsign);
+        sb += r.bits;
+        ss += r.dsig;
+        sm_ += r.dmu;
+        if (dx) dx[idx] = (dx_addend ? dx_addend[idx] : 0.f) + g * r.dv;
       }
-      RateTerm r = rate_term(v, m, sabs, 0.5f, gsign);
-      sb += r.bits;
-      ss += r.dsig;
-      sm_ += r.dmu;
-      if (dx) dx[idx] = (dx_addend ? dx_addend[idx] : 0.f) + g * r.dv;
+      sb = nvf_wave_sum(sb);
+      ss = nvf_wave_sum(ss);
+      sm_ = nvf_wave_sum(sm_);
+      if (lane == 0) { red[vw] = sb; red[NVW + vw] = ss; red[2 * NVW + vw] = sm_; }
     }
-    float tb = nvf_block_sum(sb, red);
-    float tsg = nvf_block_sum(ss, red);
-    float tm = nvf_block_sum(sm_, red);
+    __syncthreads();
     if (threadIdx.x == 0) {
+      float tb = 0.f, tsg = 0.f, tm = 0.f;
+      for (int i = 0; i < NVW; ++i) tb += red[i];
+      for (int i = 0; i < NVW; ++i) tsg += red[NVW + i];
+      for (int i = 0; i < NVW; ++i) tm += red[2 * NVW + i];
       total_bits += tb;
       float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
       if (dsigma) dsigma[ch] = g * tsg * sgn;
       if (dmu) dmu[ch] = g * tm;
     }
+    __syncthreads();
   }
   if (threadIdx.x == 0 && bits) bits[0] = total_bits;
 }
@@ -128,7 +141,7 @@ struct LatentTail {
 };
 
 constexpr int kTailMaxC = 8, kTailGdnT = 128;
-constexpr int kTailLds = 2 * kTailMaxC * (kTailGdnT + 1) + 16;      // floats of LDS the tail needs
+constexpr int kTailLds = 2 * kTailMaxC * (kTailGdnT + 1) + 48;      // floats of LDS the tail needs
 
 // GDN backward of a tensor small enough for one workgroup: the arithmetic of gdn_bwd_kernel with gridDim.x == 1 (the
 // first kTailGdnT threads do the work, every thread takes part in the barriers)

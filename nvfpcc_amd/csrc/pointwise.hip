@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
                                                            const float* __restrict__ g_dev, float g_host, int batch,
                                                            int c, int spatial, int mode, uint64_t seed, uint64_t step_in,
                                                            const uint64_t* __restrict__ step_dev) {
-  __shared__ float red[16];
+  __shared__ float red[48];
   latent_rate_body(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dx_addend, dsigma, dmu, g_dev, g_host, batch, c,
                    spatial, mode, seed, step_in, step_dev, red);
 }

@@ -16,6 +16,8 @@
 // writes one partial slab and a second kernel adds the slabs in a fixed order, so the
 // result is reproducible run to run (no float atomics).
 #include "nvf_common.h"
+#include <cstdio>
+#include <cstdlib>
 #include "finals.h"
 #include "latent_tail.h"
 
@@ -204,6 +206,12 @@ __global__ __launch_bounds__(C0::NT) void wgrad_tiled2_kernel(WgTiled2 m) {
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef NVF_WG_EPI_REGIONS
+#define NVF_WG_EPI_REGIONS 1
+#endif
+constexpr int kWgRegion = 4096 + 64;                       // one wave's sums in the epilogue (padded)
+constexpr int kWgEpiFloats = NVF_WG_EPI_REGIONS ? 4 * kWgRegion : 4096;
+
 template <int W_, int TZ_, int TY_>
 struct MCfg {
   static constexpr int W = W_, TZ = TZ_, TY = TY_;
@@ -329,9 +337,31 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
       }
     }
   }
-  // cross-wave sum through LDS (reusing the staging area), then one slab per workgroup
+  // cross-wave sum through LDS (reusing the staging area), then one slab per workgroup.  Every wave drops its 4096
+  // sums into a region of its own (a word of padding per 64: the (co, ci) pairs of a store land on different banks),
+  // then all threads add the four regions in wave order -- the same ((w0 + w1) + w2) + w3 as a serial pass, without
+  // four rounds of dependent LDS read-modify-writes.
   __syncthreads();
   const int nn = lane & 15, ci = nn & 7, sB = nn >> 3;
+#if NVF_WG_EPI_REGIONS
+  {
+    float* reg = lds + wave * kWgRegion;
+#pragma unroll
+    for (int t2 = 0; t2 < 16; ++t2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (lane >> 4) + r, co = m & 7, sA = m >> 3;
+        const int o = (co * 8 + ci) * 64 + (t2 >> 2) * 16 + (t2 & 3) * 4 + sA + 2 * sB;
+        reg[o + (o >> 6)] = acc[t2][r];
+      }
+  }
+  __syncthreads();
+  float* slab = slabs + (size_t)bx * 4096;
+  for (int o = tid; o < 4096; o += 256) {
+    const int p = o + (o >> 6);
+    slab[o] = ((lds[p] + lds[kWgRegion + p]) + lds[2 * kWgRegion + p]) + lds[3 * kWgRegion + p];
+  }
+#else
 #pragma unroll 1
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
@@ -348,12 +378,13 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
   }
   float* slab = slabs + (size_t)bx * 4096;
   for (int o = tid; o < 4096; o += 256) slab[o] = lds[o];
+#endif
 }
 
 template <class C>
 __global__ __launch_bounds__(256) void wgrad_k4_mfma(const float* __restrict__ g, const float* __restrict__ x,
                                                      float* __restrict__ slabs, WgDims d) {
-  __shared__ float lds[C::LDSF];
+  __shared__ float lds[C::LDSF > kWgEpiFloats ? C::LDSF : kWgEpiFloats];
   wgrad_k4_mfma_body<C>(g, x, slabs, d, blockIdx.x, lds);
 }
 
@@ -529,6 +560,13 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
 // its MFMA pipes busy about half of the time (tile staging, LDS waits); 256 VGPRs and <= 80 KB of LDS per workgroup
 // let two workgroups share a CU, so the second kernel's workgroups run in the first one's bubbles.  Same bodies, same
 // slabs, same results as three launches.
+// the latent tail queued by nvf_latent_tail_queue: consumed by the next nvf_wgrad_mfma3_partial or
+// nvf_wgrad_reduce_multi_and_sums launch, whichever comes first on the stream
+namespace {
+LatentTail g_tail{};
+bool g_tail_pending = false;
+}  // namespace
+
 struct WgMfma3 {
   const float* p[3];
   const float* q[3];
@@ -538,43 +576,117 @@ struct WgMfma3 {
 };
 constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
-template <class C0, class T1, class C2>
-__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m) {
-  __shared__ float lds[wg_max3(C0::LDSF, T1::LDSF, C2::LDSF)];
+template <class C0, class T1, class C2, class U0, class U1, bool TAIL>
+__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u, LatentTail tail) {
+  static_assert(U0::NT == 256 && U1::NT == 256, "one workgroup size");
+  __shared__ __attribute__((aligned(16))) float lds[wg_max3(wg_max3(C0::LDSF, T1::LDSF, C2::LDSF), kWgEpiFloats,
+                                                            wg_max3(kTailLds, U0::LDSF, U1::LDSF))];
   int bid = blockIdx.x;
-  if (bid < m.n[0]) { wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds); return; }
+  if (TAIL) {                          // the latent tail: one workgroup, dispatched first, hidden behind the gradients
+    if (bid == 0) { latent_tail_body(tail, lds); return; }
+    --bid;
+  }
+  if (bid < m.n[0]) {
+#if NVF_WG_PRIO
+    __builtin_amdgcn_s_setprio(NVF_WG_PRIO);              // conv2's workgroups are the launch's critical path
+#endif
+    wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds);
+    return;
+  }
   bid -= m.n[0];
   if (bid < m.n[1]) { wgrad_s2k5_mfma_body<T1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid, lds); return; }
   bid -= m.n[1];
-  wgrad_k4_mfma_body<C2>(m.p[2], m.q[2], m.slabs[2], m.d[2], bid, lds);
+  if (bid < m.n[2]) { wgrad_k4_mfma_body<C2>(m.p[2], m.q[2], m.slabs[2], m.d[2], bid, lds); return; }
+  bid -= m.n[2];
+  // the two small transposed convolutions' gradients (VALU kernels, latency-bound on their own) fill the slots the
+  // short matrix-core workgroups leave while conv2's are still running
+  if (bid < u.nx[0] * u.ny[0]) {
+    wgrad_tiled_body<U0>(u.p[0], u.q[0], u.slabs[0], u.d[0], bid % u.nx[0], bid / u.nx[0], lds);
+    return;
+  }
+  bid -= u.nx[0] * u.ny[0];
+  wgrad_tiled_body<U1>(u.p[1], u.q[1], u.slabs[1], u.d[1], bid % u.nx[1], bid / u.nx[1], lds);
 }
 
-// job 0: conv2 (p = dY [B,8,32^3], q = X [B,8,35^3]); job 1: up2 (p = X [B,8,16^3], q = dY [B,8,35^3]);
-// job 2: conv1 (p = dY [B,8,16^3], q = X [B,8,19^3]).  slabs[j] must hold 256 slabs of 4096 / 8000 / 4096 floats;
-// nslabs[j] receives the number written (to be added by nvf_wgrad_reduce_multi).
-extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                                       int* nslabs, void* stream) {
+// geometry of the up1 / conv0 jobs (nvf_wgrad_up1_conv0_partial, nvf_wgrad_trunk5_partial)
+template <class U0, class U1>
+static void fill_up1_conv0(WgTiled2& m, const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                           int* nslabs) {
+  const int geo[2][6] = {{8, 8, 19, 0, 16, 8}, {4, 16, 8, 2, 8, 16}};   // wp, bc, wq, pad, a, b
+  for (int j = 0; j < 2; ++j) {
+    WgDims d{};
+    d.batch = batch; d.bc = geo[j][1]; d.dp = d.hp = d.wp = geo[j][0]; d.dq = d.hq = d.wq = geo[j][2]; d.pad = geo[j][3];
+    d.out_mode = 0; d.jtotal = geo[j][4] * geo[j][5] * 125;
+    const int tx = j == 0 ? U0::TX : U1::TX, ty = j == 0 ? U0::TY : U1::TY, tz = j == 0 ? U0::TZ : U1::TZ;
+    const int nb = j == 0 ? U0::NB : U1::NB;
+    d.tiles_x = d.wp / tx; d.tiles_y = d.hp / ty; d.tiles_z = d.dp / tz;
+    d.items = batch * d.tiles_x * d.tiles_y * d.tiles_z;
+    int n = d.items < kMaxSlabs ? d.items : kMaxSlabs;
+    d.items_per_wg = (d.items + n - 1) / n;
+    n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+    m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j]; m.d[j] = d; m.nx[j] = n; m.ny[j] = (d.bc + nb - 1) / nb;
+    nslabs[j] = n;
+  }
+}
+
+// njobs = 3: conv2, up2, conv1 (matrix cores); njobs = 5: + up1, conv0 (the VALU tile kernel with 256-thread workgroups)
+static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                               int* nslabs, int njobs, void* stream) {
   if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
   using C0 = MCfg<32, 4, 4>; using T1 = TWCfg<2, 2>; using C2 = MCfg<16, 2, 8>;
+  using U0 = WCfg<16, 5, 2, 2, 8, 4, 2, 0>; using U1 = WCfg<8, 5, 2, 2, 4, 4, 4, 0>;
+  for (int j = 0; j < njobs; ++j)
+    if (!ps[j] || !qs[j] || !slabs[j]) return NVF_EINVAL;
   WgMfma3 m{};
   const int items[3] = {batch * (32 / 4) * (32 / 4), batch * (16 / 2) * (16 / 2), batch * (16 / 8) * (16 / 2)};
   for (int j = 0; j < 3; ++j) {
-    if (!ps[j] || !qs[j] || !slabs[j]) return NVF_EINVAL;
     m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j];
     WgDims d{};
     d.batch = batch; d.bc = 8; d.items = items[j];
     // slabs (= workgroups) per job: two workgroups share a CU, so conv2 (the longest) gets one per CU and the other
     // two half of that -- fewer slabs to add up afterwards, same launch time
-    constexpr int caps[3] = {256, 128, 128};
+    static int caps[3] = {0, 0, 0};
+    if (!caps[0]) {                                          // tuning hook: NVF_WG_CAPS=a,b,c (each <= 512)
+      int c[3] = {256, 128, 128};
+      if (const char* e = getenv("NVF_WG_CAPS")) sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
+      for (int i = 0; i < 3; ++i) caps[i] = c[i] < 1 ? 1 : (c[i] > 512 ? 512 : c[i]);
+    }
     const int cap = caps[j];
     int n = items[j] < cap ? items[j] : cap;
     d.items_per_wg = (items[j] + n - 1) / n;
     n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
     m.d[j] = d; m.n[j] = n; nslabs[j] = n;
   }
-  wgrad_mfma3_kernel<C0, T1, C2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
+  WgTiled2 u{};
+  int grid = m.n[0] + m.n[1] + m.n[2];
+  if (njobs == 5) {
+    fill_up1_conv0<U0, U1>(u, ps + 3, qs + 3, slabs + 3, batch, nslabs + 3);
+    grid += u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1];
+  }
+  if (g_tail_pending) {
+    g_tail_pending = false;
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, g_tail);
+  } else {
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{});
+  }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
+}
+
+// job 0: conv2 (p = dY [B,8,32^3], q = X [B,8,35^3]); job 1: up2 (p = X [B,8,16^3], q = dY [B,8,35^3]);
+// job 2: conv1 (p = dY [B,8,16^3], q = X [B,8,19^3]).  slabs[j] must hold 512 slabs of 4096 / 8000 / 4096 floats;
+// nslabs[j] receives the number written (to be added by nvf_wgrad_reduce_multi).
+extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                                       int* nslabs, void* stream) {
+  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 3, stream);
+}
+
+// ... and jobs 3, 4 = up1 (p = X [B,16,8^3], q = dY [B,8,19^3]), conv0 (p = X [B,8,4^3], q = dY [B,16,8^3]) of
+// nvf_wgrad_up1_conv0_partial in the same launch: all five weight gradients of the narrow trunk above the stem.
+// slabs[3], slabs[4]: up to 512 slabs of 16000 floats.  Same results as the two separate launches.
+extern "C" int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
+                                        int* nslabs, void* stream) {
+  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, stream);
 }
 
 template <class C>
@@ -731,22 +843,9 @@ extern "C" int nvf_wgrad_up1_conv0_partial(const float* const* ps, const float* 
   if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
   using C0 = WCfg<16, 5, 2, 4, 8, 4, 2, 0>; using C1 = WCfg<8, 5, 2, 4, 4, 4, 4, 0>;
   WgTiled2 m{};
-  const int geo[2][6] = {{8, 8, 19, 0, 16, 8}, {4, 16, 8, 2, 8, 16}};   // wp, bc, wq, pad, a, b
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < 2; ++j)
     if (!ps[j] || !qs[j] || !slabs[j]) return NVF_EINVAL;
-    WgDims d{};
-    d.batch = batch; d.bc = geo[j][1]; d.dp = d.hp = d.wp = geo[j][0]; d.dq = d.hq = d.wq = geo[j][2]; d.pad = geo[j][3];
-    d.out_mode = 0; d.jtotal = geo[j][4] * geo[j][5] * 125;
-    const int tx = j == 0 ? C0::TX : C1::TX, ty = j == 0 ? C0::TY : C1::TY, tz = j == 0 ? C0::TZ : C1::TZ;
-    const int nb = j == 0 ? C0::NB : C1::NB;
-    d.tiles_x = d.wp / tx; d.tiles_y = d.hp / ty; d.tiles_z = d.dp / tz;
-    d.items = batch * d.tiles_x * d.tiles_y * d.tiles_z;
-    int n = d.items < kMaxSlabs ? d.items : kMaxSlabs;
-    d.items_per_wg = (d.items + n - 1) / n;
-    n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
-    m.p[j] = ps[j]; m.q[j] = qs[j]; m.slabs[j] = slabs[j]; m.d[j] = d; m.nx[j] = n; m.ny[j] = (d.bc + nb - 1) / nb;
-    nslabs[j] = n;
-  }
+  fill_up1_conv0<C0, C1>(m, ps, qs, slabs, batch, nslabs);
   wgrad_tiled2_kernel<C0, C1><<<m.nx[0] * m.ny[0] + m.nx[1] * m.ny[1], C0::NT, 0, nvf_stream(stream)>>>(m);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -888,6 +987,9 @@ extern "C" int nvf_channel_sum(const float* x, float* out, void* workspace, size
 // all bias gradients of a backward pass in two launches: out_i[c] = sum_{n,s} x_i[n,c,s] for up to 12 tensors
 // ---------------------------------------------------------------------------
 
+#ifndef NVF_SUM_T
+#define NVF_SUM_T 256
+#endif
 // `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
 // workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
 template <int T>
@@ -926,9 +1028,9 @@ __device__ __forceinline__ void multi_channel_sum_partial_body(const MultiSumDes
   if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
 }
 
-__global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
+__global__ __launch_bounds__(NVF_SUM_T) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
   __shared__ float red[16];
-  multi_channel_sum_partial_body<256>(d, part, blockIdx.x, blockIdx.y, red);
+  multi_channel_sum_partial_body<NVF_SUM_T>(d, part, blockIdx.x, blockIdx.y, red);
 }
 
 // the slab reduction of all weight gradients and the partial bias sums are independent: one launch
@@ -938,24 +1040,24 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
   const int bid = blockIdx.x;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, sm); return; }
   const int q = bid - r_blocks;
-  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
+  multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
 }
 
 // ... and with the latent tail (latent_tail.h) as one more workgroup, the first one dispatched
 __global__ __launch_bounds__(1024) void wgrad_reduce_sums_tail(WgReduceMulti r, int r_blocks, MultiSumDesc m,
                                                                float* __restrict__ part, LatentTail t) {
   __shared__ float sm[kTailLds > 16 * 64 ? kTailLds : 16 * 64];
-  if (blockIdx.x == 0) { latent_tail_body(t, sm); return; }
+  if (blockIdx.x == 0) {
+#if !NVF_TAIL_NOP
+    latent_tail_body(t, sm);
+#endif
+    return;
+  }
   const int bid = blockIdx.x - 1;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, (float(*)[64])sm); return; }
   const int q = bid - r_blocks;
-  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, sm);
+  multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, sm);
 }
-
-namespace {
-LatentTail g_tail{};
-bool g_tail_pending = false;
-}  // namespace
 
 // Queue the latent tail of a training step (NVFPCC.py:186-196 backward of the latent generator): the gradient of the
 // latent rate (+ dx_addend, the decoder's gradient) -> GDN backward -> 1x1x1 weight and bias gradients, on
@@ -1014,7 +1116,7 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
   d.nchunk = (int)nchunk;
   if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  multi_channel_sum_partial<<<dim3(base, d.nchunk), 256, 0, s>>>(d, (float*)workspace);
+  multi_channel_sum_partial<<<dim3(base, d.nchunk), NVF_SUM_T, 0, s>>>(d, (float*)workspace);
   if (!nvf_finals_push_sums(d, (const float*)workspace))
     multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();

@@ -374,8 +374,7 @@ class TrainEngine:
         if ev_t1 is not None:
             main.wait_event(ev_t1)
         g3 = self._dx_convT(Ls["up2"], g4, a["y3"], mask=a["y3"], addend=t1)
-        if wg3:
-            self._wg.add_mfma3([g5, a["y3"], g3], [a["y4"], g4, a["y2"]], [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk])
+        if wg3:     # launched after the latent tail has been queued (below): the tail rides in that launch
             self._bias_jobs += [(g5, Ls["conv2"].gb), (g4, Ls["up2"].gb), (g3, Ls["conv1"].gb)]
         else:
             side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
@@ -385,8 +384,7 @@ class TrainEngine:
         if ev_t0 is not None:
             main.wait_event(ev_t0)
         g1 = self._dx_convT(Ls["up1"], g2, a["y1"], mask=a["y1"], addend=t0)
-        if wg3:                                      # up1 and conv0 weight gradients in one launch
-            self._wg.add_up1_conv0([a["y1"], a["h0"]], [g2, g1], [Ls["up1"].gk, Ls["conv0"].gk])
+        if wg3:                                      # up1 and conv0 weight gradients: with the other three, below
             self._bias_jobs += [(g2, Ls["up1"].gb), (g1, Ls["conv0"].gb)]
         else:
             side_wgrad(self._wgrad_convT, Ls["conv0"], g1, a["h0"])
@@ -417,8 +415,8 @@ class TrainEngine:
         g2m = net.latent_gen.gdn_2
         tail = defer and not want_emb and a["e"].shape[1] <= 8 and _NAIVE_OFF()
         if tail:
-            # three dependent launches on [B, ch, 2^3] tensors -> one workgroup of the slab-reduction launch below;
-            # dlat / dh / dx0 stay referenced until that launch has been enqueued
+            # three dependent launches on [B, ch, 2^3] tensors -> one workgroup of the next weight-gradient launch
+            # (or of the slab reduction); dlat / dh / dx0 stay referenced until that launch has been enqueued
             dlat, dh = torch.empty_like(a["lat"]), torch.empty_like(a["h"])
             ops.latent_tail_queue(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode, block_ids, dx0, dlat,
                                   gview("entropy_coder.sigma"), gview("entropy_coder.mu"), self._g_lat_dev, g_lat,
@@ -438,6 +436,17 @@ class TrainEngine:
                                    None if not want_w else self._g("latent_gen.gdn_2.gamma").view(g2m.gamma.shape))
             side_wgrad(self._wgrad_conv, Ls["latent"], dh, a["e"])
             de = self._dx_conv(Ls["latent"], dh, a["e"]) if want_emb else None
+        if wg3:
+            # conv2 / up2 / conv1 weight gradients, the longest launch of the step, go last of the big kernels: the
+            # queued latent tail (a 30 us chain of three dependent stages in ONE workgroup) runs as its first workgroup
+            # and is hidden behind them instead of being the critical path of the slab reduction; up1's and conv0's
+            # gradients (small VALU kernels) fill the slots that the short matrix-core workgroups leave
+            if os.environ.get("NVF_TRUNK5", "1") == "1":
+                self._wg.add_trunk5([g5, a["y3"], g3, a["y1"], a["h0"]], [a["y4"], g4, a["y2"], g2, g1],
+                                    [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk])
+            else:
+                self._wg.add_mfma3([g5, a["y3"], g3], [a["y4"], g4, a["y2"]], [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk])
+                self._wg.add_up1_conv0([a["y1"], a["h0"]], [g2, g1], [Ls["up1"].gk, Ls["conv0"].gk])
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
         # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model

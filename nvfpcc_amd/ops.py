@@ -375,7 +375,7 @@ class WgradBatch:
         _f32(*ps, *qs, *outs)
         B = ps[0].shape[0]
         jt = (4096, 8000, 4096)
-        sizes = [(256 * j * 4 + 255) // 256 * 256 for j in jt]
+        sizes = [(512 * j * 4 + 255) // 256 * 256 for j in jt]
         if self.offset + sum(sizes) > self.ws.numel():
             if self.jobs:
                 self.finish()
@@ -413,6 +413,29 @@ class WgradBatch:
     def add_up1_conv0(self, ps, qs, outs):
         """up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch, two reduction jobs."""
         self._grouped(lib().nvf_wgrad_up1_conv0_partial, "nvf_wgrad_up1_conv0_partial", ps, qs, outs, (16000, 16000), 512)
+
+    def add_trunk5(self, ps, qs, outs):
+        """conv2 / up2 / conv1 / up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch (which also
+        carries a queued latent tail), five reduction jobs.  ps/qs/outs: add_mfma3's three, then add_up1_conv0's two."""
+        import ctypes
+        _f32(*ps, *qs, *outs)
+        B = ps[0].shape[0]
+        jt = (4096, 8000, 4096, 16000, 16000)
+        sizes = [(512 * j * 4 + 255) // 256 * 256 for j in jt]
+        if self.offset + sum(sizes) > self.ws.numel():
+            if self.jobs:
+                self.finish()
+            self._retired.append(self.ws)
+            self.ws = torch.empty(max(sum(sizes), 2 * self.ws.numel()), dtype=torch.uint8, device=self.device)
+        bases = []
+        for sz in sizes:
+            bases.append(self.ws.data_ptr() + self.offset)
+            self.offset += sz
+        nsl = (ctypes.c_int * 5)()
+        check(lib().nvf_wgrad_trunk5_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases), B, nsl, _stream()),
+              "nvf_wgrad_trunk5_partial")
+        for h in range(5):
+            self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
 
     def add_heads3(self, dls, xs, outs, max_slabs=512):
         """Weight gradients of the three classifier heads: one partial-sum launch, three reduction jobs."""

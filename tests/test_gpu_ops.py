@@ -161,7 +161,7 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     y3, g4 = R(B, 8, 16, 16, 16), R(B, 8, 35, 35, 35)
     g3, y2 = R(B, 8, 16, 16, 16), R(B, 8, 19, 19, 19)
     outs = [torch.empty(8, 8, k, k, k, device=g5.device) for k in (4, 5, 4)]
-    wg = ops.WgradBatch(g5.device, nbytes=64 << 20)
+    wg = ops.WgradBatch(g5.device, nbytes=128 << 20)
     wg.add_mfma3([g5, y3, g3], [y4, g4, y2], outs)
     wg.finish()
     assert torch.equal(outs[0], ops.wgrad(g5, y4, 4, 1, 0, out_mode=0))
@@ -175,6 +175,12 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     wg.finish()
     assert torch.equal(outs2[0], ops.wgrad(y1, g2, 5, 2, 0, out_mode=0))
     assert torch.equal(outs2[1], ops.wgrad(h0, g1, 5, 2, 2, out_mode=0))
+    # ... and all five in one launch (nvf_wgrad_trunk5_partial: the two VALU jobs run as 256-thread workgroups)
+    outs5 = [torch.empty_like(o) for o in outs + outs2]
+    wg.add_trunk5([g5, y3, g3, y1, h0], [y4, g4, y2, g2, g1], outs5)
+    wg.finish()
+    for got, ref in zip(outs5, outs + outs2):
+        assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("mode,c", [("train", 3), ("eval", 8)])
