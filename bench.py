@@ -191,6 +191,8 @@ def main():
                lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
     # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
     probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
+    # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
+    probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs: True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -252,7 +254,9 @@ def main():
             us = single[label]
             # algorithmic MACs of what the launch computes (not the halo / padding lanes it also executes);
             # the three-gradient launch: conv2 + up2 (32 768 000 MAC/block) + conv1 (16 777 216), SURVEY 2.1
-            layer_macs = {"wgrad_conv2_up2_conv1": macs + 32768000 + 16777216}
+            # the five-gradient launch adds up1 (8 192 000) and conv0 (1 024 000)
+            layer_macs = {"wgrad_conv2_up2_conv1": macs + 32768000 + 16777216,
+                          "wgrad_trunk5": macs + 32768000 + 16777216 + 8192000 + 1024000}
             flops = 2.0 * layer_macs.get(label, macs) * B
             achieved = flops / (us * 1e-6) / 1e12
             traffic = None
@@ -260,7 +264,8 @@ def main():
             if os.path.isfile(tj):     # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/)
                 t = json.load(open(tj))
                 if t.get("batch") == B and t.get("chanstr") == args.chanstr:
-                    traffic = t["hbm_bytes_per_launch"].get({"wgrad_conv2_up2_conv1": "conv2_bwd_weight"}.get(label, label))
+                    traffic = t["hbm_bytes_per_launch"].get({"wgrad_conv2_up2_conv1": "conv2_bwd_weight",
+                                                                 "wgrad_trunk5": "conv2_bwd_weight"}.get(label, label))
             roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_us": round(us, 2), "flops_per_launch": flops,

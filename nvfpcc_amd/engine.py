@@ -441,12 +441,8 @@ class TrainEngine:
             # queued latent tail (a 30 us chain of three dependent stages in ONE workgroup) runs as its first workgroup
             # and is hidden behind them instead of being the critical path of the slab reduction; up1's and conv0's
             # gradients (small VALU kernels) fill the slots that the short matrix-core workgroups leave
-            if os.environ.get("NVF_TRUNK5", "1") == "1":
-                self._wg.add_trunk5([g5, a["y3"], g3, a["y1"], a["h0"]], [a["y4"], g4, a["y2"], g2, g1],
-                                    [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk])
-            else:
-                self._wg.add_mfma3([g5, a["y3"], g3], [a["y4"], g4, a["y2"]], [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk])
-                self._wg.add_up1_conv0([a["y1"], a["h0"]], [g2, g1], [Ls["up1"].gk, Ls["conv0"].gk])
+            self._wg.add_trunk5([g5, a["y3"], g3, a["y1"], a["h0"]], [a["y4"], g4, a["y2"], g2, g1],
+                                [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk])
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
         # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model

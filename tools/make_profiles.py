@@ -64,7 +64,7 @@ def main():
               "conv2_bwd_data": find("conv_k4_mfma<MCvFlat<8, 18") or find("conv_gather_glds<GCfg<8, 8, 4, 1, 4, 9"),
               "conv2_fwd": find("conv_k4_mfma<MCv<8, 0, 1, 16"),
               "conv2_bwd_weight": find("wgrad_mfma3_kernel") or find("wgrad_k4_mfma<MCfg<32")},
-          "note": "conv2_bwd_weight is the one-launch kernel that also holds the up2 and conv1 weight gradients"}
+          "note": "conv2_bwd_weight is the one-launch kernel that also holds the up2, conv1, up1 and conv0 weight gradients"}
     json.dump(tj, open(os.path.join(prof, f"{tag}_traffic.json"), "w"), indent=1)
     names = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
              "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA"]
