@@ -161,6 +161,16 @@ int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs
 int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
                  const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
                  float* y1, int batch, int ch, int c0, int c1, void* stream);
+
+/* nvf_latent_fwd and nvf_stem_fwd in ONE launch (the stem's workgroups compute their block's rounded latents themselves;
+ * one more workgroup produces h, lat, x_rounded and the latent rate of the whole batch); results of the two calls, bit
+ * for bit.  utils/network.py:4592-4612, 4514-4539, 4759-4760. */
+int nvf_stem_latent_fwd(const float* e, const float* lat_w_fwd, const float* lat_bias, const float* lat_beta_hat,
+                        const float* lat_gamma_hat, const int64_t* block_ids, const float* sigma, const float* mu,
+                        float* h, float* lat, float* x_rounded, float* bits, int mode, uint64_t seed, uint64_t step,
+                        const uint64_t* step_dev, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
+                        const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
+                        float* y1, int batch, int ch, int c0, int c1, void* stream);
 size_t nvf_stem_bwd_workspace(int batch, int ch);
 int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                  const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,

@@ -111,6 +111,115 @@ __device__ __forceinline__ void latent_rate_body(const float* __restrict__ x, co
   if (threadIdx.x == 0 && bits) bits[0] = total_bits;
 }
 
+// ---- latent generator + quantiser, forward (nvf_latent_fwd; also one workgroup of nvf_stem_latent_fwd) --------
+// e -> 1x1x1 conv (+ bias) -> GDN -> round / noise + rate for ALL blocks by one workgroup; the arithmetic of
+// nvf_conv3d_gather (k = 1) + nvf_gdn_fwd + nvf_latent_rate, and that of a 1024-thread workgroup whatever blockDim.x
+// is (see latent_rate_body).  s_par: 144 + 16 floats of LDS.
+__device__ __forceinline__ void latent_fwd_body(const float* __restrict__ e, const float* __restrict__ w,
+                                                const float* __restrict__ bw, const float* __restrict__ beta_hat,
+                                                const float* __restrict__ gamma_hat,
+                                                const int64_t* __restrict__ block_ids, const float* __restrict__ sigma,
+                                                const float* __restrict__ mu, float* __restrict__ h_out,
+                                                float* __restrict__ lat_out, float* __restrict__ x_rounded,
+                                                float* __restrict__ bits, int batch, int c, int spatial, int mode,
+                                                uint64_t seed, uint64_t step_in, const uint64_t* __restrict__ step_dev,
+                                                float* s_par) {
+  float* s_w = s_par;            // [64]  w_fwd layout [ci][co]
+  float* s_gamma = s_par + 64;   // [64]
+  float* s_b = s_par + 128;      // [8]
+  float* s_beta = s_par + 136;   // [8]
+  float* red = s_par + 144;      // [16]
+  if ((int)threadIdx.x < c * c) {
+    s_w[threadIdx.x] = w[threadIdx.x];
+    s_gamma[threadIdx.x] = gdn_gamma(gamma_hat[threadIdx.x]);
+  }
+  if ((int)threadIdx.x < c) {
+    s_b[threadIdx.x] = bw[threadIdx.x];
+    s_beta[threadIdx.x] = gdn_beta(beta_hat[threadIdx.x]);
+  }
+  __syncthreads();
+  const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  constexpr int NVW = kRateVT / 64;
+  float total_bits = 0.f;
+  for (int ch = 0; ch < c; ++ch) {
+    const float sabs = fabsf(sigma[ch]), m = mu[ch];
+    for (int vw = wave; vw < NVW; vw += nw) {
+      float sb = 0.f;
+      for (long el = vw * 64 + lane; el < (long)batch * spatial; el += kRateVT) {
+        const long b = el / spatial;
+        const int sp = (int)(el % spatial);
+        float h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j < c) {
+            float acc = 0.f;
+            for (int i = 0; i < c; ++i) acc = fmaf(e[(b * c + i) * spatial + sp], s_w[i * c + j], acc);
+            h[j] = acc + s_b[j];
+          }
+        }
+        float nrm = s_beta[ch], hc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j < c) {
+            nrm = fmaf(s_gamma[ch * c + j], h[j] * h[j], nrm);
+            if (j == ch) hc = h[j];
+          }
+        }
+        const float xv = hc / sqrtf(nrm);
+        const long idx = (b * c + ch) * spatial + sp;
+        h_out[idx] = hc;
+        lat_out[idx] = xv;
+        const float xr = rintf(xv);
+        x_rounded[idx] = xr;
+        float v = xr;
+        if (mode == 0) {
+          const uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
+          const float uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + sp));
+          v = xv + (uu - 0.5f);
+        }
+        sb += rate_term(v, m, sabs, 0.5f, 0.f).bits;
+      }
+      sb = nvf_wave_sum(sb);
+      if (lane == 0) red[vw] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tb = 0.f;
+      for (int i = 0; i < NVW; ++i) tb += red[i];
+      total_bits += tb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bits[0] = total_bits;
+}
+
+// rounded latent of ONE element (block b, channel ch, voxel sp) -- what latent_fwd_body writes to x_rounded, for a
+// consumer that wants it without waiting for that workgroup (the fused stem); parameters straight from global memory
+__device__ __forceinline__ float latent_x_rounded(const float* __restrict__ e, const float* __restrict__ w,
+                                                  const float* __restrict__ bw, const float* __restrict__ beta_hat,
+                                                  const float* __restrict__ gamma_hat, long b, int ch, int sp, int c,
+                                                  int spatial) {
+  float h[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < c) {
+      float acc = 0.f;
+      for (int i = 0; i < c; ++i) acc = fmaf(e[(b * c + i) * spatial + sp], w[i * c + j], acc);
+      h[j] = acc + bw[j];
+    }
+  }
+  float nrm = gdn_beta(beta_hat[ch]), hc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < c) {
+      nrm = fmaf(gdn_gamma(gamma_hat[ch * c + j]), h[j] * h[j], nrm);
+      if (j == ch) hc = h[j];
+    }
+  }
+  return rintf(hc / sqrtf(nrm));
+}
+
 // ---- the latent tail ---------------------------------------------------------------------------------------------
 struct LatentTail {
   // rate of the latents (+ the decoder's gradient arriving at them): d lat

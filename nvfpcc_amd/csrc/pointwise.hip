@@ -348,60 +348,9 @@ __global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restric
                                                           float* __restrict__ x_rounded, float* __restrict__ bits,
                                                           int batch, int c, int spatial, int mode, uint64_t seed,
                                                           uint64_t step_in, const uint64_t* __restrict__ step_dev) {
-  __shared__ float red[16];
-  __shared__ float s_w[64], s_b[8], s_beta[8], s_gamma[64];
-  if ((int)threadIdx.x < c * c) {
-    s_w[threadIdx.x] = w[threadIdx.x];                       // w_fwd layout [ci][co]
-    s_gamma[threadIdx.x] = gdn_gamma(gamma_hat[threadIdx.x]);
-  }
-  if ((int)threadIdx.x < c) {
-    s_b[threadIdx.x] = bw[threadIdx.x];
-    s_beta[threadIdx.x] = gdn_beta(beta_hat[threadIdx.x]);
-  }
-  __syncthreads();
-  const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
-  float total_bits = 0.f;
-  for (int ch = 0; ch < c; ++ch) {
-    const float sabs = fabsf(sigma[ch]), m = mu[ch];
-    float sb = 0.f;
-    for (long el = threadIdx.x; el < (long)batch * spatial; el += blockDim.x) {
-      const long b = el / spatial;
-      const int sp = (int)(el % spatial);
-      float h[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < c) {
-          float acc = 0.f;
-          for (int i = 0; i < c; ++i) acc = fmaf(e[(b * c + i) * spatial + sp], s_w[i * c + j], acc);
-          h[j] = acc + s_b[j];
-        }
-      }
-      float nrm = s_beta[ch], hc = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < c) {
-          nrm = fmaf(s_gamma[ch * c + j], h[j] * h[j], nrm);
-          if (j == ch) hc = h[j];
-        }
-      }
-      const float xv = hc / sqrtf(nrm);
-      const long idx = (b * c + ch) * spatial + sp;
-      h_out[idx] = hc;
-      lat_out[idx] = xv;
-      const float xr = rintf(xv);
-      x_rounded[idx] = xr;
-      float v = xr;
-      if (mode == 0) {
-        const uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
-        const float uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + sp));
-        v = xv + (uu - 0.5f);
-      }
-      sb += rate_term(v, m, sabs, 0.5f, 0.f).bits;
-    }
-    const float tb = nvf_block_sum(sb, red);
-    if (threadIdx.x == 0) total_bits += tb;
-  }
-  if (threadIdx.x == 0) bits[0] = total_bits;
+  __shared__ float s_par[160];
+  latent_fwd_body(e, w, bw, beta_hat, gamma_hat, block_ids, sigma, mu, h_out, lat_out, x_rounded, bits, batch, c, spatial,
+                  mode, seed, step_in, step_dev, s_par);
 }
 
 extern "C" int nvf_latent_fwd(const float* e, const float* w_fwd, const float* bias, const float* beta_hat,

@@ -13,8 +13,7 @@
 // is bit-identical to the unfused path.
 #include "nvf_common.h"
 #include "finals.h"
-
-#define NVF_PEDESTAL 1.4551915228366852e-11f
+#include "latent_tail.h"
 
 namespace {
 constexpr int C0 = 8, C1 = 16, MAXCH = 8;
@@ -61,22 +60,52 @@ __device__ __forceinline__ void stem_conv0_class(const float* s_h, const float* 
 // grid = (batch, C1 / COG): every workgroup recomputes the (tiny) up0 + IGDN of its block and produces COG of
 // conv0's 16 output channels, so a batch of 16 blocks runs on 64 CUs instead of 16.  All weights are copied to
 // LDS with coalesced vector loads first: scalar loads in the tap loops were a chain of cache misses.
-template <int COG>
+// The latent generator + quantiser (nvf_latent_fwd) for the launch that also runs the stem: the stem's workgroups
+// compute the 8 ch rounded latents of their own block themselves (latent_x_rounded: the same arithmetic), so they do
+// not wait for the one workgroup (blockIdx = (0, C1 / COG)) that produces h, lat, x_rounded and the rate for the
+// whole batch.
+struct StemLatent {
+  const float* e;
+  const float* w;          // latent generator's w_fwd [ci][co], bias
+  const float* bw;
+  const float* beta_hat;   // its GDN
+  const float* gamma_hat;
+  const int64_t* block_ids;
+  const float* sigma;
+  const float* mu;
+  float* h_out;
+  float* lat_out;
+  float* x_rounded;
+  float* bits;
+  const uint64_t* step_dev;
+  uint64_t seed, step;
+  int32_t mode, batch;
+};
+
+template <int COG, bool LATENT>
 __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w0,
                                                        const float* __restrict__ b0,
                                                        const float* __restrict__ beta_hat,
                                                        const float* __restrict__ gamma_hat,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        float* __restrict__ a0, float* __restrict__ h0,
-                                                       float* __restrict__ y1, int ch) {
+                                                       float* __restrict__ y1, int ch, StemLatent L) {
   __shared__ float s_x[MAXCH * 8];
   __shared__ float s_a[C0 * 64];
+  if (LATENT && blockIdx.y == C1 / COG) {
+    if (blockIdx.x == 0)
+      latent_fwd_body(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, L.block_ids, L.sigma, L.mu, L.h_out, L.lat_out,
+                      L.x_rounded, L.bits, L.batch, ch, 8, L.mode, L.seed, L.step, L.step_dev, s_a);
+    return;
+  }
   __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1
   __shared__ __attribute__((aligned(16))) float s_w0[MAXCH * 125 * C0];
   __shared__ __attribute__((aligned(16))) float s_w1[C0 * 125 * COG];
   __shared__ float s_beta[C0], s_gamma[C0 * C0];
   const int b = blockIdx.x, part = blockIdx.y, co0 = part * COG, tid = threadIdx.x;
-  if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
+  if (tid < ch * 8)
+    s_x[tid] = LATENT ? latent_x_rounded(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, b, tid >> 3, tid & 7, ch, 8)
+                      : x0[(size_t)b * ch * 8 + tid];
   if (tid >= 64 && tid < 64 + C0) s_beta[tid - 64] = st_beta(beta_hat[tid - 64]);
   if (tid >= 128 && tid < 128 + C0 * C0) s_gamma[tid - 128] = st_gamma(gamma_hat[tid - 128]);
   for (int e = tid; e < C0 * 216; e += 512) s_h[e] = 0.f;
@@ -143,8 +172,30 @@ extern "C" int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float
     return NVF_EINVAL;
   if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
   constexpr int COG = 4;
-  stem_fwd_kernel<COG><<<dim3(batch, C1 / COG), 512, 0, nvf_stream(stream)>>>(
-      x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch);
+  stem_fwd_kernel<COG, false><<<dim3(batch, C1 / COG), 512, 0, nvf_stream(stream)>>>(
+      x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch, StemLatent{});
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// nvf_latent_fwd (e -> h, lat, x_rounded, bits) and nvf_stem_fwd (x_rounded -> a0, h0, y1) in ONE launch; same results
+// as the two calls, bit for bit.  Latent tensors are [batch, ch <= 8, 2^3].
+extern "C" int nvf_stem_latent_fwd(const float* e, const float* lat_w_fwd, const float* lat_bias,
+                                   const float* lat_beta_hat, const float* lat_gamma_hat, const int64_t* block_ids,
+                                   const float* sigma, const float* mu, float* h, float* lat, float* x_rounded,
+                                   float* bits, int mode, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                                   const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
+                                   const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0,
+                                   float* h0, float* y1, int batch, int ch, int c0, int c1, void* stream) {
+  if (!e || !lat_w_fwd || !lat_bias || !lat_beta_hat || !lat_gamma_hat || !sigma || !mu || !h || !lat || !x_rounded ||
+      !bits || !up0_w_fwd || !up0_b || !beta_hat || !gamma_hat || !conv0_w_fwd || !conv0_b || !a0 || !h0 || !y1)
+    return NVF_EINVAL;
+  if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1 || (mode != 0 && mode != 1)) return NVF_EINVAL;
+  constexpr int COG = 4;
+  StemLatent L{e, lat_w_fwd, lat_bias, lat_beta_hat, lat_gamma_hat, block_ids, sigma, mu, h, lat, x_rounded, bits,
+               step_dev, seed, step, mode, batch};
+  stem_fwd_kernel<COG, true><<<dim3(batch, C1 / COG + 1), 512, 0, nvf_stream(stream)>>>(
+      nullptr, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch, L);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -94,6 +94,7 @@ class TrainEngine:
         # one stream; NVF_OVERLAP=1 turns the two-stream schedule back on.
         self.allow_overlap = os.environ.get("NVF_OVERLAP", "0") == "1"
         self.fused_stem = tuple(net.reconstructor.channels[:2]) == (8, 16) and net.entropy_coder.sigma.shape[1] <= 8
+        self.fused_latent_stem = True      # latent generator + quantiser ride in the stem's forward launch
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
         self._wg = None
@@ -228,7 +229,16 @@ class TrainEngine:
         g2 = net.latent_gen.gdn_2
         ec = net.entropy_coder
         sd = self._step_dev
-        if e.shape[1] <= 8 and _NAIVE_OFF():         # latent generator + quantiser in one launch
+        ig = net.reconstructor.activation
+        stem_done = False
+        if e.shape[1] <= 8 and _NAIVE_OFF() and self.fused_stem and self.fused_latent_stem:   # latent generator,
+            # quantiser and stem in one launch
+            (a["h"], a["lat"], a["x0"], a["lbits"], a["a0"], a["h0"], a["y1"]) = ops.stem_latent_fwd(
+                e, Ls["latent"].w_fwd, Ls["latent"].b_eff, g2.beta, g2.gamma, ec.sigma.reshape(-1), ec.mu.reshape(-1),
+                mode, Ls["up0"].w_fwd, Ls["up0"].b_eff, ig.beta, ig.gamma, Ls["conv0"].w_fwd, Ls["conv0"].b_eff,
+                block_ids=block_ids, seed=self.seed, step=0 if sd is not None else self.noise_step, step_dev=sd)
+            stem_done = True
+        elif e.shape[1] <= 8 and _NAIVE_OFF():         # latent generator + quantiser in one launch
             a["h"], a["lat"], a["x0"], a["lbits"] = ops.latent_fwd(
                 e, Ls["latent"].w_fwd, Ls["latent"].b_eff, g2.beta, g2.gamma, ec.sigma.reshape(-1), ec.mu.reshape(-1),
                 mode, block_ids=block_ids, seed=self.seed, step=0 if sd is not None else self.noise_step, step_dev=sd)
@@ -238,9 +248,10 @@ class TrainEngine:
             a["x0"], a["lbits"], _, _, _ = ops.latent_rate(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode,
                                                            block_ids=block_ids, seed=self.seed,
                                                            step=0 if sd is not None else self.noise_step, step_dev=sd)
-        ig = net.reconstructor.activation
         self.overlap = self.allow_overlap and e.shape[0] <= 64   # large batches fill the chip by themselves
-        if self.fused_stem:
+        if stem_done:
+            pass
+        elif self.fused_stem:
             a["a0"], a["h0"], a["y1"] = ops.stem_fwd(a["x0"], Ls["up0"].w_fwd, Ls["up0"].b_eff, ig.beta, ig.gamma,
                                                      Ls["conv0"].w_fwd, Ls["conv0"].b_eff)
         else:

@@ -248,6 +248,29 @@ def stem_fwd(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b):
     return a0, h0, y1
 
 
+def stem_latent_fwd(e, lat_w_fwd, lat_bias, lat_beta_hat, lat_gamma_hat, sigma, mu, mode, up0_w_fwd, up0_b, beta_hat,
+                    gamma_hat, conv0_w_fwd, conv0_b, block_ids=None, seed=0, step=0, step_dev=None):
+    """latent_fwd and stem_fwd in one launch: returns (h, lat, x_rounded, bits[1], a0, h0, y1), bit-identical to the
+    two calls."""
+    _f32(e, lat_w_fwd, lat_bias, lat_beta_hat, lat_gamma_hat, sigma, mu, up0_w_fwd, up0_b, beta_hat, gamma_hat,
+         conv0_w_fwd, conv0_b)
+    _chk(block_ids)
+    B, ch = e.shape[0], e.shape[1]
+    if e[0, 0].numel() != 8:
+        raise ValueError("stem_latent_fwd: latents are [B, ch, 2, 2, 2]")
+    h, lat, xr = torch.empty_like(e), torch.empty_like(e), torch.empty_like(e)
+    bits = torch.empty(1, device=e.device)
+    a0 = torch.empty((B, 8, 4, 4, 4), device=e.device)
+    h0 = torch.empty((B, 8, 4, 4, 4), device=e.device)
+    y1 = torch.empty((B, 16, 8, 8, 8), device=e.device)
+    check(lib().nvf_stem_latent_fwd(_ptr(e), _ptr(lat_w_fwd), _ptr(lat_bias), _ptr(lat_beta_hat), _ptr(lat_gamma_hat),
+                                    _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(h), _ptr(lat), _ptr(xr), _ptr(bits),
+                                    0 if mode == "train" else 1, int(seed), int(step), _ptr(step_dev), _ptr(up0_w_fwd),
+                                    _ptr(up0_b), _ptr(beta_hat), _ptr(gamma_hat), _ptr(conv0_w_fwd), _ptr(conv0_b),
+                                    _ptr(a0), _ptr(h0), _ptr(y1), B, ch, 8, 16, _stream()), "nvf_stem_latent_fwd")
+    return h, lat, xr, bits, a0, h0, y1
+
+
 def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=None, dgamma_out=None, dw_up0=None):
     """Fused conv0 backward-data -> IGDN backward -> up0 backward-data (+ IGDN / up0 parameter gradients when
     the three outputs are given).  Returns (da0, dx0)."""

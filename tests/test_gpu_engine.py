@@ -156,6 +156,26 @@ def test_fused_stem_equals_the_per_layer_kernels(gpu):
     close(de, de2, tol=1e-5)
 
 
+def test_latent_generator_and_stem_in_one_launch(gpu):
+    """nvf_stem_latent_fwd against nvf_latent_fwd + nvf_stem_fwd: every saved activation bit for bit, train (noise in
+    the rate) and eval mode; the stem's workgroups recompute their block's rounded latents with the same arithmetic."""
+    net, eng, gt, dist, emb = make("S", gpu)
+    assert eng.fused_stem and eng.fused_latent_stem
+    ids = torch.tensor([0, 2, 5, 1, 3], device=gpu)
+    e = (emb[ids] * 2.5).contiguous()                    # spread the latents over several integers
+    for mode, q in (("train", 1), ("eval", 2)):
+        eng.prepare_weights(q)
+        eng.fused_latent_stem = True
+        a = eng.forward(e, mode, ids)
+        eng.fused_latent_stem = False
+        b = eng.forward(e, mode, ids)
+        torch.cuda.synchronize()
+        for k in ("h", "lat", "x0", "lbits", "a0", "h0", "y1", "p0", "p2"):
+            assert torch.equal(a[k], b[k]), (mode, k)
+        assert a["x0"].abs().max().item() >= 1.0
+    eng.fused_latent_stem = True
+
+
 @pytest.mark.parametrize("tag", ["S", "W"])
 def test_one_launch_step_head_equals_the_three_launches(tag, gpu):
     """nvf_step_head (effective weights + MFMA packings + mini-batch gather in one launch; the packings recompute
