@@ -209,6 +209,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef NVF_WG_EPI_REGIONS
 #define NVF_WG_EPI_REGIONS 1
 #endif
+#ifndef NVF_WG_DBG
+#define NVF_WG_DBG 0
+#endif
 constexpr int kWgRegion = 4096 + 64;                       // one wave's sums in the epilogue (padded)
 constexpr int kWgEpiFloats = NVF_WG_EPI_REGIONS ? 4 * kWgRegion : 4096;
 
@@ -307,9 +310,18 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
     (void)y0; (void)z0;
     __syncthreads();                                        // zero fill done / previous item no longer being read
+#if NVF_WG_DBG != 1                                         // tuning builds: 1 = stage the first item only, 2 = no MFMAs
     store();
+#else
+    if (item == first) store();
+#endif
     __syncthreads();
+#if NVF_WG_DBG != 1
     if (item + 1 < last) load(item + 1);
+#endif
+#if NVF_WG_DBG == 2
+    if (d.items >= 0) continue;
+#endif
 #pragma unroll 1
     for (int row = wave; row < TZ * TY; row += 4) {
       const int zz = row / TY, yy = row % TY;
@@ -586,13 +598,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
     if (bid == 0) { latent_tail_body(tail, lds); return; }
     --bid;
   }
-  if (bid < m.n[0]) {
-#if NVF_WG_PRIO
-    __builtin_amdgcn_s_setprio(NVF_WG_PRIO);              // conv2's workgroups are the launch's critical path
-#endif
-    wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds);
-    return;
-  }
+  if (bid < m.n[0]) { wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds); return; }
   bid -= m.n[0];
   if (bid < m.n[1]) { wgrad_s2k5_mfma_body<T1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid, lds); return; }
   bid -= m.n[1];
@@ -987,9 +993,6 @@ extern "C" int nvf_channel_sum(const float* x, float* out, void* workspace, size
 // all bias gradients of a backward pass in two launches: out_i[c] = sum_{n,s} x_i[n,c,s] for up to 12 tensors
 // ---------------------------------------------------------------------------
 
-#ifndef NVF_SUM_T
-#define NVF_SUM_T 256
-#endif
 // `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
 // workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
 template <int T>
@@ -1028,9 +1031,9 @@ __device__ __forceinline__ void multi_channel_sum_partial_body(const MultiSumDes
   if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
 }
 
-__global__ __launch_bounds__(NVF_SUM_T) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
   __shared__ float red[16];
-  multi_channel_sum_partial_body<NVF_SUM_T>(d, part, blockIdx.x, blockIdx.y, red);
+  multi_channel_sum_partial_body<256>(d, part, blockIdx.x, blockIdx.y, red);
 }
 
 // the slab reduction of all weight gradients and the partial bias sums are independent: one launch
@@ -1040,23 +1043,18 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
   const int bid = blockIdx.x;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, sm); return; }
   const int q = bid - r_blocks;
-  multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
+  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
 }
 
 // ... and with the latent tail (latent_tail.h) as one more workgroup, the first one dispatched
 __global__ __launch_bounds__(1024) void wgrad_reduce_sums_tail(WgReduceMulti r, int r_blocks, MultiSumDesc m,
                                                                float* __restrict__ part, LatentTail t) {
   __shared__ float sm[kTailLds > 16 * 64 ? kTailLds : 16 * 64];
-  if (blockIdx.x == 0) {
-#if !NVF_TAIL_NOP
-    latent_tail_body(t, sm);
-#endif
-    return;
-  }
+  if (blockIdx.x == 0) { latent_tail_body(t, sm); return; }
   const int bid = blockIdx.x - 1;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, (float(*)[64])sm); return; }
   const int q = bid - r_blocks;
-  multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, sm);
+  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, sm);
 }
 
 // Queue the latent tail of a training step (NVFPCC.py:186-196 backward of the latent generator): the gradient of the
@@ -1116,7 +1114,7 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
   d.nchunk = (int)nchunk;
   if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  multi_channel_sum_partial<<<dim3(base, d.nchunk), NVF_SUM_T, 0, s>>>(d, (float*)workspace);
+  multi_channel_sum_partial<<<dim3(base, d.nchunk), 256, 0, s>>>(d, (float*)workspace);
   if (!nvf_finals_push_sums(d, (const float*)workspace))
     multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
