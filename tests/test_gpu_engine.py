@@ -126,6 +126,56 @@ def test_two_rank_sharding_sums_to_the_single_rank_gradient(gpu):
     close(parts[0] + parts[1], g_all, tol=1e-5)
 
 
+def test_graph_replay_equals_the_host_launched_step(gpu):
+    """bench.py times GraphedTrainStep (the step body replayed from one HIP graph, block ids / noise step / rate
+    coefficient read from device memory): its gradients, loss terms and Adam-updated parameters equal those of the
+    host-launched train_step bit for bit, step after step (q = 1: weight and latent noise on)."""
+    from nvfpcc_amd.engine import GraphedTrainStep
+    net, eng, gt, dist, emb = make("S", gpu, nblk=24)
+    B = 16
+    rng = np.random.default_rng(5)
+    batches = [rng.permutation(24)[:B] for _ in range(3)]
+    state = lambda: (eng.flat_p.clone(), eng.flat_m.clone(), eng.flat_v.clone(), eng.noise_step, eng.opt_step)
+    s0 = state()
+    ref = []
+    for ids in batches:
+        eng.train_step(ids, 1)
+        ref.append((eng.flat_g.clone(), eng.flat_p.clone(), eng.loss_value()))
+    eng.flat_p.copy_(s0[0]); eng.flat_m.copy_(s0[1]); eng.flat_v.copy_(s0[2])
+    eng.noise_step, eng.opt_step = s0[3], s0[4]
+    graphed = GraphedTrainStep(eng, B, 1)                # capture runs the body: restore the state it touched
+    eng.flat_p.copy_(s0[0]); eng.flat_m.copy_(s0[1]); eng.flat_v.copy_(s0[2])
+    eng.noise_step, eng.opt_step = s0[3], s0[4]
+    for ids, (g_ref, p_ref, loss_ref) in zip(batches, ref):
+        graphed(ids)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.flat_g, g_ref)
+        assert torch.equal(eng.flat_p, p_ref)
+        assert eng.loss_value() == loss_ref
+
+
+def test_full_size_step_is_the_sum_of_its_mini_batches(gpu):
+    """Size-independent property at the large-batch configuration (B = 256: conv2's backward-data takes the VALU tile
+    kernel above batch 64, the loss its multi-launch form above batch 32): every loss term is a SUM over blocks, so the
+    gradient of the 256-block step equals the sum of the gradients of its sixteen 16-block mini-batches -- the
+    configuration the golden vectors pin -- with the weight-rate term counted once (rate_grad_scale = 1/16)."""
+    net, eng, gt, dist, emb = make("S", gpu, nblk=256)
+    whole = list(range(256))
+    n_pts = float(eng.counts[whole].sum())
+    eng.train_step(whole, 2, update=False, n_pts=n_pts)
+    g_all, loss_all = eng.flat_g.clone(), eng.loss_value()
+    assert torch.isfinite(g_all).all()
+    eng.rate_grad_scale = 1.0 / 16
+    acc = torch.zeros_like(g_all, dtype=torch.float64)
+    for r in range(16):
+        eng.train_step(whole[16 * r:16 * (r + 1)], 2, update=False, n_pts=n_pts)
+        acc += eng.flat_g.double()
+    eng.rate_grad_scale = 1.0
+    for name, (off, n) in eng.slices.items():
+        close(g_all[off:off + n], acc[off:off + n], tol=2e-4)
+    assert np.isfinite(loss_all)
+
+
 def test_weight_noise_and_latent_noise_are_reproducible(gpu):
     net, eng, gt, dist, emb = make("S", gpu)
     eng.train_step([0, 1, 2], 1, update=False)
