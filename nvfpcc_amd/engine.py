@@ -34,7 +34,8 @@ def _NAIVE_OFF():
 TRUNK = ("up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls")
 HEADS = ("conv1_cls", "conv0_cls")
 # layers whose backward-data also runs on the matrix cores: name -> (pair axis, largest batch it is used for)
-MFMA_BWD = {"conv1": (2, 1 << 30), "conv2": (0, 64)}
+# (above batch 64 the VALU tile kernel is faster for both: conv1 222 vs 367 us, conv2 1167 vs 1234 us at batch 256)
+MFMA_BWD = {"conv1": (2, 64), "conv2": (0, 64)}
 
 _DESC = np.dtype([("kernel", "<u8"), ("kernel_init", "<u8"), ("b", "<u8"), ("b_init", "<u8"), ("w_fwd", "<u8"),
                   ("w_bwd", "<u8"), ("b_eff", "<u8"), ("dim0", "<i4"), ("dim1", "<i4"), ("k3", "<i4"),
@@ -305,7 +306,9 @@ class TrainEngine:
 
     def _dx_convT(self, L, g_out, x_in, mask=None, addend=None):
         if L.wp_s is not None:
-            return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask)
+            # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256)
+            var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else None
+            return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask, variant=var)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)
 

@@ -221,8 +221,9 @@ def pack_s2k5_mfma(w_bwd, cig, cog, out=None):
     return wp
 
 
-def conv3d_s2k5_mfma(g, wp, cog, addend=None, mask=None, out=None):
-    """Matrix-core backward-data of a k5 s2 padding-0 transposed convolution (stride-2 gather conv)."""
+def conv3d_s2k5_mfma(g, wp, cog, addend=None, mask=None, out=None, variant=None):
+    """Matrix-core backward-data of a k5 s2 padding-0 transposed convolution (stride-2 gather conv).
+    ``variant``: tile shape (None = the module default, set_mfma_variant)."""
     _f32(g, wp, addend, mask)
     B, cig, di = g.shape[0], g.shape[1], g.shape[2]
     do = (di - 3) // 2
@@ -231,7 +232,8 @@ def conv3d_s2k5_mfma(g, wp, cog, addend=None, mask=None, out=None):
         if t is not None and t.shape != dx.shape:
             raise RuntimeError("addend/mask shape must equal the output shape")
     check(lib().nvf_conv3d_s2k5_mfma(_ptr(g), _ptr(wp), _ptr(dx), _ptr(addend), _ptr(mask), B, cig, cog, di, do,
-                                     _MFMA_VARIANT, _stream()), "nvf_conv3d_s2k5_mfma")
+                                     _MFMA_VARIANT if variant is None else int(variant), _stream()),
+          "nvf_conv3d_s2k5_mfma")
     return dx
 
 

@@ -50,6 +50,11 @@ def main():
         pair = MFMA_BWD[name][0]
         wpb = ops.pack_mfma_k4(wb, 8, pair)
         cases.append((name + ".bwd_data", macs, lambda: ops.conv3d_k4_mfma(gy, wpb, None, 3, pair, mask=x, out=dx)))
+        wpb2 = ops.pack_mfma_k4(wb, 8, 2 - pair)            # the other pair axis, and the VALU tile kernel
+        cases.append((name + f".bwd_data.pair{2 - pair}", macs,
+                      lambda: ops.conv3d_k4_mfma(gy, wpb2, None, 3, 2 - pair, mask=x, out=dx)))
+        cases.append((name + ".bwd_data.valu", macs,
+                      lambda: ops.conv3d_gather(gy, wb, None, 8, 4, 1, 3, (n, n, n), mask=x)))
 
     def convT(name, cin, n):                   # cin -> 8, k5 s2, padding 0: n -> 2n + 3
         w = R(cin, 8, 5, 5, 5) * 0.05
@@ -69,7 +74,11 @@ def main():
     for name, macs, fn in cases:
         if a.only and a.only not in name:
             continue
-        us = timeit(fn)
+        try:
+            us = timeit(fn)
+        except RuntimeError:
+            print(f"{name:18s}      n/a (no such variant)", flush=True)
+            continue
         print(f"{name:18s} {us:8.1f} us  {2 * macs / us / 1e6:6.1f} TF", flush=True)
 
 
