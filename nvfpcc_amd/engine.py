@@ -219,7 +219,10 @@ class TrainEngine:
 
     def _conv(self, L, x, act):
         if L.wp_f is not None:
-            return ops.conv3d_k4_mfma(x, L.wp_f, L.b_eff, 0, 0, act)
+            # conv1 at large batch: four planes per wave (variant 2: 124 vs 141 us at batch 256).  Every variant runs
+            # the same per-output fmaf chain, so the bits -- and encode-at-any-batch == decode-at-batch-1 -- do not change
+            var = 2 if (x.shape[-1] == 19 and x.shape[0] > 64) else None
+            return ops.conv3d_k4_mfma(x, L.wp_f, L.b_eff, 0, 0, act, variant=var)
         osz = tuple(s + 2 * L.pad - L.k + 1 for s in x.shape[2:])
         return ops.conv3d_gather(x, L.w_fwd, L.b_eff, L.cout, L.k, 1, L.pad, osz, act)
 

@@ -152,7 +152,7 @@ def pack_mfma_all(jobs):
                                   (ctypes.c_int * n)(*[j[4] for j in jobs]), n, _stream()), "nvf_pack_mfma_all")
 
 
-def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=None, out=None):
+def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=None, out=None, variant=None):
     """Matrix-core 4^3 convolution, 8 output channels: same contract as conv3d_gather(k=4, stride=1)."""
     _f32(x, wp, bias, addend, mask)
     B, cin, di, hi, wi = x.shape
@@ -162,7 +162,8 @@ def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=
         if t is not None and t.shape != y.shape:
             raise RuntimeError("addend/mask shape must equal the output shape")
     check(lib().nvf_conv3d_k4_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(addend), _ptr(mask), B, cin, 8, pad,
-                                   pair_axis, di, hi, wi, do, ho, wo, act, _MFMA_VARIANT, _stream()),
+                                   pair_axis, di, hi, wi, do, ho, wo, act,
+                                   _MFMA_VARIANT if variant is None else int(variant), _stream()),
           "nvf_conv3d_k4_mfma")
     return y
 

@@ -225,6 +225,8 @@ def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
     for i in range(B):                                                       # batch invariance, bit for bit
         yi = ops.conv3d_k4_mfma(xd[i:i + 1].contiguous(), wpf, dev(b), 0, 0, ops.ACT_RELU)
         assert torch.equal(yi[0], y[i])
+    for var in ((2, 3, 4, 5, 6) if n == 35 else (2, 3)):                     # every tile shape: the same bits
+        assert torch.equal(ops.conv3d_k4_mfma(xd, wpf, dev(b), 0, 0, ops.ACT_RELU, variant=var), y), var
     gy = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(gy)
     mask = torch.randn(x.shape, generator=g)
