@@ -782,7 +782,7 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
     if (variant == 0 && a == 1 && k == 3 && stride == 1 && pad == 1 && out_mode == 0 && dp == hp && hp == wp &&
         dq == dp && hq == dp && wq == dp) {     // classifier heads (heads.hip): p = dlogit, q = X
       int n = 0;
-      if (nvf_head_wgrad_launch(p, q, slabs, kMaxSlabs, batch, b, wp, &n, s) == 0) {
+      if (nvf_head_wgrad_launch(p, q, slabs, 256, batch, b, wp, &n, s) == 0) {   // 256 slabs: see WgradBatch.add_heads3
         if (defer_nslab) *defer_nslab = n;
         else wgrad_reduce<<<(d.jtotal + 63) / 64, 1024, 0, s>>>(slabs, dw, n, d.jtotal, accumulate);
         rc = NVF_OK;
@@ -993,6 +993,9 @@ extern "C" int nvf_channel_sum(const float* x, float* out, void* workspace, size
 // all bias gradients of a backward pass in two launches: out_i[c] = sum_{n,s} x_i[n,c,s] for up to 12 tensors
 // ---------------------------------------------------------------------------
 
+#ifndef NVF_SUM_T
+#define NVF_SUM_T 512      // threads that load a row (256: 17.6 us for the step's reduction launch, 512 / 1024: 15.9)
+#endif
 // `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
 // workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
 template <int T>
@@ -1031,9 +1034,9 @@ __device__ __forceinline__ void multi_channel_sum_partial_body(const MultiSumDes
   if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
 }
 
-__global__ __launch_bounds__(256) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
+__global__ __launch_bounds__(NVF_SUM_T) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
   __shared__ float red[16];
-  multi_channel_sum_partial_body<256>(d, part, blockIdx.x, blockIdx.y, red);
+  multi_channel_sum_partial_body<NVF_SUM_T>(d, part, blockIdx.x, blockIdx.y, red);
 }
 
 // the slab reduction of all weight gradients and the partial bias sums are independent: one launch
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
   const int bid = blockIdx.x;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, sm); return; }
   const int q = bid - r_blocks;
-  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
+  multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, &sm[0][0]);
 }
 
 // ... and with the latent tail (latent_tail.h) as one more workgroup, the first one dispatched
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_sums_tail(WgReduceMulti r, 
   const int bid = blockIdx.x - 1;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, (float(*)[64])sm); return; }
   const int q = bid - r_blocks;
-  multi_channel_sum_partial_body<256>(m, part, q % m.total_channels, q / m.total_channels, sm);
+  multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, sm);
 }
 
 // Queue the latent tail of a training step (NVFPCC.py:186-196 backward of the latent generator): the gradient of the
@@ -1114,7 +1117,7 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
   d.nchunk = (int)nchunk;
   if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  multi_channel_sum_partial<<<dim3(base, d.nchunk), 256, 0, s>>>(d, (float*)workspace);
+  multi_channel_sum_partial<<<dim3(base, d.nchunk), NVF_SUM_T, 0, s>>>(d, (float*)workspace);
   if (!nvf_finals_push_sums(d, (const float*)workspace))
     multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
