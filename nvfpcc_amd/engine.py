@@ -546,21 +546,23 @@ class GraphedTrainStep:
     from device memory: block ids, the rate coefficient lambda*w1/n_pts and the noise-step counter.
     Adam stays outside the graph (its bias correction depends on the step number)."""
 
-    def __init__(self, eng, batch, q):
+    def __init__(self, eng, batch, q, ring=8):
         self.eng, self.batch, self.q = eng, batch, q
         dev = eng.dev
         # one device buffer [idx (B x i64) | noise step (u64) | lambda*w1/n_pts (f32 in the low half)] refreshed by a
-        # single pinned-memory copy per step
+        # single pinned-memory copy per step.  The host may run several steps ahead of the GPU, so the staging side is
+        # a ring of pinned buffers: a slot is rewritten only after the copy that read it has executed (its event).
         self.buf = torch.zeros(batch + 2, dtype=torch.int64, device=dev)
-        self.pin = torch.zeros(batch + 2, dtype=torch.int64).pin_memory()
+        self.pins = [torch.zeros(batch + 2, dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
+        self.pin_events = [None] * len(self.pins)
+        self.calls = 0
         self.idx = self.buf[:batch]
         self.step = self.buf[batch:batch + 1]
         self.g_lat = self.buf[batch + 1:batch + 2].view(torch.float32)[0:1]
-        self.pin_g = self.pin[batch + 1:batch + 2].view(torch.float32)
         eng._step_dev, eng._g_lat_dev = self.step, self.g_lat
-        self.pin[:batch] = torch.arange(batch) % eng.N_leaf
-        self.pin_g[0] = 1.0
-        self.buf.copy_(self.pin)
+        self.pins[0][:batch] = torch.arange(batch) % eng.N_leaf
+        self.pins[0][batch + 1:batch + 2].view(torch.float32)[0] = 1.0
+        self.buf.copy_(self.pins[0])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up: allocates the grow-only workspaces outside the graph
@@ -588,10 +590,18 @@ class GraphedTrainStep:
             eng.noise_step += 1
         if n_pts is None:
             n_pts = float(eng.counts[idx_host].sum())
-        self.pin[:self.batch] = torch.from_numpy(idx_host)
-        self.pin[self.batch] = eng.noise_step
-        self.pin_g[0] = eng.lmbda * eng.w1 / n_pts
-        self.buf.copy_(self.pin, non_blocking=True)
+        slot = self.calls % len(self.pins)
+        self.calls += 1
+        if self.pin_events[slot] is not None:
+            self.pin_events[slot].synchronize()      # blocks only when the host is a whole ring ahead of the GPU
+        pin = self.pins[slot]
+        pin[:self.batch] = torch.from_numpy(idx_host)
+        pin[self.batch] = eng.noise_step
+        pin[self.batch + 1:self.batch + 2].view(torch.float32)[0] = eng.lmbda * eng.w1 / n_pts
+        self.buf.copy_(pin, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pin_events[slot] = ev
         self.graph.replay()
         eng.last["n_pts"] = n_pts
         if eng.grad_hook is not None:

@@ -152,6 +152,22 @@ def test_graph_replay_equals_the_host_launched_step(gpu):
         assert torch.equal(eng.flat_g, g_ref)
         assert torch.equal(eng.flat_p, p_ref)
         assert eng.loss_value() == loss_ref
+    # the host may run ahead of the GPU: six more steps without a sync in between, through a two-slot staging ring
+    more = [rng.permutation(24)[:B] for _ in range(6)]
+    s1 = state()
+    for ids in more:
+        eng.train_step(ids, 1)
+    p_end = eng.flat_p.clone()
+    eng.flat_p.copy_(s1[0]); eng.flat_m.copy_(s1[1]); eng.flat_v.copy_(s1[2])
+    eng.noise_step, eng.opt_step = s1[3], s1[4]
+    graphed2 = GraphedTrainStep(eng, B, 1, ring=2)
+    eng.flat_p.copy_(s1[0]); eng.flat_m.copy_(s1[1]); eng.flat_v.copy_(s1[2])
+    eng.noise_step, eng.opt_step = s1[3], s1[4]
+    torch.cuda.synchronize()
+    for ids in more:
+        graphed2(ids)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat_p, p_end)
 
 
 def test_full_size_step_is_the_sum_of_its_mini_batches(gpu):
