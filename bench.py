@@ -132,8 +132,8 @@ def cpu_baseline(args, seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch", type=int, default=16, help="blocks per GPU per step (reference --batchsize 16)")
     ap.add_argument("--blocks", type=int, default=917, help="leaf blocks resident per GPU (longdress l5: 917)")
     ap.add_argument("--distinct", type=int, default=128, help="distinct synthetic blocks generated, then tiled")
