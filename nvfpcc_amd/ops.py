@@ -200,14 +200,15 @@ def pack_convT_mfma(w_fwd, cin, out=None):
     return wp
 
 
-def convT3d_k5s2_mfma(x, wp, bias, act=ACT_NONE, out=None):
+def convT3d_k5s2_mfma(x, wp, bias, act=ACT_NONE, out=None, variant=None):
     """Matrix-core transposed convolution k5 s2 padding 0, 8 output channels."""
     _f32(x, wp, bias)
     B, cin, di = x.shape[0], x.shape[1], x.shape[2]
     do = 2 * di + 3
     y = out if out is not None else torch.empty((B, 8, do, do, do), device=x.device)
-    check(lib().nvf_convT3d_k5s2_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, cin, 8, di, act, _MFMA_VARIANT,
-                                      _stream()), "nvf_convT3d_k5s2_mfma")
+    check(lib().nvf_convT3d_k5s2_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, cin, 8, di, act,
+                                      _MFMA_VARIANT if variant is None else int(variant), _stream()),
+          "nvf_convT3d_k5s2_mfma")
     return y
 
 
