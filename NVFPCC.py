@@ -67,7 +67,7 @@ def _psnr1(sse, denom):
 def train(args):
     from nvfpcc_amd import dist as nd, ops
     from nvfpcc_amd.dataloader import LoadedVoxelDataset
-    from nvfpcc_amd.engine import TrainEngine
+    from nvfpcc_amd.engine import TrainEngine, EpochDriver
     dev, rank, world = _device(args)
     say = print if rank == 0 else (lambda *a, **k: None)
     say(f'Rate loss = {args.w1} * b1 + b2 + {args.w2} * b3')
@@ -82,6 +82,9 @@ def train(args):
     say('Embedding learning rate: %f x %f = %f' % (args.lr, args.wemb, args.lr * args.wemb))
     B, N = args.batchsize, data.N_leaf
     lo, hi = nd.shard_range(N, rank, world)
+    # mini-batch phase: full-size mini-batches replay one captured HIP graph per (share, q); the log line's sums
+    # live in device accumulators and are read ONCE per epoch (the reference syncs ~14 .item()s per step)
+    driver = EpochDriver(eng, B, rank, world, use_graph=os.environ.get("NVF_TRAIN_GRAPH", "1") != "0")
     q = 1
     for epoch in range(0, args.epochs):
         t0 = time.time()
@@ -89,36 +92,18 @@ def train(args):
             q = 2
         eng.lr = lr_at_epoch(args.lr, epoch)
         order = data.epoch_order(epoch, bool(args.shuffle), seed=args.seed)
-        nsteps = (N + B - 1) // B
-        acc = torch.zeros(6, device=dev)          # tp, ap, tn, an (thh .5); sse, denom (thh .6) over the epoch
-        loss_sum = torch.zeros(3, device=dev)
-        bits_sum = torch.zeros(2, device=dev)
-        for s in range(nsteps):
-            ids, whole = nd.shard_minibatch(order, s, B, rank, world)
-            if len(ids) == 0:                     # short last batch: this rank idles but still joins the all-reduce
-                eng.flat_g.zero_()
-                nd.allreduce_sum_(eng.flat_g)
-                eng.opt_step += 1
-                ops.adam_step(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, eng.lr, eng.opt_step)
-                continue
-            n_pts = float(eng.counts[whole].sum())
-            a = eng.train_step(ids, q, n_pts=n_pts)
-            idd = torch.from_numpy(np.asarray(ids)).to(dev)
-            ops.metrics(a["p2"], ops.gather_rows(eng.gt, idd), ops.gather_rows(eng.dist, idd), 0.5, 0.6, out=acc,
-                        accumulate=True)
-            loss_sum += eng.last["loss_terms"][:3]
-            bits_sum[0] += eng.last["latent_bits"][0] / n_pts
-            bits_sum[1] += eng.last["net_bits"].sum() / eng.n_points_total
-        # latent update on this rank's shard, then re-synchronise the replicated table
+        nsteps = driver.run(order, q)
+        # latent update on this rank's shard (every rank advances the noise counter), then re-synchronise the table
         if hi > lo:
             eng.latent_step(q, lo, hi)
+        else:
+            eng.noise_step += 1
         nd.allgather_rows_(eng.emb, rank, world)
-        if world > 1:
-            for t in (acc, loss_sum, bits_sum):
-                nd.allreduce_sum_(t)
-        m = acc.cpu().numpy()
-        ls = loss_sum.cpu().numpy() / nsteps
-        bs = bits_sum.cpu().numpy() / nsteps
+        # NaN guards of NVFPCC.py:199-212 are checked here, on the summed counters (raises ValueError)
+        m, sums = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None)
+        ls = sums[0:3] / nsteps
+        # b_net is replicated: every rank (idle ones included) added it once per step
+        bs = np.array([sums[3], sums[4] / world]) / nsteps
         mse1, psnr1 = _psnr1(m[4], m[5])
         total = ls.sum() + args.lmbda * (bs[0] * args.w1 + bs[1] * args.w2)
         say('[Epoch %04d TRAIN %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f '

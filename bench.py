@@ -3,34 +3,88 @@
 32^3 blocks, chanstr 8,16,8,8, ch 3).
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 8                      # starts 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one mini-batch decoder update (gather latents -> forward, mode 'train', q = 1 -> GT pyramid
 -> 3 focal losses + rate terms -> backward -> [RCCL all-reduce of the flat decoder gradient] -> fused Adam),
 NVFPCC.py:149-223 minus its logging syncs, on `--batch` blocks PER GPU (weak scaling: the global
 mini-batch is batch x N).  Inputs (grids, latent table, weights) are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Beside the step number the line carries `epoch`: whole epochs of NVFPCC.py train
+(58 mini-batches incl. the short last one + the full-batch latent step + the log line's device sums, eval on
+every 10th) as end-to-end blocks/s -- what a user of the CLI sees.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import socket
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_MACS = {"8,16,8,8": 201190992, "16,32,16,16": 788428800}      # SURVEY.md section 2.1 / BASELINE.md section 3
 CONV2_MACS = {"8,16,8,8": 134217728, "16,32,16,16": 536870912}     # per block, each of fwd / bwd-data / bwd-weight
+# per-block MACs of the other trunk layers (each of fwd / bwd-data / bwd-weight), SURVEY.md section 2.1
+UP2_MACS = {"8,16,8,8": 32768000, "16,32,16,16": 131072000}
+CONV1_MACS = {"8,16,8,8": 16777216, "16,32,16,16": 67108864}
+UP1_MACS = {"8,16,8,8": 8192000, "16,32,16,16": 32768000}
+CONV0_MACS = {"8,16,8,8": 1024000, "16,32,16,16": 4096000}
 BYTES_PER_BLOCK = {"8,16,8,8": 15050624, "16,32,16,16": 29092224}  # layer-granular HBM model, SURVEY.md 8(d)
 PEAK_FP32_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: fp32 vector = matrix peak
 PEAK_HBM_GBS = 8000.0
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=16, help="blocks per GPU per step (reference --batchsize 16)")
+    ap.add_argument("--blocks", type=int, default=917, help="leaf blocks resident per GPU (longdress l5: 917)")
+    ap.add_argument("--distinct", type=int, default=128, help="distinct synthetic blocks generated, then tiled")
+    ap.add_argument("--ch", type=int, default=3)
+    ap.add_argument("--chanstr", default="8,16,8,8")
+    ap.add_argument("--q", type=int, default=1)
+    ap.add_argument("--mode", choices=["step", "epoch"], default="step",
+                    help="epoch: time whole NVFPCC.py-train epochs only (the default run reports both)")
+    ap.add_argument("--epochs", type=int, default=10, help="epochs timed for the `epoch` object")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each (value = the first)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic")
+    ap.add_argument("--sweep", action="store_true", help="also time batch 256 and the full-batch latent step")
+    ap.add_argument("--naive", action="store_true", help="debug: one-thread-per-output kernels")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying a captured HIP graph")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one rank, but with an RCCL process group and the all-reduce in the step (plumbing check)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks (one process per GPU, RCCL)
+    BEFORE this process touches the GPU, and pass rank 0's JSON line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def build_engine(args, device, world):
+    import numpy as np
+    import torch
     from nvfpcc_amd import network, dist as nd
     from nvfpcc_amd.engine import TrainEngine
     from nvfpcc_amd.model import Net
@@ -45,20 +99,21 @@ def build_engine(args, device, world):
     dist_t = torch.from_numpy(np.tile(dists, (reps, 1, 1, 1, 1))[:args.blocks]).float().to(device)
     eng = TrainEngine(net, gt, dist_t, n_points_total=float(gt.sum().item()), lmbda=200.0, w1=10.0, w2=57.0,
                       lr=1e-3, wemb=5.0, seed=0)
-    nd.attach(eng, world)
+    nd.attach(eng, world, force=args.force_collective)
     return eng
 
 
 class KernelProbe:
     """HIP-event brackets around chosen C-ABI launches (same stream).  The launch is repeated REPEAT times inside
     one bracket: with a single launch the bracket also holds the host's launch latency whenever the GPU has caught
-    up with the host, which a ~0.6 ms step does."""
+    up with the host, which a ~0.5 ms step does."""
     REPEAT = 8
 
     def __init__(self):
         self.events = {}
 
     def wrap(self, ops, fn_name, label, match):
+        import torch
         orig = getattr(ops, fn_name)
         probe = self
 
@@ -83,12 +138,14 @@ class KernelProbe:
     enabled = False
 
     def summary(self):
+        import numpy as np
         return {k: float(np.mean([s.elapsed_time(e) for s, e in v])) * 1e3 / self.REPEAT
                 for k, v in self.events.items()}  # us per launch
 
 
 def cpu_baseline(args, seconds=15.0):
     """The oracle (CPU restatement of the reference's step) on this box's host cores: bounded sample."""
+    import torch
     from oracle import nvf_oracle as O
     from nvfpcc_amd.seeds import synthetic_seed
     from nvfpcc_amd.synth import make_blocks
@@ -129,43 +186,89 @@ def cpu_baseline(args, seconds=15.0):
                       f"host has {cores} logical CPUs)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--batch", type=int, default=16, help="blocks per GPU per step (reference --batchsize 16)")
-    ap.add_argument("--blocks", type=int, default=917, help="leaf blocks resident per GPU (longdress l5: 917)")
-    ap.add_argument("--distinct", type=int, default=128, help="distinct synthetic blocks generated, then tiled")
-    ap.add_argument("--ch", type=int, default=3)
-    ap.add_argument("--chanstr", default="8,16,8,8")
-    ap.add_argument("--q", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="also time batch 256 and the full-batch latent step")
-    ap.add_argument("--naive", action="store_true", help="debug: one-thread-per-output kernels")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying a captured HIP graph")
-    args = ap.parse_args()
+def kernel_source_hash():
+    """Identifies the kernel sources a PMC measurement belongs to (stale profiles are refused)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nvfpcc_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
+
+def measure_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (host-launched steps,
+    so every dispatch carries its kernel name) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two
+    do not fit one pass), medians per dispatch, FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B:
+    MI355X_MICROARCH.md, HBM section).  Returns (bytes or None, note)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(rocprof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    base = tempfile.mkdtemp(prefix="nvf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(base, counter)
+        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+               "python3", os.path.abspath(__file__), "--pmc-child", "--no-cpu-baseline", "--no-pmc", "--no-graph",
+               "--steps", "6", "--warmup", "3", "--repeats", "1", "--batch", str(args.batch), "--blocks", str(args.blocks),
+               "--distinct", str(args.distinct), "--ch", str(args.ch), "--chanstr", args.chanstr, "--q", str(args.q)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                               timeout=240)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(base, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} child timed out"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            shutil.rmtree(base, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} child failed (rc {r.returncode}): {r.stdout[-300:]}"
+        per = []
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                per.append(float(row["Counter_Value"]))
+        if not per:
+            shutil.rmtree(base, ignore_errors=True)
+            return None, f"no dispatch of {kernel_substr} in the {counter} pass"
+        vals[counter] = statistics.median(per)
+    shutil.rmtree(base, ignore_errors=True)
+    # rocprofv3 reports both in KB
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
+        f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (host-launched steps), median per "
+        f"dispatch, 2 x FETCH_SIZE + WRITE_SIZE; kernel sources {kernel_source_hash()}")
+
+
+def run(args):
+    import numpy as np
+    import torch
     from nvfpcc_amd import dist as nd, ops
+    from nvfpcc_amd.engine import GraphedTrainStep, EpochDriver
+    if args.force_collective and "WORLD_SIZE" not in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
     rank, local_rank, world = nd.init()
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     device = torch.device("cuda", int(os.environ.get("NVF_DEVICE_OVERRIDE", local_rank)))   # override: test hook
     torch.cuda.set_device(device)
+    if args.force_collective and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(backend=os.environ.get("NVF_DIST_BACKEND", "nccl"), rank=0, world_size=1)
+    if torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size()          # the live process group, not the command line
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but the process group has {world} rank(s)", file=sys.stderr)
     ops.set_naive(args.naive)
     eng = build_engine(args, device, world)
     B = args.batch
+    nreg = max(args.repeats, 1)
 
     # epoch order shared by every rank (seeded), global mini-batch = B * world
     rng = np.random.default_rng(1234)
     order = np.concatenate([rng.permutation(args.blocks) for _ in range(
-        (args.steps + args.warmup + 2) * B * world // args.blocks + 2)])
+        (args.steps * nreg + args.warmup + 12) * B * world // args.blocks + 2)])
     counts = eng.counts
 
     graphed = None
-    if not args.no_graph:
-        from nvfpcc_amd.engine import GraphedTrainStep
+    if not args.no_graph and args.mode == "step":
         graphed = GraphedTrainStep(eng, B, args.q)
 
     def step(i, use_graph=True):
@@ -193,6 +296,9 @@ def main():
     probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
     # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
     probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs: True)
+    # rocprofv3 names of the kernels behind those labels (for the PMC child passes)
+    kernel_names = {"wgrad_trunk5": "wgrad_mfma3_kernel", "wgrad_conv2_up2_conv1": "wgrad_mfma3_kernel",
+                    "conv2_fwd": "conv_k4_mfma", "conv2_bwd_data": "conv_k4_mfma", "conv2_bwd_weight": "wgrad_k4_mfma"}
 
     def barrier():
         torch.cuda.synchronize()
@@ -200,40 +306,95 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    # kernels inside a replayed graph cannot be bracketed by events: time the dominant kernels on the same stream in
-    # the same process right after the timed region, same shapes and operands, launched from the host
-    probe.enabled = True
-    for i in range(args.warmup + args.steps, args.warmup + args.steps + min(args.steps, 10)):
-        step(i, use_graph=False)
-    torch.cuda.synchronize()
-    probe.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64,
-                         device=device if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = eng.loss_value()
-    blocks_per_s = args.steps * B * world / dt
+    def timed_max(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64,
+                             device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    region_ms = []
+    dt = None
+    if args.mode == "step":
+        for i in range(args.warmup):
+            step(i)
+        nxt = args.warmup
+        for r in range(nreg):                     # region 0 is the contract's measurement; the others show its spread
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(nxt, nxt + args.steps):
+                step(i)
+            barrier()
+            d = timed_max(time.perf_counter() - t0)
+            nxt += args.steps
+            region_ms.append(d / args.steps * 1e3)
+            if dt is None:
+                dt = d
+        # kernels inside a replayed graph cannot be bracketed by events: time the dominant kernels on the same stream
+        # in the same process right after the timed region, same shapes and operands, launched from the host
+        probe.enabled = not args.pmc_child
+        for i in range(nxt, nxt + min(args.steps, 10)):
+            step(i, use_graph=False)
+        torch.cuda.synchronize()
+        probe.enabled = False
+        loss = eng.loss_value()
+    if args.pmc_child:
+        return 0
+
+    # ---- whole epochs of NVFPCC.py train: mini-batches (graph replay + the short last batch from the host), the
+    # full-batch latent step on this rank's shard, the device-side sums of the log line, eval on every 10th epoch
+    epoch_obj = None
+    if world >= 1 and (args.mode == "epoch" or not args.no_graph):
+        N = args.blocks
+        drv = EpochDriver(eng, B * world, rank, world, use_graph=not args.no_graph)
+        lo, hi = nd.shard_range(N, rank, world)
+        erng = np.random.default_rng(99)
+
+        def one_epoch(ep):
+            n = drv.run(erng.permutation(N), args.q)
+            if hi > lo:
+                eng.latent_step(args.q, lo, hi)
+            else:
+                eng.noise_step += 1
+            nd.allgather_rows_(eng.emb, rank, world)
+            m, sums = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None)   # the epoch's one sync
+            if ep % 10 == 0 and rank == 0:
+                a = eng.eval_forward(q=2)
+                ops.metrics(a["p2"], eng.gt, eng.dist, 0.5, 0.6).cpu()
+            return n
+        one_epoch(1)
+        one_epoch(2)
+        barrier()
+        t0 = time.perf_counter()
+        nst = 0
+        for ep in range(args.epochs):
+            nst = one_epoch(ep)
+        barrier()
+        de = timed_max(time.perf_counter() - t0)
+        step_ms = region_ms[0] if region_ms else None
+        epoch_obj = {"epochs": args.epochs, "ms_per_epoch": round(de / args.epochs * 1e3, 3),
+                     "blocks_per_s": round(N * args.epochs / de, 1), "minibatches_per_epoch": nst,
+                     "includes": "mini-batch steps (graph replay; short last batch host-launched), full-batch latent "
+                                 "step, per-epoch stats read-back, eval forward + metrics on every 10th epoch",
+                     "bound_58_steps_plus_10pct_ms": None if step_ms is None else round(1.1 * nst * step_ms, 3)}
+        if args.mode == "epoch":
+            dt = de
+            loss = float("nan")
+
+    blocks_per_s = (args.steps * B * world / dt) if args.mode == "step" else args.blocks * args.epochs / dt
 
     extra = {}
     if args.sweep and rank == 0 and world == 1:
-        order = np.concatenate([rng.permutation(args.blocks) for _ in range(13 * 256 // args.blocks + 2)])
+        order2 = np.concatenate([rng.permutation(args.blocks) for _ in range(13 * 256 // args.blocks + 2)])
         for b2 in (256,):
             for i in range(3):
-                eng.train_step(order[i * b2:(i + 1) * b2], args.q)
+                eng.train_step(order2[i * b2:(i + 1) * b2], args.q)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n2 = 10
             for i in range(n2):
-                eng.train_step(order[i * b2:(i + 1) * b2], args.q)
+                eng.train_step(order2[i * b2:(i + 1) * b2], args.q)
             torch.cuda.synchronize()
             extra[f"train_step_B{b2}_blocks_per_s"] = round(n2 * b2 / (time.perf_counter() - t1), 1)
         eng.latent_step(args.q)
@@ -253,52 +414,72 @@ def main():
             label = max(single, key=single.get)      # the dominant single launch of the step
             us = single[label]
             # algorithmic MACs of what the launch computes (not the halo / padding lanes it also executes);
-            # the three-gradient launch: conv2 + up2 (32 768 000 MAC/block) + conv1 (16 777 216), SURVEY 2.1
-            # the five-gradient launch adds up1 (8 192 000) and conv0 (1 024 000)
-            layer_macs = {"wgrad_conv2_up2_conv1": macs + 32768000 + 16777216,
-                          "wgrad_trunk5": macs + 32768000 + 16777216 + 8192000 + 1024000}
+            # the three-gradient launch: conv2 + up2 + conv1; the five-gradient launch adds up1 and conv0
+            cs = args.chanstr
+            layer_macs = {"wgrad_conv2_up2_conv1": macs + UP2_MACS[cs] + CONV1_MACS[cs],
+                          "wgrad_trunk5": macs + UP2_MACS[cs] + CONV1_MACS[cs] + UP1_MACS[cs] + CONV0_MACS[cs]}
             flops = 2.0 * layer_macs.get(label, macs) * B
             achieved = flops / (us * 1e-6) / 1e12
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.isfile(tj):     # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/)
-                t = json.load(open(tj))
-                if t.get("batch") == B and t.get("chanstr") == args.chanstr:
-                    traffic = t["hbm_bytes_per_launch"].get({"wgrad_conv2_up2_conv1": "conv2_bwd_weight",
-                                                                 "wgrad_trunk5": "conv2_bwd_weight"}.get(label, label))
+            traffic, tnote = None, "not measured (--no-pmc or N > 1)"
+            if world == 1 and not args.no_pmc:
+                torch.cuda.synchronize()
+                traffic, tnote = measure_traffic(args, kernel_names[label])
             roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                        "traffic": None if traffic is None else round(traffic), "traffic_source": tnote,
                         "avg_launch_us": round(us, 2), "flops_per_launch": flops,
                         "all_kernels_avg_us": {k: round(v, 2) for k, v in kern_us.items()}}
         fwd = FWD_MACS.get(args.chanstr)
+        workload = ("train_step: decoder mini-batch update, NVFPCC.py:149-223 (fwd mode=train q=%d, 3 focal losses + "
+                    "rate terms, bwd, fused Adam)" % args.q) if args.mode == "step" else (
+                   "train epoch: NVFPCC.py:128-292 (mini-batch updates, full-batch latent step, eval every 10th)")
         out = {
             "metric": "leaf-blocks/sec NVF train step (32^3, chanstr=%s)" % args.chanstr,
-            "value": round(blocks_per_s, 1), "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train_step: decoder mini-batch update, NVFPCC.py:149-223 (fwd mode=train q=%d, "
-                                   "3 focal losses + rate terms, bwd, fused Adam)" % args.q,
-                       "launch": "host" if graphed is None else "hip-graph replay + fused Adam",
+            "value": round(blocks_per_s, 1), "unit": "blocks/s", "n_gpus": world,
+            "steps": args.steps if args.mode == "step" else args.epochs,
+            "warmup": args.warmup, "ms_per_step": round(dt / (args.steps if args.mode == "step" else args.epochs) * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak" if args.mode == "step" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload,
+                       "launch": "host" if (graphed is None and args.mode == "step") else
+                                 "hip-graph replay (step head .. Adam in one graph)",
+                       "collective": None if eng.grad_hook is None else
+                                     ("all-reduce captured in the step graph" if (graphed is not None and graphed.collective == "graph")
+                                      else "all-reduce launched from the host"),
                        "batch_per_gpu": B, "global_batch": B * world, "blocks_resident": args.blocks,
                        "ch": args.ch, "chanstr": args.chanstr, "parallelism": f"dp{world}",
                        "data_detail": f"{min(args.blocks, args.distinct)} distinct synthetic 32^3 quadric-sheet blocks "
                                       f"(2.5-3.5% occupancy, exact EDT distance) tiled to {args.blocks}; seed-init weights"},
-            "loss_last_step": round(loss, 3),
         }
-        if fwd:
+        if args.mode == "step":
+            out["loss_last_step"] = round(loss, 3)
+            out["repeats"] = {"ms_per_step": [round(x, 4) for x in region_ms], "min": round(min(region_ms), 4),
+                              "median": round(statistics.median(region_ms), 4),
+                              "note": "value / ms_per_step come from the first region (the contract's K steps)"}
+        if fwd and args.mode == "step":
             tf = blocks_per_s / world * 6.0 * fwd / 1e12
             out["step_level"] = {"fp32_tflops_per_gpu": round(tf, 3), "frac_of_fp32_peak": round(tf / PEAK_FP32_TFLOPS, 4),
                                  "hbm_fraction_layer_granular_model": round(
                                      blocks_per_s / world * BYTES_PER_BLOCK[args.chanstr] / (PEAK_HBM_GBS * 1e9), 4)}
         if roofline:
             out["roofline"] = roofline
+        if epoch_obj:
+            out["epoch"] = epoch_obj
         if extra:
             out["sweep"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # nothing above has touched the GPU
+    sys.exit(run(args))
 
 
 if __name__ == "__main__":

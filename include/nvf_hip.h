@@ -12,7 +12,10 @@
  * Conventions
  *   - every tensor is fp32, contiguous, NCDHW, resident in device memory;
  *   - the caller owns every buffer (inputs, outputs, workspace); the library
- *     never allocates, frees or keeps a pointer after returning;
+ *     never allocates, frees or keeps a pointer after returning, and holds NO state of its own between
+ *     calls: work that one call hands to a later one (the deferred final passes, the queued latent
+ *     tail) travels in a caller-owned NvfStepCtx, so any number of engines, streams and threads can
+ *     use the library at once, each with its own context;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call
  *     synchronises; outputs are overwritten unless the argument says accumulate;
  *   - return 0 on success, a positive hipError_t from the launch, or a negative
@@ -39,6 +42,17 @@ extern "C" {
 #define NVF_ACT_SIGMOID 2
 
 int nvf_version(void);
+
+/* ---- step context ---------------------------------------------------------------
+ * Host-side state of ONE training step in flight: the queue of deferred final passes (nvf_finals_*) and the
+ * queued latent tail (nvf_latent_tail_queue).  Opaque; the caller allocates nvf_step_ctx_bytes() bytes of host
+ * memory (8-byte aligned), calls nvf_step_ctx_init once, and passes the pointer to every entry point that takes
+ * an `NvfStepCtx* ctx`.  ctx == NULL everywhere means "defer nothing": every final pass is launched by the call
+ * that produces its partial sums.  A context must not be used from two threads at the same time; different
+ * contexts are independent (tests/test_gpu_engine.py::test_two_step_contexts_do_not_interfere). */
+typedef struct NvfStepCtx NvfStepCtx;
+size_t nvf_step_ctx_bytes(void);
+int nvf_step_ctx_init(NvfStepCtx* ctx);
 
 /* ---- weight packing -------------------------------------------------------
  * Re-lays an effective kernel into the two layouts the direct-conv kernels read
@@ -139,13 +153,13 @@ int nvf_heads3_bwd_data(const float* const* dlogits, const float* const* w_bwds,
 
 /* nvf_focal_loss_multi (chain_sigmoid) of the three heads and nvf_heads3_bwd_data in ONE launch (NVFPCC.py:166-184
  * + the heads' backward-data): dls[h] = d term_h / d logit_h is computed while the tiles are staged, written for
- * the weight gradient, and loss[slots[h]] = term_h (final pass deferred by nvf_finals_begin).  dists[h] may be
+ * the weight gradient, and loss[slots[h]] = term_h (final pass deferred while ctx has an open nvf_finals_begin).  dists[h] may be
  * NULL.  batch <= 32 (one loss partial per workgroup); otherwise NVF_EINVAL. */
 int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, const float* const* dists,
                              const float* alphas, const float* betas, const int* slots, float* loss,
                              float* const* dls, const float* const* wbs, float* const* dxs,
                              const float* const* masks, const int* cs, const int* ss, int batch, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             size_t workspace_bytes, NvfStepCtx* ctx, void* stream);
 /* partial sums only: slabs[h] receives nslabs[h] (<= max_slabs) slabs of cs[h] * 27 floats, to be added by
  * nvf_wgrad_reduce_multi */
 int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs, float* const* slabs, const int* cs,
@@ -184,7 +198,7 @@ int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float*
 int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                          const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
                          float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs, void* workspace,
-                         size_t workspace_bytes, int batch, int ch, int c0, int c1, void* stream);
+                         size_t workspace_bytes, int batch, int ch, int c0, int c1, NvfStepCtx* ctx, void* stream);
 
 /* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
  * dw[a][b][k] (+)= sum_{n,i} p[n,a,i] * q[n,b, stride*i - pad + k]      (out_mode 0)
@@ -214,7 +228,7 @@ int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* dws, const i
  * (p = dY [B,8,16^3], q = X [B,8,19^3]); slabs[j] holds 512 slabs of 4096 / 8000 / 4096 floats, nslabs[j] = number
  * written.  Same kernels and results as three nvf_wgrad_partial calls; two workgroups share a CU. */
 int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                            int* nslabs, void* stream);
+                            int* nslabs, NvfStepCtx* ctx, void* stream);
 
 /* up1's and conv0's weight gradients of the narrow trunk in one launch (partial sums): job 0 = up1 (p = X [B,16,8^3],
  * q = dY [B,8,19^3]), job 1 = conv0 (p = X [B,8,4^3], q = dY [B,16,8^3]); slabs[j]: up to 512 slabs of 16000 floats */
@@ -227,7 +241,7 @@ int nvf_wgrad_up1_conv0_partial(const float* const* ps, const float* const* qs, 
  * 4096 / 8000 / 4096 floats, slabs[3..4]: up to 512 slabs of 16000 floats; nslabs[5].  Results identical to the two
  * separate launches.  Like nvf_wgrad_mfma3_partial it carries a queued latent tail as its first workgroup. */
 int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                             int* nslabs, void* stream);
+                             int* nslabs, NvfStepCtx* ctx, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */
@@ -238,28 +252,29 @@ int nvf_channel_sum(const float* x, float* out, void* workspace, size_t workspac
 /* several bias gradients at once (<= 12 tensors of the same batch): outs[i][c] = sum xs[i][b,c,:]; two launches */
 size_t nvf_multi_channel_sum_workspace(int total_channels);
 int nvf_multi_channel_sum(const float* const* xs, float* const* outs, const int* channels, const int* spatials,
-                          int ntensors, int batch, void* workspace, size_t workspace_bytes, void* stream);
+                          int ntensors, int batch, void* workspace, size_t workspace_bytes, NvfStepCtx* ctx,
+                          void* stream);
 
 /* nvf_wgrad_reduce_multi and the partial pass of nvf_multi_channel_sum in one launch (independent work), then the
  * bias sums' final pass; same results as the two separate calls */
 int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws, const int* nslabs,
                                     const int* jtotals, int n, const float* const* xs, float* const* outs,
                                     const int* channels, const int* spatials, int ntensors, int batch,
-                                    void* workspace, size_t workspace_bytes, void* stream);
+                                    void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream);
 
 /* The latent tail of a training step (backward of NVFPCC.py:186-196's latent generator on [batch, c <= 8, spatial]
  * tensors): gradient of the latent rate (+ dx_addend) -> GDN backward -> 1x1x1 weight and bias gradients, i.e.
- * nvf_latent_rate (want_grad) + nvf_gdn_bwd + nvf_wgrad + the bias sum.  Queued here, it runs as ONE workgroup of the
- * next nvf_wgrad_mfma3_partial or nvf_wgrad_reduce_multi_and_sums launch, whichever comes first (every input must
- * already be enqueued on that stream), instead of three dependent launches.  NVF_EINVAL while another tail is
- * pending. */
-int nvf_latent_tail_queue(const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
+ * nvf_latent_rate (want_grad) + nvf_gdn_bwd + nvf_wgrad + the bias sum.  Queued in `ctx`, it runs as ONE workgroup of
+ * the next nvf_wgrad_mfma3_partial / nvf_wgrad_trunk5_partial or nvf_wgrad_reduce_multi_and_sums call that is given the
+ * same ctx, whichever comes first (every input must already be enqueued on that call's stream), instead of three
+ * dependent launches.  NVF_EINVAL: ctx is not an initialised context, or another tail is pending in it. */
+int nvf_latent_tail_queue(NvfStepCtx* ctx, const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
                           const float* dx_addend, float* dlat, float* dsigma, float* dmu, const float* g_dev,
                           float g_host, int mode, uint64_t seed, uint64_t step, const uint64_t* step_dev,
                           const float* h, const float* beta_hat, const float* gamma_hat, float* dh, float* dbeta_hat,
                           float* dgamma_hat, const float* e, float* dw, float* db, int batch, int c, int spatial);
-int nvf_latent_tail_pending(void);
-void nvf_latent_tail_cancel(void);
+int nvf_latent_tail_pending(const NvfStepCtx* ctx);
+void nvf_latent_tail_cancel(NvfStepCtx* ctx);
 
 /* ---- GDN / IGDN (gdn_3d.py:72-95, 137-159; LowerBound gdn_3d.py:13-29) ----------
  * beta = max(beta_hat, beta_bound)^2 - 2^-36, gamma = max(gamma_hat, 2^-18)^2 - 2^-36;
@@ -307,18 +322,20 @@ int nvf_weight_rate(const float* kernel, int n, const float* sigma, const float*
 size_t nvf_weight_rate_batch_workspace(void);
 int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const int* ns, int nlayers,
                           const float* sigma, const float* mu, float* bits, float* dsigma, float* dmu,
-                          const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, void* stream);
+                          const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, NvfStepCtx* ctx,
+                          void* stream);
 
 /* ---- deferred final passes ------------------------------------------------------
  * nvf_focal_loss_multi, nvf_multi_channel_sum / nvf_wgrad_reduce_multi_and_sums and nvf_weight_rate_batch end with a
- * tiny launch that adds per-workgroup partial sums in a fixed order.  Between nvf_finals_begin() and
- * nvf_finals_flush(stream) those final passes (at most one of each kind; further ones are launched as usual) are
- * queued and flush runs them in ONE launch on `stream`: their outputs (the loss terms, the bias gradients, the
- * weight-rate bits and d/dsigma, d/dmu) exist only after the flush.  Same device code: identical results.  Used by
- * the training step, where nothing reads those outputs before the optimiser (NVFPCC.py:161-223). */
-void nvf_finals_begin(void);
-int nvf_finals_flush(void* stream);
-void nvf_finals_cancel(void);   /* drop the queue without launching (error paths) */
+ * tiny launch that adds per-workgroup partial sums in a fixed order.  Between nvf_finals_begin(ctx) and
+ * nvf_finals_flush(ctx, stream) the final passes of calls given that ctx (at most one of each kind; further ones are
+ * launched as usual) are queued in the context and flush runs them in ONE launch on `stream`: their outputs (the loss
+ * terms, the bias gradients, the weight-rate bits and d/dsigma, d/dmu) exist only after the flush.  Same device code:
+ * identical results.  Used by the training step, where nothing reads those outputs before the optimiser
+ * (NVFPCC.py:161-223).  nvf_finals_begin returns NVF_EINVAL when a queue is already open on ctx. */
+int nvf_finals_begin(NvfStepCtx* ctx);
+int nvf_finals_flush(NvfStepCtx* ctx, void* stream);
+void nvf_finals_cancel(NvfStepCtx* ctx);   /* drop the queue without launching (error paths) */
 
 /* workspace (bytes) for the two-stage reductions of nvf_focal_loss / nvf_metrics */
 size_t nvf_reduce_workspace(void);
@@ -336,11 +353,14 @@ int nvf_focal_loss(const float* p, const float* gt, const float* dist, float alp
  * loss[t] overwritten; dps[t] (optional) = d loss_t / d p_t, times p(1-p) with chain_sigmoid. */
 int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const float* const* dists,
                          float* const* dps, const float* alphas, const float* betas, const int64_t* ns, int nterm,
-                         float* loss, int chain_sigmoid, void* workspace, size_t workspace_bytes, void* stream);
+                         float* loss, int chain_sigmoid, void* workspace, size_t workspace_bytes, NvfStepCtx* ctx,
+                         void* stream);
 
 /* metrics (utils/loss.py:74-84, 113-121): out[0..5] (+)= tp, ap, tn, an at thh_acc; sse, denom at thh_sse */
+/* with ctx (an open nvf_finals_begin) the final pass joins the deferred ones: out exists after nvf_finals_flush, and
+ * `workspace` must then be a buffer no other deferred pass uses */
 int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
-                void* workspace, size_t workspace_bytes, int64_t n, int accumulate, void* stream);
+                void* workspace, size_t workspace_bytes, int64_t n, int accumulate, NvfStepCtx* ctx, void* stream);
 
 /* dlogit = dp * p * (1 - p)   (sigmoid backward of network.py:4761,4764,4768) */
 int nvf_sigmoid_bwd(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
@@ -359,6 +379,19 @@ int nvf_maxpool2(const float* x, float* y, int batch_channels, int d, int h, int
  * one fused update over a flat buffer; step counts from 1. */
 int nvf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);
+
+/* The tail of a training step with every per-step scalar in device memory (so it can be a node of a replayed HIP
+ * graph, behind the data-parallel all-reduce): nvf_adam_step with coef_dev[0] = lr / (1 - beta1^t) and
+ * coef_dev[1] = sqrt(1 - beta2^t) (coef_dev NULL: the two host values coef0_host, coef1_host instead) --
+ * nvf_adam_coefficients() gives exactly the two floats nvf_adam_step would use, so the updates are identical -- plus, when acc is non-NULL, the epoch's running sums (NVFPCC.py:190-221 without the
+ * per-step .item() syncs): acc[0..2] += loss_terms[0..2]; acc[3] += lbits[0] * (g_lat_dev ? *g_lat_dev : 1) *
+ * lbits_scale (b_latent, NVFPCC.py:161); acc[4] += sum(nbits[0..nnb)) * nbits_scale (b_net, :162); acc[5] += number
+ * of non-finite terms among those; acc[6] += number of non-finite gradient entries (the checks of NVFPCC.py:199-212,
+ * read by the host once per epoch); acc[7] += 1. */
+int nvf_step_tail(float* p, const float* g, float* m, float* v, int64_t n, const float* coef_dev, float coef0_host,
+                  float coef1_host, float beta1, float beta2, float eps, const float* loss_terms, const float* lbits, const float* nbits, int nnb,
+                  const float* g_lat_dev, float lbits_scale, float nbits_scale, float* acc, void* stream);
+int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
 
 /* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose
  * dst[idx[r],:] += src[r,:] (indices unique within a call) */

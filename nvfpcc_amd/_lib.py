@@ -19,6 +19,8 @@ Z = C.c_size_t
 # name -> (restype, argtypes); mirrors include/nvf_hip.h one to one
 PROTOTYPES = {
     "nvf_version": (I, []),
+    "nvf_step_ctx_bytes": (Z, []),
+    "nvf_step_ctx_init": (I, [P]),
     "nvf_pack_conv_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_pack_convT_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_effective_params": (I, [P, P, P, P, I, P, P, P, I, I, U, U, P]),
@@ -39,31 +41,31 @@ PROTOTYPES = {
     "nvf_pack_mfma_all": (I, [P, P, P, P, P, I, P]),
     "nvf_heads3_fwd": (I, [P, P, P, P, P, P, I, I, P]),
     "nvf_heads3_bwd_data": (I, [P, P, P, P, P, P, I, P]),
-    "nvf_heads3_loss_bwd_data": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P]),
+    "nvf_heads3_loss_bwd_data": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P, P]),
     "nvf_heads3_wgrad_partial": (I, [P, P, P, P, P, I, I, P, P]),
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "nvf_stem_latent_fwd": (I, [P] * 12 + [I, U, U, P] + [P] * 9 + [I, I, I, I, P]),
     "nvf_stem_bwd_workspace": (Z, [I, I]),
     "nvf_stem_bwd": (I, [P] * 13 + [Z, I, I, I, I, P]),
-    "nvf_stem_bwd_partial": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "nvf_stem_bwd_partial": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P, P]),
     "nvf_wgrad_workspace": (Z, [I] * 7),
     "nvf_wgrad": (I, [P, P, P, P, Z] + [I] * 15 + [P]),
     "nvf_wgrad_partial": (I, [P, P, P, P, Z] + [I] * 14 + [P, P]),
     "nvf_wgrad_reduce_multi": (I, [P, P, P, P, I, P]),
-    "nvf_wgrad_mfma3_partial": (I, [P, P, P, I, P, P]),
+    "nvf_wgrad_mfma3_partial": (I, [P, P, P, I, P, P, P]),
     "nvf_wgrad_up1_conv0_partial": (I, [P, P, P, I, P, P]),
-    "nvf_wgrad_trunk5_partial": (I, [P, P, P, I, P, P]),
+    "nvf_wgrad_trunk5_partial": (I, [P, P, P, I, P, P, P]),
     "nvf_channel_sum_workspace": (Z, [I]),
     "nvf_channel_sum": (I, [P, P, P, Z, I, I, I, I, P]),
     "nvf_multi_channel_sum_workspace": (Z, [I]),
-    "nvf_multi_channel_sum": (I, [P, P, P, P, I, I, P, Z, P]),
-    "nvf_wgrad_reduce_multi_and_sums": (I, [P, P, P, P, I, P, P, P, P, I, I, P, Z, P]),
-    "nvf_latent_tail_queue": (I, [P, P, P, P, P, P, P, P, P, F, I, U, U, P, P, P, P, P, P, P, P, P, P, I, I, I]),
-    "nvf_latent_tail_pending": (I, []),
-    "nvf_latent_tail_cancel": (None, []),
-    "nvf_finals_begin": (None, []),
-    "nvf_finals_flush": (I, [P]),
-    "nvf_finals_cancel": (None, []),
+    "nvf_multi_channel_sum": (I, [P, P, P, P, I, I, P, Z, P, P]),
+    "nvf_wgrad_reduce_multi_and_sums": (I, [P, P, P, P, I, P, P, P, P, I, I, P, Z, P, P]),
+    "nvf_latent_tail_queue": (I, [P, P, P, P, P, P, P, P, P, P, F, I, U, U, P, P, P, P, P, P, P, P, P, P, I, I, I]),
+    "nvf_latent_tail_pending": (I, [P]),
+    "nvf_latent_tail_cancel": (None, [P]),
+    "nvf_finals_begin": (I, [P]),
+    "nvf_finals_flush": (I, [P, P]),
+    "nvf_finals_cancel": (None, [P]),
     "nvf_gdn_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "nvf_gdn_bwd_workspace": (Z, [I]),
     "nvf_gdn_bwd": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
@@ -71,16 +73,18 @@ PROTOTYPES = {
     "nvf_latent_rate": (I, [P] * 12 + [F, I, I, I, I, U, U, P, P]),
     "nvf_weight_rate": (I, [P, I, P, P, P, P, P, P, P, F, I, P]),
     "nvf_weight_rate_batch_workspace": (Z, []),
-    "nvf_weight_rate_batch": (I, [P, P, P, I, P, P, P, P, P, P, F, P, Z, P]),
+    "nvf_weight_rate_batch": (I, [P, P, P, I, P, P, P, P, P, P, F, P, Z, P, P]),
     "nvf_reduce_workspace": (Z, []),
     "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, I, P]),
-    "nvf_focal_loss_multi": (I, [P, P, P, P, P, P, P, I, P, I, P, Z, P]),
-    "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P]),
+    "nvf_focal_loss_multi": (I, [P, P, P, P, P, P, P, I, P, I, P, Z, P, P]),
+    "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P, P]),
     "nvf_sigmoid_bwd": (I, [P, P, P, L, P]),
     "nvf_relu_bwd": (I, [P, P, P, L, P]),
     "nvf_squared_error_map": (I, [P, P, F, P, I, I, P]),
     "nvf_maxpool2": (I, [P, P, I, I, I, I, P]),
     "nvf_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
+    "nvf_step_tail": (I, [P, P, P, P, L, P, F, F, F, F, F, P, P, P, I, P, F, F, P, P]),
+    "nvf_adam_coefficients": (I, [F, F, F, I, P]),
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
     "nvf_gather_rows_multi": (I, [P, P, P, I, P, I, P]),

@@ -135,13 +135,38 @@ __device__ __forceinline__ void stem_gdn_final_body(const StemGdnFinal& f, int p
   }
 }
 
-// Queue (finals.hip).  A push returns false when nothing is being deferred or a job of that kind is already waiting:
-// the caller then launches its own final pass as usual.
-bool nvf_finals_push_focal(const FocalMulti& m, const float* part, float* loss, int nterm);
+// Everything one finals launch needs (at most one job of each kind)
+struct FinalsArgs {
+  FocalMulti f;
+  const float* f_part;
+  float* f_loss;
+  MultiSumDesc s;
+  const float* s_part;
+  WeightRateBatch r;
+  const float* r_part;
+  const float* r_sigma;
+  float* r_bits;
+  float* r_dsigma;
+  float* r_dmu;
+  const float* r_gdev;
+  float r_ghost;
+  StemGdnFinal g;
+  const float* m_part;   // metrics (nvf_metrics): m_nwg rows of 6 partial sums, added into m_out[0..5]
+  float* m_out;
+  int32_t m_nwg, m_accumulate;
+  int32_t f_nterm, has_f, has_s, has_r, has_g, has_m;
+};
+
+// Queue (finals.hip), held in the caller's NvfStepCtx (step_ctx.h); ctx == nullptr means "nothing is deferred".  A push
+// returns false when nothing is being deferred or a job of that kind is already waiting: the caller then launches its
+// own final pass as usual.
+struct NvfStepCtx;
+bool nvf_finals_push_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm);
 // queue the stem's IGDN final pass or, when nothing is being deferred, launch it on `stream` (c0 + c0^2 <= 128)
-int nvf_finals_run_stem_gdn(const StemGdnFinal& f, void* stream);
+int nvf_finals_run_stem_gdn(NvfStepCtx* ctx, const StemGdnFinal& f, void* stream);
 // queue the focal final pass or, when nothing is being deferred, launch it on `stream`
-int nvf_finals_run_focal(const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);
-bool nvf_finals_push_sums(const MultiSumDesc& d, const float* part);
-bool nvf_finals_push_rate(const WeightRateBatch& b, const float* part, const float* sigma, float* bits, float* dsigma,
-                          float* dmu, const float* g_dev, float g_host);
+int nvf_finals_run_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);
+bool nvf_finals_push_sums(NvfStepCtx* ctx, const MultiSumDesc& d, const float* part);
+bool nvf_finals_push_metrics(NvfStepCtx* ctx, const float* part, float* out, int nwg, int accumulate);
+bool nvf_finals_push_rate(NvfStepCtx* ctx, const WeightRateBatch& b, const float* part, const float* sigma, float* bits,
+                          float* dsigma, float* dmu, const float* g_dev, float g_host);

@@ -13,7 +13,7 @@
 //   * give each thread four consecutive x outputs, so one row segment (a b128 plus two b32 LDS
 //     reads) feeds 12 FMAs per input channel.
 #include "nvf_common.h"
-#include "finals.h"
+#include "step_ctx.h"
 
 namespace {
 
@@ -537,7 +537,7 @@ extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* con
                                         const float* alphas, const float* betas, const int* slots, float* loss,
                                         float* const* dls, const float* const* wbs, float* const* dxs,
                                         const float* const* masks, const int* cs, const int* ss, int batch,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
   if (!ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs || !masks || !cs || !ss ||
       !workspace || batch <= 0)
     return NVF_EINVAL;
@@ -560,7 +560,7 @@ extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* con
   if (slots[0] == slots[1] || slots[0] == slots[2] || slots[1] == slots[2]) return NVF_EINVAL;
   heads3_loss_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m, f);
   NVF_LAUNCH_CHECK();
-  return nvf_finals_run_focal(fm, (const float*)workspace, loss, 3, stream);
+  return nvf_finals_run_focal(ctx, fm, (const float*)workspace, loss, 3, stream);
 }
 
 // partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)

@@ -4,7 +4,7 @@
 // data with the gradient fused into the forward where the caller wants it, and fixed-order
 // two-stage reductions instead of float atomics so results are reproducible.
 #include "nvf_common.h"
-#include "finals.h"
+#include "step_ctx.h"
 #include "pack_mfma.h"
 #include "latent_tail.h"
 
@@ -457,7 +457,7 @@ extern "C" size_t nvf_weight_rate_batch_workspace(void) { return (size_t)3 * 512
 extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const int* ns, int nlayers,
                                      const float* sigma, const float* mu, float* bits, float* dsigma, float* dmu,
                                      const float* g_dev, float g_host, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     NvfStepCtx* ctx, void* stream) {
   if (!kernels || !ns || nlayers <= 0 || nlayers > 8 || !sigma || !mu || !bits || !workspace) return NVF_EINVAL;
   if (workspace_bytes < nvf_weight_rate_batch_workspace()) return NVF_EWORKSPACE;
   WeightRateBatch b{};
@@ -482,7 +482,7 @@ extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* 
   if (wg > 512) return NVF_EINVAL;
   hipStream_t s = nvf_stream(stream);
   weight_rate_batch_kernel<<<wg, 256, 0, s>>>(b, sigma, mu, (float*)workspace, g_dev, g_host);
-  if (!nvf_finals_push_rate(b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host))
+  if (!nvf_finals_push_rate(ctx, b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host))
     weight_rate_batch_final<<<1, 64, 0, s>>>(b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -569,7 +569,7 @@ __global__ void focal_multi_final(FocalMulti m, const float* __restrict__ part, 
 extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const float* const* dists,
                                     float* const* dps, const float* alphas, const float* betas, const int64_t* ns,
                                     int nterm, float* loss, int chain_sigmoid, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
   if (!ps || !gts || !alphas || !ns || !loss || !workspace || nterm <= 0 || nterm > 3) return NVF_EINVAL;
   if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
   FocalMulti m{};
@@ -587,7 +587,7 @@ extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* 
   }
   hipStream_t s = nvf_stream(stream);
   focal_multi_kernel<<<dim3(maxwg, nterm), 256, 0, s>>>(m, (float*)workspace, chain_sigmoid);
-  if (!nvf_finals_push_focal(m, (const float*)workspace, loss, nterm))
+  if (!nvf_finals_push_focal(ctx, m, (const float*)workspace, loss, nterm))
     focal_multi_final<<<1, 64 * nterm, 0, s>>>(m, (const float*)workspace, loss, nterm);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -620,14 +620,16 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
 }
 
 extern "C" int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
-                           void* workspace, size_t workspace_bytes, int64_t n, int accumulate, void* stream) {
+                           void* workspace, size_t workspace_bytes, int64_t n, int accumulate, NvfStepCtx* ctx,
+                           void* stream) {
   if (!p || !gt || !out || !workspace || n <= 0) return NVF_EINVAL;
   if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
   int nwg = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (nwg > kLossMaxWG) nwg = kLossMaxWG;
   hipStream_t s = nvf_stream(stream);
   metrics_kernel<<<nwg, 256, 0, s>>>(p, gt, dist, thh_acc, thh_sse, (float*)workspace, (long)n);
-  finalize_partials<<<1, 64, 0, s>>>((const float*)workspace, out, nwg, 6, accumulate);
+  if (!nvf_finals_push_metrics(ctx, (const float*)workspace, out, nwg, accumulate))
+    finalize_partials<<<1, 64, 0, s>>>((const float*)workspace, out, nwg, 6, accumulate);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -735,6 +737,82 @@ extern "C" int nvf_adam_step(float* p, const float* g, float* m, float* v, int64
   adam_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(p, g, m, v, (long)n, (float)(lr / bc1), beta1, beta2,
                                                                 eps, (float)sqrt(bc2));
   NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// The tail of a training step with every per-step scalar in DEVICE memory, so that it can sit inside a replayed HIP graph
+// (and behind the data-parallel all-reduce): Adam with coef[0] = lr / (1 - b1^t), coef[1] = sqrt(1 - b2^t) staged by the
+// host (the floats nvf_adam_step computes: identical updates), a count of non-finite gradient entries
+// (NVFPCC.py:199-212's checks, read once per epoch instead of synchronising every step), and the epoch's running sums of
+// the objective's terms.  Workgroup 0's first thread does the sums after the element-wise part.
+struct StepStats {
+  const float* loss_terms;   // [3] focal terms (main, head 0, head 1)
+  const float* lbits;        // [1] latent bits of the mini-batch
+  const float* nbits;        // [nnb] weight bits per quantised kernel
+  const float* g_lat_dev;    // [1] optional factor: lambda * w1 / n_pts when lbits_scale = 1 / (lambda * w1)
+  float* acc;                // [8]: loss terms 0..2, b_latent, b_net, non-finite objective terms, non-finite gradient
+                             //      entries, steps
+  float lbits_scale, nbits_scale;
+  int32_t nnb;
+};
+
+__global__ void step_tail_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long n, const float* __restrict__ coef, float c0, float c1,
+                                 float b1, float b2, float eps, StepStats st) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int bad = 0;
+  if (i < n) {
+    const float step_size = coef ? coef[0] : c0, bc2_sqrt = coef ? coef[1] : c1;
+    float gi = g[i];
+    bad = !(fabsf(gi) <= 3.402823466e38f);          // NaN or +-inf
+    float mi = m[i] * b1 + gi * (1.f - b1);
+    float vi = v[i] * b2 + (gi * gi) * (1.f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+  if (!st.acc) return;
+  const unsigned long long any = __ballot(bad);
+  if (any && (threadIdx.x & 63) == 0) atomicAdd(st.acc + 6, (float)__popcll(any));   // integer-valued: order-free
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int bad_terms = 0;
+    for (int t = 0; t < 3; ++t) {
+      const float x = st.loss_terms[t];
+      st.acc[t] += x;
+      bad_terms += !(fabsf(x) <= 3.402823466e38f);
+    }
+    const float bl = st.lbits[0] * (st.g_lat_dev ? st.g_lat_dev[0] : 1.f) * st.lbits_scale;
+    float nb = 0.f;
+    for (int l = 0; l < st.nnb; ++l) nb += st.nbits[l];
+    nb *= st.nbits_scale;
+    st.acc[3] += bl;
+    st.acc[4] += nb;
+    bad_terms += !(fabsf(bl) <= 3.402823466e38f) + !(fabsf(nb) <= 3.402823466e38f);
+    st.acc[5] += (float)bad_terms;
+    st.acc[7] += 1.f;
+  }
+}
+
+extern "C" int nvf_step_tail(float* p, const float* g, float* m, float* v, int64_t n, const float* coef_dev,
+                             float coef0_host, float coef1_host, float beta1, float beta2, float eps, const float* loss_terms, const float* lbits,
+                             const float* nbits, int nnb, const float* g_lat_dev, float lbits_scale, float nbits_scale,
+                             float* acc, void* stream) {
+  if (!p || !g || !m || !v || n <= 0) return NVF_EINVAL;
+  if (acc && (!loss_terms || !lbits || !nbits || nnb <= 0 || nnb > 16)) return NVF_EINVAL;
+  StepStats st{loss_terms, lbits, nbits, g_lat_dev, acc, lbits_scale, nbits_scale, nnb};
+  step_tail_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(p, g, m, v, (long)n, coef_dev, coef0_host,
+                                                                    coef1_host, beta1, beta2, eps, st);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// the two floats nvf_step_tail reads from coef_dev for optimiser step `step` (>= 1): what nvf_adam_step passes
+extern "C" int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host) {
+  if (!coef_host || step < 1) return NVF_EINVAL;
+  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  coef_host[0] = (float)(lr / bc1);
+  coef_host[1] = (float)sqrt(bc2);
   return NVF_OK;
 }
 

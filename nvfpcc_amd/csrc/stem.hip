@@ -12,7 +12,7 @@
 // loads before use.  Accumulation orders equal those of the per-layer kernels (conv_direct.hip), so the forward
 // is bit-identical to the unfused path.
 #include "nvf_common.h"
-#include "finals.h"
+#include "step_ctx.h"
 #include "latent_tail.h"
 
 namespace {
@@ -434,7 +434,7 @@ extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const floa
                                     const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0,
                                     float* dx0, float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs,
                                     void* workspace, size_t workspace_bytes, int batch, int ch, int c0, int c1,
-                                    void* stream) {
+                                    NvfStepCtx* ctx, void* stream) {
   if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0 || !dbeta_hat ||
       !dgamma_hat || !dw_slabs || !nslabs)
     return NVF_EINVAL;
@@ -452,5 +452,5 @@ extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const floa
   *dw_slabs = slab_w;
   *nslabs = nslab;
   StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab, C0};
-  return nvf_finals_run_stem_gdn(f, stream);
+  return nvf_finals_run_stem_gdn(ctx, f, stream);
 }

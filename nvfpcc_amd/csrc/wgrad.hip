@@ -18,8 +18,7 @@
 #include "nvf_common.h"
 #include <cstdio>
 #include <cstdlib>
-#include "finals.h"
-#include "latent_tail.h"
+#include "step_ctx.h"
 
 static const int kMaxSlabs = 512;
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
@@ -572,12 +571,8 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
 // its MFMA pipes busy about half of the time (tile staging, LDS waits); 256 VGPRs and <= 80 KB of LDS per workgroup
 // let two workgroups share a CU, so the second kernel's workgroups run in the first one's bubbles.  Same bodies, same
 // slabs, same results as three launches.
-// the latent tail queued by nvf_latent_tail_queue: consumed by the next nvf_wgrad_mfma3_partial or
-// nvf_wgrad_reduce_multi_and_sums launch, whichever comes first on the stream
-namespace {
-LatentTail g_tail{};
-bool g_tail_pending = false;
-}  // namespace
+// the latent tail queued in the caller's NvfStepCtx by nvf_latent_tail_queue: consumed by the next
+// nvf_wgrad_mfma3_partial / nvf_wgrad_trunk5_partial or nvf_wgrad_reduce_multi_and_sums call with that context
 
 struct WgMfma3 {
   const float* p[3];
@@ -637,7 +632,7 @@ static void fill_up1_conv0(WgTiled2& m, const float* const* ps, const float* con
 
 // njobs = 3: conv2, up2, conv1 (matrix cores); njobs = 5: + up1, conv0 (the VALU tile kernel with 256-thread workgroups)
 static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                               int* nslabs, int njobs, void* stream) {
+                               int* nslabs, int njobs, NvfStepCtx* ctx, void* stream) {
   if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
   using C0 = MCfg<32, 4, 4>; using T1 = TWCfg<2, 2>; using C2 = MCfg<16, 2, 8>;
   using U0 = WCfg<16, 5, 2, 2, 8, 4, 2, 0>; using U1 = WCfg<8, 5, 2, 2, 4, 4, 4, 0>;
@@ -669,9 +664,9 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     fill_up1_conv0<U0, U1>(u, ps + 3, qs + 3, slabs + 3, batch, nslabs + 3);
     grid += u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1];
   }
-  if (g_tail_pending) {
-    g_tail_pending = false;
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, g_tail);
+  if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
+    ctx->tail_pending = 0;
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail);
   } else {
     wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{});
   }
@@ -683,16 +678,16 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
 // job 2: conv1 (p = dY [B,8,16^3], q = X [B,8,19^3]).  slabs[j] must hold 512 slabs of 4096 / 8000 / 4096 floats;
 // nslabs[j] receives the number written (to be added by nvf_wgrad_reduce_multi).
 extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                                       int* nslabs, void* stream) {
-  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 3, stream);
+                                       int* nslabs, NvfStepCtx* ctx, void* stream) {
+  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 3, ctx, stream);
 }
 
 // ... and jobs 3, 4 = up1 (p = X [B,16,8^3], q = dY [B,8,19^3]), conv0 (p = X [B,8,4^3], q = dY [B,16,8^3]) of
 // nvf_wgrad_up1_conv0_partial in the same launch: all five weight gradients of the narrow trunk above the stem.
 // slabs[3], slabs[4]: up to 512 slabs of 16000 floats.  Same results as the two separate launches.
 extern "C" int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                                        int* nslabs, void* stream) {
-  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, stream);
+                                        int* nslabs, NvfStepCtx* ctx, void* stream) {
+  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream);
 }
 
 template <class C>
@@ -1065,7 +1060,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_sums_tail(WgReduceMulti r, 
 // [batch, c <= 8, spatial] tensors.  It runs as one workgroup of the NEXT nvf_wgrad_reduce_multi_and_sums launch on
 // the same stream (all of its inputs must already be enqueued there); results = nvf_latent_rate + nvf_gdn_bwd +
 // nvf_wgrad (+ the bias sum, whose summation order differs from nvf_multi_channel_sum).
-extern "C" int nvf_latent_tail_queue(const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
+extern "C" int nvf_latent_tail_queue(NvfStepCtx* ctx, const float* lat, const int64_t* block_ids, const float* sigma, const float* mu,
                                      const float* dx_addend, float* dlat, float* dsigma, float* dmu,
                                      const float* g_dev, float g_host, int mode, uint64_t seed, uint64_t step,
                                      const uint64_t* step_dev, const float* h, const float* beta_hat,
@@ -1074,20 +1069,22 @@ extern "C" int nvf_latent_tail_queue(const float* lat, const int64_t* block_ids,
   if (!lat || !sigma || !mu || !dlat || !dsigma || !dmu || !h || !beta_hat || !gamma_hat || !dh || !dbeta_hat ||
       !dgamma_hat || !e || !dw || !db)
     return NVF_EINVAL;
-  if (batch <= 0 || c <= 0 || c > kTailMaxC || spatial <= 0 || (mode != 0 && mode != 1) || g_tail_pending)
-    return NVF_EINVAL;
+  if (!nvf_ctx_ok(ctx) || ctx->tail_pending) return NVF_EINVAL;
+  if (batch <= 0 || c <= 0 || c > kTailMaxC || spatial <= 0 || (mode != 0 && mode != 1)) return NVF_EINVAL;
   LatentTail t{};
   t.lat = lat; t.block_ids = block_ids; t.sigma = sigma; t.mu = mu; t.dx_addend = dx_addend; t.dlat = dlat;
   t.dsigma = dsigma; t.dmu = dmu; t.g_dev = g_dev; t.step_dev = step_dev; t.seed = seed; t.step = step;
   t.h = h; t.beta_hat = beta_hat; t.gamma_hat = gamma_hat; t.dh = dh; t.dbeta_hat = dbeta_hat; t.dgamma_hat = dgamma_hat;
   t.e = e; t.dw = dw; t.db = db; t.g_host = g_host; t.batch = batch; t.c = c; t.spatial = spatial; t.mode = mode;
-  g_tail = t;
-  g_tail_pending = true;
+  ctx->tail = t;
+  ctx->tail_pending = 1;
   return NVF_OK;
 }
 
-extern "C" int nvf_latent_tail_pending(void) { return g_tail_pending ? 1 : 0; }
-extern "C" void nvf_latent_tail_cancel(void) { g_tail_pending = false; }
+extern "C" int nvf_latent_tail_pending(const NvfStepCtx* ctx) { return nvf_ctx_ok(ctx) && ctx->tail_pending ? 1 : 0; }
+extern "C" void nvf_latent_tail_cancel(NvfStepCtx* ctx) {
+  if (nvf_ctx_ok(ctx)) ctx->tail_pending = 0;
+}
 
 __global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part) {
   multi_channel_sum_final_body(d, part, blockIdx.x * blockDim.x + threadIdx.x);
@@ -1099,7 +1096,7 @@ extern "C" size_t nvf_multi_channel_sum_workspace(int total_channels) {
 
 extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs, const int* channels,
                                      const int* spatials, int ntensors, int batch, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
   if (!xs || !outs || !channels || !spatials || ntensors <= 0 || ntensors > 12 || batch <= 0 || !workspace)
     return NVF_EINVAL;
   MultiSumDesc d{};
@@ -1118,7 +1115,7 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
   if (workspace_bytes < nvf_multi_channel_sum_workspace(base)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
   multi_channel_sum_partial<<<dim3(base, d.nchunk), NVF_SUM_T, 0, s>>>(d, (float*)workspace);
-  if (!nvf_finals_push_sums(d, (const float*)workspace))
+  if (!nvf_finals_push_sums(ctx, d, (const float*)workspace))
     multi_channel_sum_final<<<(base + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -1130,7 +1127,7 @@ extern "C" int nvf_multi_channel_sum(const float* const* xs, float* const* outs,
 extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws, const int* nslabs,
                                                const int* jtotals, int n, const float* const* xs, float* const* outs,
                                                const int* channels, const int* spatials, int ntensors, int batch,
-                                               void* workspace, size_t workspace_bytes, void* stream) {
+                                               void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
   if (!slabs || !dws || !nslabs || !jtotals || n <= 0 || n > 16) return NVF_EINVAL;
   if (!xs || !outs || !channels || !spatials || ntensors <= 0 || ntensors > 12 || batch <= 0 || !workspace)
     return NVF_EINVAL;
@@ -1157,13 +1154,13 @@ extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float*
   d.nchunk = batch < kSumChunks ? batch : kSumChunks;
   if (workspace_bytes < nvf_multi_channel_sum_workspace(cb)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  if (g_tail_pending) {
-    g_tail_pending = false;
-    wgrad_reduce_sums_tail<<<1 + base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace, g_tail);
+  if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
+    ctx->tail_pending = 0;
+    wgrad_reduce_sums_tail<<<1 + base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace, ctx->tail);
   } else {
     wgrad_reduce_and_sums<<<base + cb * d.nchunk, 1024, 0, s>>>(r, base, d, (float*)workspace);
   }
-  if (!nvf_finals_push_sums(d, (const float*)workspace))
+  if (!nvf_finals_push_sums(ctx, d, (const float*)workspace))
     multi_channel_sum_final<<<(cb + 63) / 64, 64, 0, s>>>(d, (const float*)workspace);
   NVF_LAUNCH_CHECK();
   return NVF_OK;

@@ -7,10 +7,15 @@ Leaf blocks are independent given the shared decoder and every loss term is a SU
     all-reduce (SUM) of the flat fp32 gradient buffer (52 219 floats = 209 KB at chanstr 8,16,8,8 --
     latency-bound on xGMI, far below the per-link bandwidth regime), then every rank applies the same
     fused Adam update to its replica;
-  * the weight-rate term is identical on every rank, so its gradient is scaled by 1/W before the SUM;
+  * the weight-rate term is identical on every rank, so its gradient is scaled by 1/W before the SUM -- on EVERY
+    rank, including one whose share of a short last mini-batch is empty (TrainEngine._idle_backward), so the summed
+    gradient equals the single-GPU one whatever W is;
   * n_pts (points of the global mini-batch) is computed on the host from per-block counts: no collective;
   * weight noise (q = 1) is keyed by (seed, step, layer) and so identical on all ranks; latent noise is
-    keyed by block id, so results do not depend on W;
+    keyed by (block id, step), so results do not depend on W; the step counter advances once per mini-batch and
+    once per latent phase on every rank, idle or not;
+  * inside a replayed HIP graph the all-reduce is a captured node (RCCL is capture-aware), so the hand-over between
+    the compute stream and RCCL's stream costs no event wait at run time (engine.GraphedTrainStep);
   * latent phase / eval: contiguous block shards, no collective inside the step; one all-gather of the
     updated latent rows per epoch.
 """
@@ -89,9 +94,17 @@ def allgather_rows_(table, rank, world):
     return table
 
 
-def attach(engine, world):
-    """Wire an engine for data parallelism."""
-    if world > 1:
+def attach(engine, world, force=False):
+    """Wire an engine for data parallelism.  ``force``: install the all-reduce hook even for one rank (exercises the
+    RCCL plumbing -- communicator, capture inside the step graph -- on a single GPU)."""
+    if world > 1 or (force and dist.is_initialized()):
         engine.rate_grad_scale = 1.0 / world
-        engine.grad_hook = allreduce_sum_
+        engine.grad_hook = _allreduce_any_world if force and world == 1 else allreduce_sum_
+        # gloo (test hook) reduces through host memory, which cannot be captured into a HIP graph
+        engine.collective_mode = "host" if dist.get_backend() == "gloo" else os.environ.get("NVF_GRAPH_COLLECTIVE", "graph")
     return engine
+
+
+def _allreduce_any_world(flat):
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat

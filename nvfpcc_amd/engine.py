@@ -66,6 +66,10 @@ class TrainEngine:
         self.lmbda, self.w1, self.w2 = float(lmbda), float(w1), float(w2)
         self.lr, self.lr_emb = float(lr), float(lr) * float(wemb)
         self.seed = int(seed)
+        # Counter behind both noise sources (weight noise at q = 1, latent rate-proxy noise in every train-mode
+        # forward): it advances once per train / latent step WHATEVER q is -- the reference draws a fresh
+        # torch.rand_like(x) on every mode='train' forward (network.py:4516), also after --phase_change.  Every rank
+        # advances it identically (idle ranks of a short last batch included, NVFPCC.py train()).
         self.noise_step = 0
         self.rate_grad_scale = 1.0   # 1/world_size under data parallelism: the weight-rate term is replicated
         self.grad_hook = None        # called on flat_g between backward and Adam (RCCL all-reduce)
@@ -99,6 +103,10 @@ class TrainEngine:
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
         self._wg = None
+        self.ctx = ops.StepCtx()  # deferred final passes + queued latent tail of the step in flight (caller-owned)
+        self.metrics_acc = None   # float[6] epoch accumulator of tp, ap, tn, an, sse, denom (NVFPCC.py train logging)
+        self.epoch_acc = None     # float[8] epoch sums written by nvf_step_tail (enable_epoch_stats)
+        self.collective_mode = None   # "graph" / "host": where GraphedTrainStep puts the all-reduce (dist.attach)
         # the three classifier heads of the narrow decoder go through the one-launch kernels
         self.heads3 = tuple(net.reconstructor.channels) == (8, 16, 8, 8)
 
@@ -319,7 +327,7 @@ class TrainEngine:
         try:
             return self._backward(*args, **kw)
         except BaseException:
-            ops.finals_cancel()            # never leave the library queueing final passes
+            self.ctx.cancel()              # never leave final passes or a latent tail queued in the context
             raise
 
     def _backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
@@ -332,25 +340,31 @@ class TrainEngine:
         self.overlap = self.allow_overlap and a["e"].shape[0] <= 64
         self._bias_jobs = []
         if self._wg is None:
-            self._wg = ops.WgradBatch(self.dev)    # partial sums now, ONE reduction launch for all ten gradients
+            self._wg = ops.WgradBatch(self.dev, ctx=self.ctx)    # partial sums now, ONE reduction launch for all ten
         loss = torch.empty(4, device=self.dev)   # [main, head0, head1, unused]
         nbits = torch.empty(7, device=self.dev)
         # the one-block final passes of the focal terms, the bias sums and the weight rate feed nothing inside the
         # step: queue them and run all three in one launch at the end (single-stream schedule only)
         defer = want_w and not self.overlap
+        ctx = self.ctx if defer else None
         if defer:
-            ops.finals_begin()
+            self.ctx.begin()
         fused_loss = self.heads3 and a["e"].shape[0] <= 32 and _NAIVE_OFF()
         if not fused_loss:
             dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
-                                                  (a["p1"], gt16, None, 0.85, 0.0)], loss)
+                                                  (a["p1"], gt16, None, 0.85, 0.0)], loss, ctx=ctx)
+        if self.metrics_acc is not None and want_w:
+            # logging sums of NVFPCC.py:190-221 (Pacc / Nacc / sse / denom over the epoch): one partial-sum launch, the
+            # final pass rides in the finals launch and adds into the epoch accumulator
+            ops.metrics(a["p2"], gt, dist, 0.5, 0.6, out=self.metrics_acc, accumulate=True, ctx=ctx)
         ev_t1 = ev_t0 = None
         if self.heads3:
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
             if fused_loss:      # the three focal terms, their logit gradients and the heads' backward-data: one launch
                 (dl0, dl1, dl2), (t0, t1, g5) = ops.heads3_loss_bwd_data(
                     [a["p0"], a["p1"], a["p2"]], [gt8, gt16, gt], [None, None, dist], [0.85, 0.85, 0.9],
-                    [0.0, 0.0, 1.0], [1, 2, 0], loss, [L.w_bwd for L in hl], [L.cin for L in hl], [None, None, a["y5"]])
+                    [0.0, 0.0, 1.0], [1, 2, 0], loss, [L.w_bwd for L in hl], [L.cin for L in hl], [None, None, a["y5"]],
+                    ctx=ctx)
             else:
                 t0, t1, g5 = ops.heads3_bwd_data([dl0, dl1, dl2], [L.w_bwd for L in hl], [L.cin for L in hl],
                                                  [None, None, a["y5"]])
@@ -411,7 +425,7 @@ class TrainEngine:
         if self.fused_stem and defer:        # its final launch is shared with the slab reduction / the final passes
             da0, dx0 = ops.stem_bwd_partial(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta,
                                             ig.gamma, gview("reconstructor.activation.beta"), gamma_view,
-                                            Ls["up0"].gk, self._wg)
+                                            Ls["up0"].gk, self._wg, ctx=ctx)
             self._bias_jobs.append((da0, Ls["up0"].gb))
         elif self.fused_stem:
             da0, dx0 = ops.stem_bwd(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta, ig.gamma,
@@ -435,7 +449,7 @@ class TrainEngine:
             # three dependent launches on [B, ch, 2^3] tensors -> one workgroup of the next weight-gradient launch
             # (or of the slab reduction); dlat / dh / dx0 stay referenced until that launch has been enqueued
             dlat, dh = torch.empty_like(a["lat"]), torch.empty_like(a["h"])
-            ops.latent_tail_queue(a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode, block_ids, dx0, dlat,
+            ops.latent_tail_queue(self.ctx, a["lat"], ec.sigma.reshape(-1), ec.mu.reshape(-1), mode, block_ids, dx0, dlat,
                                   gview("entropy_coder.sigma"), gview("entropy_coder.mu"), self._g_lat_dev, g_lat,
                                   self.seed, 0 if sd is not None else self.noise_step, sd, a["h"], g2m.beta, g2m.gamma,
                                   dh, gview("latent_gen.gdn_2.beta"),
@@ -471,11 +485,11 @@ class TrainEngine:
             if want_w:     # slab reduction of every weight gradient + all bias sums
                 self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
                 ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
-                                      g_host=g_net * self.rate_grad_scale)
+                                      g_host=g_net * self.rate_grad_scale, ctx=ctx)
             else:
                 ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
             if defer:
-                ops.finals_flush()
+                self.ctx.flush()
         if self.overlap:
             main.wait_stream(self.side)      # join: nothing below (Adam, frees) may pass the side work
         self.last = {"loss_terms": loss, "latent_bits": a["lbits"], "net_bits": nbits, "n_pts": n_pts}
@@ -486,32 +500,88 @@ class TrainEngine:
         """(gt, dist, gt16, gt8, emb) rows of the mini-batch: one fused gather."""
         return ops.gather_rows_multi([self.gt, self.dist, self.gt16, self.gt8, self.emb], idx_dev)
 
-    def train_step(self, idx_host, q, idx_dev=None, update=True, n_pts=None):
-        """One mini-batch decoder update (NVFPCC.py:149-223, minus logging).  Under data parallelism
-        ``idx_host`` is this rank's share of the global mini-batch and ``n_pts`` the occupied-voxel count
-        of the WHOLE mini-batch (host-known: every rank derives the same epoch order)."""
-        idx_host = np.asarray(idx_host, np.int64)
-        if idx_dev is None:
-            idx_dev = torch.from_numpy(idx_host).to(self.dev)
-        if q == 1:
-            self.noise_step += 1
-        if n_pts is None:
-            n_pts = float(self.counts[idx_host].sum())
-        gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q)
-        a = self.forward(e, "train", idx_dev)
-        self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False)
+    def enable_epoch_stats(self):
+        """Device accumulators behind NVFPCC.py train's per-epoch log line (the reference syncs ~14 .item()s per step,
+        NVFPCC.py:190-221): metrics_acc[6] = tp, ap, tn, an, sse, denom; epoch_acc[8] = the three focal terms,
+        b_latent, b_net, non-finite objective terms, non-finite gradient entries, steps (nvf_step_tail)."""
+        if self.epoch_acc is None:
+            self.metrics_acc = torch.zeros(6, device=self.dev)
+            self.epoch_acc = torch.zeros(8, device=self.dev)
+
+    def read_epoch_stats(self, reset=True, reduce=None):
+        """(metrics[6], sums[8]) as float64 numpy arrays: ONE host sync per epoch (``reduce``: the data-parallel
+        all-reduce applied to the 14 floats first).  Raises on the reference's NaN checks (NVFPCC.py:199-212:
+        'Problem in loss' / 'Problem with grad') instead of opening an IPython shell."""
+        both = torch.cat([self.metrics_acc, self.epoch_acc])
+        if reduce is not None:
+            reduce(both)
+        both = both.double().cpu().numpy()
+        if reset:
+            self.metrics_acc.zero_()
+            self.epoch_acc.zero_()
+        if both[6 + 5] > 0:
+            raise ValueError("Problem in loss: %d non-finite objective terms this epoch" % int(both[6 + 5]))
+        if both[6 + 6] > 0:
+            raise ValueError("Problem with grad: %d non-finite gradient entries this epoch" % int(both[6 + 6]))
+        return both[:6], both[6:]
+
+    def _tail(self, n_pts, coef_dev=None, g_lat_dev=None):
+        """All-reduce hook (data parallelism), then Adam (+ the epoch sums): nvf_step_tail."""
         if self.grad_hook is not None:
             self.grad_hook(self.flat_g)
+        self.opt_step += 1
+        coef = (0.0, 0.0) if coef_dev is not None else ops.adam_coefficients(self.lr, self.opt_step)
+        t = self.last
+        stats = self.epoch_acc is not None
+        ops.step_tail(self.flat_p, self.flat_g, self.flat_m, self.flat_v, coef_dev, coef,
+                      loss_terms=t["loss_terms"] if stats else None, lbits=t["latent_bits"] if stats else None,
+                      nbits=t["net_bits"] if stats else None, g_lat_dev=g_lat_dev,
+                      lbits_scale=(1.0 / (self.lmbda * self.w1)) if g_lat_dev is not None else 1.0 / n_pts,
+                      nbits_scale=1.0 / self.n_points_total, acc=self.epoch_acc)
+
+    def _idle_backward(self):
+        """A rank whose share of a short last mini-batch is empty (NVFPCC.py:149 with 917 mod 16 = 5 blocks on 8
+        GPUs): no block terms, but its 1/W share of the replicated weight-rate gradient (and of d/d sigma, d/d mu of
+        the likelihood model) still goes into the all-reduce, so the summed gradient is the single-GPU one."""
+        net, Ls = self.net, self.layers
+        self.flat_g.zero_()
+        lm = net.reconstructor.likelihood_model
+        nbits = torch.empty(7, device=self.dev)
+        g_net = self.lmbda * self.w2 / self.n_points_total
+        ops.weight_rate_batch([Ls[n].mod.kernel for n in TRUNK], [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits,
+                              self._g("reconstructor.likelihood_model.sigma"),
+                              self._g("reconstructor.likelihood_model.mu"), g_host=g_net * self.rate_grad_scale)
+        self.last = {"loss_terms": torch.zeros(4, device=self.dev), "latent_bits": torch.zeros(1, device=self.dev),
+                     "net_bits": nbits, "n_pts": 1.0}
+
+    def train_step(self, idx_host, q, idx_dev=None, update=True, n_pts=None):
+        """One mini-batch decoder update (NVFPCC.py:149-223, minus logging).  Under data parallelism
+        ``idx_host`` is this rank's share of the global mini-batch (possibly empty) and ``n_pts`` the occupied-voxel
+        count of the WHOLE mini-batch (host-known: every rank derives the same epoch order)."""
+        idx_host = np.asarray(idx_host, np.int64)
+        self.noise_step += 1       # a fresh draw per train-mode forward whatever q is (latent noise, network.py:4516)
+        a = None
+        if idx_host.shape[0] == 0:
+            self._idle_backward()
+            n_pts = 1.0
+        else:
+            if idx_dev is None:
+                idx_dev = torch.from_numpy(idx_host).to(self.dev)
+            if n_pts is None:
+                n_pts = float(self.counts[idx_host].sum())
+            gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q)
+            a = self.forward(e, "train", idx_dev)
+            self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False)
         if update:
-            self.opt_step += 1
-            ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.opt_step)
+            self._tail(n_pts)
+        elif self.grad_hook is not None:
+            self.grad_hook(self.flat_g)
         return a
 
     def latent_step(self, q, lo=0, hi=None, update=True):
         """Full-batch latent update over blocks [lo, hi) (NVFPCC.py:225-251); no weight gradients."""
         hi = self.N_leaf if hi is None else hi
-        if q == 1:
-            self.noise_step += 1
+        self.noise_step += 1
         ids = torch.arange(lo, hi, device=self.dev)
         n_pts = float(self.counts.sum())          # the reference divides by the points of ALL blocks
         self.prepare_weights(q)
@@ -541,53 +611,96 @@ class TrainEngine:
 
 
 class GraphedTrainStep:
-    """The mini-batch step body captured once into a HIP graph and replayed: removes ~90 host-side launches
-    per step (the reference pays ~1 500 aten dispatches).  Everything that changes from step to step comes
-    from device memory: block ids, the rate coefficient lambda*w1/n_pts and the noise-step counter.
-    Adam stays outside the graph (its bias correction depends on the step number)."""
+    """The whole mini-batch step -- step head, forward, losses, backward, [all-reduce], Adam + epoch sums -- captured
+    once into a HIP graph and replayed: removes ~90 host-side launches per step (the reference pays ~1 500 aten
+    dispatches).  Everything that changes from step to step comes from device memory, refreshed by ONE pinned-memory
+    copy: block ids, the noise-step counter, the rate coefficient lambda*w1/n_pts and Adam's two step-dependent
+    coefficients (lr / (1 - b1^t), sqrt(1 - b2^t): nvf_step_tail).
 
-    def __init__(self, eng, batch, q, ring=8):
+    Data parallelism: ``collective`` = "graph" captures the all-reduce of flat_g inside the graph (RCCL is
+    capture-aware: the hand-over between the compute stream and RCCL's stream becomes a graph edge instead of two
+    event waits per step); "host" ends the graph before it and launches hook + tail from the host."""
+
+    def __init__(self, eng, batch, q, ring=8, collective=None):
         self.eng, self.batch, self.q = eng, batch, q
         dev = eng.dev
-        # one device buffer [idx (B x i64) | noise step (u64) | lambda*w1/n_pts (f32 in the low half)] refreshed by a
-        # single pinned-memory copy per step.  The host may run several steps ahead of the GPU, so the staging side is
-        # a ring of pinned buffers: a slot is rewritten only after the copy that read it has executed (its event).
-        self.buf = torch.zeros(batch + 2, dtype=torch.int64, device=dev)
-        self.pins = [torch.zeros(batch + 2, dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
+        if collective is None:
+            collective = getattr(eng, "collective_mode", None) or os.environ.get("NVF_GRAPH_COLLECTIVE", "graph")
+        self.collective = collective if eng.grad_hook is not None else "none"
+        # one device buffer [idx (B x i64) | noise step (u64) | lambda*w1/n_pts (f32 in the low half) | Adam coef (2 x f32)]
+        # refreshed by a single pinned-memory copy per step.  The host may run several steps ahead of the GPU, so the
+        # staging side is a ring of pinned buffers: a slot is rewritten only after the copy that read it has executed.
+        nw = batch + 3
+        self.buf = torch.zeros(nw, dtype=torch.int64, device=dev)
+        self.pins = [torch.zeros(nw, dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
         self.pin_events = [None] * len(self.pins)
         self.calls = 0
         self.idx = self.buf[:batch]
         self.step = self.buf[batch:batch + 1]
         self.g_lat = self.buf[batch + 1:batch + 2].view(torch.float32)[0:1]
+        self.coef = self.buf[batch + 2:batch + 3].view(torch.float32)
         eng._step_dev, eng._g_lat_dev = self.step, self.g_lat
         self.pins[0][:batch] = torch.arange(batch) % eng.N_leaf
         self.pins[0][batch + 1:batch + 2].view(torch.float32)[0] = 1.0
         self.buf.copy_(self.pins[0])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # warm-up: allocates the grow-only workspaces outside the graph
-            for _ in range(2):
-                self._body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._body()
-        eng._step_dev, eng._g_lat_dev = None, None
+        macc = eng.metrics_acc
+        try:
+            with torch.cuda.stream(side):      # warm-up: allocates the grow-only workspaces outside the graph; the
+                if macc is not None:           # tail (no workspace) is left out, so no state is touched
+                    eng.metrics_acc = torch.zeros_like(macc)
+                for _ in range(2):
+                    self._body(tail=False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            eng.metrics_acc = macc
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._body(tail=self.collective != "host")
+            except Exception as exc:           # a collective that cannot be captured: keep it outside the graph
+                if self.collective != "graph":
+                    raise
+                print(f"[nvfpcc_amd] all-reduce not capturable ({type(exc).__name__}: {exc}); launching it from the "
+                      f"host between the step graph and the optimiser", flush=True)
+                self.collective = eng.collective_mode = "host"
+                eng.ctx.cancel()
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._body(tail=False)
+        finally:
+            eng.metrics_acc = macc
+            eng._step_dev, eng._g_lat_dev = None, None
 
-    def _body(self):
+    def _body(self, tail):
         eng = self.eng
         gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q)
         a = eng.forward(e, "train", self.idx)
         eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False)
         self.out = a
+        self.last = dict(eng.last)
+        if tail:
+            self._tail()
+
+    def _tail(self):
+        eng = self.eng
+        if eng.grad_hook is not None:
+            eng.grad_hook(eng.flat_g)
+        t = self.last
+        stats = eng.epoch_acc is not None
+        ops.step_tail(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, self.coef,
+                      loss_terms=t["loss_terms"] if stats else None, lbits=t["latent_bits"] if stats else None,
+                      nbits=t["net_bits"] if stats else None, g_lat_dev=self.g_lat,
+                      lbits_scale=1.0 / (eng.lmbda * eng.w1), nbits_scale=1.0 / eng.n_points_total, acc=eng.epoch_acc)
 
     def __call__(self, idx_host, n_pts=None):
         eng = self.eng
         idx_host = np.asarray(idx_host, np.int64)
         assert idx_host.shape[0] == self.batch
-        if self.q == 1:
-            eng.noise_step += 1
+        eng.noise_step += 1
+        eng.opt_step += 1
         if n_pts is None:
             n_pts = float(eng.counts[idx_host].sum())
         slot = self.calls % len(self.pins)
@@ -598,14 +711,46 @@ class GraphedTrainStep:
         pin[:self.batch] = torch.from_numpy(idx_host)
         pin[self.batch] = eng.noise_step
         pin[self.batch + 1:self.batch + 2].view(torch.float32)[0] = eng.lmbda * eng.w1 / n_pts
+        c = pin[self.batch + 2:self.batch + 3].view(torch.float32)
+        c[0], c[1] = ops.adam_coefficients(eng.lr, eng.opt_step)
         self.buf.copy_(pin, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pin_events[slot] = ev
         self.graph.replay()
+        eng.last = dict(self.last)
         eng.last["n_pts"] = n_pts
-        if eng.grad_hook is not None:
-            eng.grad_hook(eng.flat_g)
-        eng.opt_step += 1
-        ops.adam_step(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, eng.lr, eng.opt_step)
+        if self.collective == "host":
+            self._tail()
         return self.out
+
+
+class EpochDriver:
+    """The mini-batch phase of one epoch of NVFPCC.py train (NVFPCC.py:149-223) on this rank: full-size mini-batches
+    replay the captured graph of their (share size, q), anything else (the short last batch, an empty share) takes the
+    host-launched step.  No host synchronisation: the log line's sums stay in device accumulators
+    (TrainEngine.read_epoch_stats, once per epoch)."""
+
+    def __init__(self, eng, batch, rank=0, world=1, use_graph=True):
+        from . import dist as nd
+        self.eng, self.batch, self.rank, self.world, self.use_graph = eng, int(batch), rank, world, use_graph
+        self.nd = nd
+        self.graphs = {}
+        eng.enable_epoch_stats()
+
+    def run(self, order, q):
+        eng, B = self.eng, self.batch
+        n = len(order)
+        nsteps = (n + B - 1) // B
+        for s in range(nsteps):
+            ids, whole = self.nd.shard_minibatch(order, s, B, self.rank, self.world)
+            n_pts = float(eng.counts[whole].sum())
+            if self.use_graph and len(whole) == B and len(ids) > 0:
+                key = (len(ids), q)
+                g = self.graphs.get(key)
+                if g is None:
+                    g = self.graphs[key] = GraphedTrainStep(eng, len(ids), q)
+                g(ids, n_pts=n_pts)
+            else:
+                eng.train_step(ids, q, n_pts=n_pts)
+        return nsteps

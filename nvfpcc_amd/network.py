@@ -52,11 +52,13 @@ def _advance(n):
 # ---------------------------------------------------------------------------------------------
 class NoiseState:
     seed = 0
-    step = 0
+    step = 0          # weight noise: advances on every q == 1 decoder forward (network.py:612,678 draw per call)
+    latent_step = 0   # latent rate-proxy noise: advances on every mode='train' forward, whatever q (network.py:4516)
 
 
-def set_noise_seed(seed, step=0):
+def set_noise_seed(seed, step=0, latent_step=None):
     NoiseState.seed, NoiseState.step = int(seed), int(step)
+    NoiseState.latent_step = int(step if latent_step is None else latent_step)
 
 
 def get_kaiming_init_from_seed(w, seed):
@@ -178,7 +180,10 @@ class QuantGaussianLikelihood(nn.Module):
     def forward(self, x, mode='train', u=None, block_ids=None):
         if mode not in ('train', 'eval'):
             raise ValueError(mode)
-        return NF.LatentRate.apply(x, self.sigma, self.mu, mode, u, block_ids, NoiseState.seed, NoiseState.step)
+        if mode == 'train':
+            NoiseState.latent_step += 1
+        return NF.LatentRate.apply(x, self.sigma, self.mu, mode, u, block_ids, NoiseState.seed,
+                                   NoiseState.latent_step)
 
     def get_bits(self):
         return int(np.prod(self.sigma.shape) * 32 + np.prod(self.mu.shape) * 32)

@@ -52,6 +52,38 @@ def _f32(*tensors):
             raise RuntimeError(f"expected float32, got {t.dtype}")
 
 
+class StepCtx:
+    """Caller-owned NvfStepCtx (include/nvf_hip.h): the queue of deferred final passes and the queued latent tail of ONE
+    step in flight.  The library keeps no state of its own; each engine owns one of these."""
+
+    def __init__(self):
+        import ctypes
+        self._mem = ctypes.create_string_buffer(int(lib().nvf_step_ctx_bytes()) + 16)
+        addr = ctypes.addressof(self._mem)
+        self.ptr = (addr + 15) // 16 * 16
+        check(lib().nvf_step_ctx_init(self.ptr), "nvf_step_ctx_init")
+
+    def begin(self):
+        """Queue the final passes of focal_loss_multi / heads3_loss_bwd_data / WgradBatch.finish_with_sums /
+        weight_rate_batch / metrics issued with this context (their outputs exist only after flush())."""
+        check(lib().nvf_finals_begin(self.ptr), "nvf_finals_begin")
+
+    def flush(self):
+        """Run the queued final passes in one launch on the current stream."""
+        check(lib().nvf_finals_flush(self.ptr, _stream()), "nvf_finals_flush")
+
+    def cancel(self):
+        lib().nvf_finals_cancel(self.ptr)
+        lib().nvf_latent_tail_cancel(self.ptr)
+
+    def tail_pending(self):
+        return bool(lib().nvf_latent_tail_pending(self.ptr))
+
+
+def _ctx(ctx):
+    return None if ctx is None else ctx.ptr
+
+
 _ws_cache = {}
 
 
@@ -289,7 +321,8 @@ def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=
     return da0, dx0
 
 
-def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, wg):
+def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, wg,
+                     ctx=None):
     """stem_bwd whose final launch is shared: up0's weight-gradient slabs become a job of the WgradBatch ``wg``
     (dw_up0 exists after wg.finish*), the IGDN parameter gradients a deferred final pass.  Returns (da0, dx0)."""
     import ctypes
@@ -302,7 +335,7 @@ def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, db
     check(lib().nvf_stem_bwd_partial(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
                                      _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
                                      ctypes.byref(slabs), ctypes.byref(nsl), _ptr(ws), ws.numel(), B, ch, 8, 16,
-                                     _stream()), "nvf_stem_bwd_partial")
+                                     _ctx(ctx), _stream()), "nvf_stem_bwd_partial")
     wg.jobs.append((slabs.value, dw_up0.data_ptr(), nsl.value, dw_up0.numel()))
     return da0, dx0
 
@@ -351,7 +384,7 @@ def heads3_bwd_data(dls, w_bwds, cs, masks):
     return dxs
 
 
-def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs, masks):
+def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs, masks, ctx=None):
     """focal_loss_multi (gradients w.r.t. the logits) + heads3_bwd_data in one launch: returns (dls, dxs);
     loss[slots[h]] = focal term of head h (after finals_flush when the final passes are deferred).  batch <= 32."""
     import ctypes
@@ -363,8 +396,8 @@ def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs,
     check(lib().nvf_heads3_loss_bwd_data(_parr(ps), _parr(gts), _parr(dists), (ctypes.c_float * 3)(*alphas),
                                          (ctypes.c_float * 3)(*betas), _iarr(slots), _ptr(loss), _parr(dls),
                                          _parr(w_bwds), _parr(dxs), _parr(masks), _iarr(cs),
-                                         _iarr([p.shape[-1] for p in ps]), B, _ptr(ws), ws.numel(), _stream()),
-          "nvf_heads3_loss_bwd_data")
+                                         _iarr([p.shape[-1] for p in ps]), B, _ptr(ws), ws.numel(), _ctx(ctx),
+                                         _stream()), "nvf_heads3_loss_bwd_data")
     return dls, dxs
 
 
@@ -372,8 +405,9 @@ class WgradBatch:
     """Weight gradients of one backward pass with a single reduction launch: ``add`` launches only the partial
     sums (each gradient keeps its own slab region until ``finish``), ``finish`` adds all slabs in one kernel."""
 
-    def __init__(self, device, nbytes=128 << 20):
+    def __init__(self, device, nbytes=128 << 20, ctx=None):
         self.device, self.jobs, self.offset = device, [], 0
+        self.ctx = ctx          # StepCtx: a queued latent tail rides in add_mfma3 / add_trunk5 / finish_with_sums
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self._retired = []      # outgrown buffers stay alive: kernels on another stream may still read them
 
@@ -413,8 +447,8 @@ class WgradBatch:
             bases.append(self.ws.data_ptr() + self.offset)
             self.offset += sz
         nsl = (ctypes.c_int * 3)()
-        check(lib().nvf_wgrad_mfma3_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 3)(*bases), B, nsl, _stream()),
-              "nvf_wgrad_mfma3_partial")
+        check(lib().nvf_wgrad_mfma3_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 3)(*bases), B, nsl, _ctx(self.ctx),
+                                            _stream()), "nvf_wgrad_mfma3_partial")
         for h in range(3):
             self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
 
@@ -459,8 +493,8 @@ class WgradBatch:
             bases.append(self.ws.data_ptr() + self.offset)
             self.offset += sz
         nsl = (ctypes.c_int * 5)()
-        check(lib().nvf_wgrad_trunk5_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases), B, nsl, _stream()),
-              "nvf_wgrad_trunk5_partial")
+        check(lib().nvf_wgrad_trunk5_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases), B, nsl,
+                                             _ctx(self.ctx), _stream()), "nvf_wgrad_trunk5_partial")
         for h in range(5):
             self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
 
@@ -494,7 +528,7 @@ class WgradBatch:
         if not jobs or len(jobs) > 16 or not tensors:
             self.finish()
             if tensors:
-                multi_channel_sum(tensors, outs)
+                multi_channel_sum(tensors, outs, ctx=self.ctx)
             return
         self.jobs, self.offset = [], 0
         _f32(*tensors)
@@ -506,7 +540,8 @@ class WgradBatch:
             (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
             (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n,
             _parr(tensors), _parr(outs), _iarr([t.shape[1] for t in tensors]), _iarr([t[0, 0].numel() for t in tensors]),
-            nt, tensors[0].shape[0], _ptr(ws), ws.numel(), _stream()), "nvf_wgrad_reduce_multi_and_sums")
+            nt, tensors[0].shape[0], _ptr(ws), ws.numel(), _ctx(self.ctx), _stream()),
+            "nvf_wgrad_reduce_multi_and_sums")
 
     def finish(self):
         import ctypes
@@ -532,7 +567,7 @@ def channel_sum(x, out=None, accumulate=False):
     return o
 
 
-def multi_channel_sum(tensors, outs):
+def multi_channel_sum(tensors, outs, ctx=None):
     """outs[i][c] = sum over batch and space of tensors[i][:, c]; all tensors share the batch size."""
     import ctypes
     _f32(*tensors)
@@ -545,7 +580,8 @@ def multi_channel_sum(tensors, outs):
     sp = (ctypes.c_int * n)(*[t[0, 0].numel() for t in tensors])
     total = sum(t.shape[1] for t in tensors)
     ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum")
-    check(lib().nvf_multi_channel_sum(xs, os_, cs, sp, n, B, _ptr(ws), ws.numel(), _stream()), "nvf_multi_channel_sum")
+    check(lib().nvf_multi_channel_sum(xs, os_, cs, sp, n, B, _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
+          "nvf_multi_channel_sum")
 
 
 # ---------------------------------------------------------------- GDN
@@ -614,38 +650,23 @@ def weight_rate(kernel, sigma, mu, bits_out=None, dk=None, dsigma=None, dmu=None
     return bits
 
 
-def latent_tail_queue(lat, sigma, mu, mode, block_ids, dx_addend, dlat, dsigma, dmu, g_dev, g_host, seed, step, step_dev,
-                      h, beta_hat, gamma_hat, dh, dbeta_hat, dgamma_hat, e, dw, db):
+def latent_tail_queue(ctx, lat, sigma, mu, mode, block_ids, dx_addend, dlat, dsigma, dmu, g_dev, g_host, seed, step,
+                      step_dev, h, beta_hat, gamma_hat, dh, dbeta_hat, dgamma_hat, e, dw, db):
     """latent_rate (gradient) -> gdn_bwd -> 1x1x1 weight / bias gradient as one workgroup of the next
-    WgradBatch.finish_with_sums launch on this stream (see include/nvf_hip.h).  Outputs are written in place; the
-    caller keeps every tensor alive until that launch has been enqueued."""
+    WgradBatch.add_trunk5 / add_mfma3 / finish_with_sums launch of a WgradBatch that holds the same StepCtx (see
+    include/nvf_hip.h).  Outputs are written in place; the caller keeps every tensor alive until that launch has
+    been enqueued."""
     _f32(lat, sigma, mu, dx_addend, dlat, dsigma, dmu, g_dev, h, beta_hat, gamma_hat, dh, dbeta_hat, dgamma_hat, e, dw, db)
     _chk(block_ids)
     B, c = lat.shape[0], lat.shape[1]
-    check(lib().nvf_latent_tail_queue(_ptr(lat), _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(dx_addend), _ptr(dlat),
+    check(lib().nvf_latent_tail_queue(ctx.ptr, _ptr(lat), _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(dx_addend), _ptr(dlat),
                                       _ptr(dsigma), _ptr(dmu), _ptr(g_dev), float(g_host),
                                       0 if mode == "train" else 1, int(seed), int(step), _ptr(step_dev), _ptr(h),
                                       _ptr(beta_hat), _ptr(gamma_hat), _ptr(dh), _ptr(dbeta_hat), _ptr(dgamma_hat),
                                       _ptr(e), _ptr(dw), _ptr(db), B, c, lat[0, 0].numel()), "nvf_latent_tail_queue")
 
 
-def finals_begin():
-    """Queue the final passes of focal_loss_multi / WgradBatch.finish_with_sums / weight_rate_batch (their outputs
-    exist only after finals_flush); see include/nvf_hip.h."""
-    lib().nvf_finals_begin()
-
-
-def finals_cancel():
-    lib().nvf_finals_cancel()
-    lib().nvf_latent_tail_cancel()
-
-
-def finals_flush():
-    """Run the queued final passes in one launch on the current stream."""
-    check(lib().nvf_finals_flush(_stream()), "nvf_finals_flush")
-
-
-def weight_rate_batch(kernels, dks, sigma, mu, bits, dsigma=None, dmu=None, g_dev=None, g_host=1.0):
+def weight_rate_batch(kernels, dks, sigma, mu, bits, dsigma=None, dmu=None, g_dev=None, g_host=1.0, ctx=None):
     """bits[l] for every kernel; dks[l] (or None) += g dbits/dk; dsigma/dmu overwritten with the layer sum."""
     import ctypes
     _f32(*kernels)
@@ -655,7 +676,7 @@ def weight_rate_batch(kernels, dks, sigma, mu, bits, dsigma=None, dmu=None, g_de
     ns = (ctypes.c_int * n)(*[k.numel() for k in kernels])
     ws = workspace(lib().nvf_weight_rate_batch_workspace(), kernels[0].device, "wrate")
     check(lib().nvf_weight_rate_batch(ks, ds, ns, n, _ptr(sigma), _ptr(mu), _ptr(bits), _ptr(dsigma), _ptr(dmu),
-                                      _ptr(g_dev), float(g_host), _ptr(ws), ws.numel(), _stream()),
+                                      _ptr(g_dev), float(g_host), _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
           "nvf_weight_rate_batch")
     return bits
 
@@ -673,7 +694,7 @@ def focal_loss(p, gt, dist, alpha, beta=0.0, want_grad=False, g_dev=None, g_host
     return loss, dp
 
 
-def focal_loss_multi(terms, loss_out, chain_sigmoid=True):
+def focal_loss_multi(terms, loss_out, chain_sigmoid=True, ctx=None):
     """terms: list of (p, gt, dist-or-None, alpha, beta); returns the list of gradients w.r.t. p (or the logits)."""
     import ctypes
     n = len(terms)
@@ -688,16 +709,19 @@ def focal_loss_multi(terms, loss_out, chain_sigmoid=True):
     ws = workspace(lib().nvf_reduce_workspace(), terms[0][0].device, "reduce")
     check(lib().nvf_focal_loss_multi(arr([t[0] for t in terms]), arr([t[1] for t in terms]),
                                      arr([t[2] for t in terms]), arr(dps), al, be, ns, n, _ptr(loss_out),
-                                     int(chain_sigmoid), _ptr(ws), ws.numel(), _stream()), "nvf_focal_loss_multi")
+                                     int(chain_sigmoid), _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
+          "nvf_focal_loss_multi")
     return dps
 
 
-def metrics(p, gt, dist, thh_acc, thh_sse, out=None, accumulate=False):
+def metrics(p, gt, dist, thh_acc, thh_sse, out=None, accumulate=False, ctx=None):
+    """out[0..5] (+)= tp, ap, tn, an at thh_acc; sse, denom at thh_sse (utils/loss.py:74-84, 113-121).  With ``ctx``
+    (an open StepCtx.begin) the final pass joins the deferred ones: ``out`` exists after ctx.flush()."""
     _f32(p, gt, dist, out)
     o = out if out is not None else torch.empty(6, device=p.device)
-    ws = workspace(lib().nvf_reduce_workspace(), p.device, "reduce")
+    ws = workspace(lib().nvf_reduce_workspace(), p.device, "metrics")   # its own buffer: the partials may wait for a flush
     check(lib().nvf_metrics(_ptr(p), _ptr(gt), _ptr(dist), float(thh_acc), float(thh_sse), _ptr(o), _ptr(ws),
-                            ws.numel(), p.numel(), int(accumulate), _stream()), "nvf_metrics")
+                            ws.numel(), p.numel(), int(accumulate), _ctx(ctx), _stream()), "nvf_metrics")
     return o
 
 
@@ -738,6 +762,25 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     _f32(p, g, m, v)
     check(lib().nvf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
                               float(eps), int(step), _stream()), "nvf_adam_step")
+
+
+def adam_coefficients(lr, step, beta1=0.9, beta2=0.999):
+    """The two floats [lr / (1 - beta1^t), sqrt(1 - beta2^t)] step_tail reads from device memory."""
+    import ctypes
+    c = (ctypes.c_float * 2)()
+    check(lib().nvf_adam_coefficients(float(lr), float(beta1), float(beta2), int(step), c), "nvf_adam_coefficients")
+    return float(c[0]), float(c[1])
+
+
+def step_tail(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, lbits=None, nbits=None, g_lat_dev=None, lbits_scale=1.0,
+              nbits_scale=1.0, acc=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam with its two step-dependent scalars in device memory (graph-capturable) + the epoch's running sums and
+    non-finite counters in ``acc`` [8] (see nvf_step_tail in include/nvf_hip.h)."""
+    _f32(p, g, m, v, coef_dev, loss_terms, lbits, nbits, g_lat_dev, acc)
+    check(lib().nvf_step_tail(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(coef_dev), float(coef_host[0]),
+                              float(coef_host[1]), float(beta1), float(beta2), float(eps), _ptr(loss_terms), _ptr(lbits), _ptr(nbits),
+                              0 if nbits is None else nbits.numel(), _ptr(g_lat_dev), float(lbits_scale),
+                              float(nbits_scale), _ptr(acc), _stream()), "nvf_step_tail")
 
 
 def gather_rows(src, idx):

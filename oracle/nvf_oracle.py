@@ -334,6 +334,12 @@ def sse1(p, dist, thh):
     return torch.square(pred * dist).sum(), pred.sum()
 
 
+def squared_error_map(p, dist, thh):
+    """get_se (loss.py:123-128) -> [B,2,...]: ((p>thh)*dist)^2 stacked with p along the channel axis."""
+    pred = (p > thh).float()
+    return torch.cat([torch.square(pred * dist), p], 1)
+
+
 def rd_loss(P, emb, gt, dist, n_points_total, lmbda, w1, w2, mode, q,
             u_latent=None, u_w=None, focal_alpha=0.9):
     """The training objective (NVFPCC.py:154-196)."""

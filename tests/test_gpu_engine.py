@@ -100,7 +100,8 @@ def test_decoder_update_matches_torch_adam(gpu):
     for i in range(3):
         eng.train_step([i, i + 1], 2, update=False)
         p_ref.grad = eng.flat_g.clone()
-        # re-run the same step with the update enabled: identical gradient, then fused Adam
+        # re-run the same step (same noise draw) with the update enabled: identical gradient, then fused Adam
+        eng.noise_step -= 1
         eng.train_step([i, i + 1], 2, update=True)
         opt.step()
         assert torch.allclose(eng.flat_p, p_ref.detach(), rtol=2e-5, atol=1e-6)
@@ -120,6 +121,7 @@ def test_two_rank_sharding_sums_to_the_single_rank_gradient(gpu):
     eng.rate_grad_scale = 0.5
     parts = []
     for r in range(2):
+        eng.noise_step = 0               # every rank is at the same step: same per-block latent noise
         eng.train_step(whole[r::2], 2, update=False, n_pts=n_pts)
         parts.append(eng.flat_g.clone())
     eng.rate_grad_scale = 1.0
@@ -184,6 +186,7 @@ def test_full_size_step_is_the_sum_of_its_mini_batches(gpu):
     eng.rate_grad_scale = 1.0 / 16
     acc = torch.zeros_like(g_all, dtype=torch.float64)
     for r in range(16):
+        eng.noise_step = 0               # the same draw as the 256-block step (noise is keyed by block id and step)
         eng.train_step(whole[16 * r:16 * (r + 1)], 2, update=False, n_pts=n_pts)
         acc += eng.flat_g.double()
     eng.rate_grad_scale = 1.0
@@ -203,6 +206,33 @@ def test_weight_noise_and_latent_noise_are_reproducible(gpu):
     assert not torch.equal(eng.flat_g, g1)
 
 
+def test_latent_noise_is_redrawn_every_step_after_the_phase_change(gpu):
+    """q = 2 (epochs >= --phase_change, 80 % of training): the reference still draws torch.rand_like(x) on every
+    mode='train' forward (network.py:4516), so consecutive steps -- host-launched, latent, and graph-replayed -- see
+    different latent noise; the same counter value reproduces the same draw."""
+    from nvfpcc_amd.engine import GraphedTrainStep
+    net, eng, gt, dist, emb = make("S", gpu, nblk=16)
+    ids = list(range(16))
+    a = eng.train_step(ids, 2, update=False)
+    b1, g1, s1 = a["lbits"].clone(), eng.flat_g.clone(), eng.noise_step
+    a = eng.train_step(ids, 2, update=False)
+    assert eng.noise_step == s1 + 1 and not torch.equal(a["lbits"], b1) and not torch.equal(eng.flat_g, g1)
+    eng.noise_step = s1 - 1
+    a = eng.train_step(ids, 2, update=False)
+    assert torch.equal(a["lbits"], b1) and torch.equal(eng.flat_g, g1)
+    _, de1 = eng.latent_step(2, update=False)
+    _, de2 = eng.latent_step(2, update=False)
+    assert not torch.equal(de1, de2)
+    graphed = GraphedTrainStep(eng, 16, 2)
+    eng.noise_step = s1 - 1
+    out = graphed(ids)
+    torch.cuda.synchronize()
+    assert torch.equal(out["lbits"], b1)
+    out = graphed(ids)
+    torch.cuda.synchronize()
+    assert not torch.equal(out["lbits"], b1)
+
+
 def test_fused_stem_equals_the_per_layer_kernels(gpu):
     """Forward bit-identical (same accumulation order); gradients to rounding."""
     net, eng, gt, dist, emb = make("S", gpu)
@@ -211,6 +241,7 @@ def test_fused_stem_equals_the_per_layer_kernels(gpu):
     a = eng.train_step(idx, 2, update=False)
     g_fused, y1, h0 = eng.flat_g.clone(), a["y1"].clone(), a["h0"].clone()
     eng.fused_stem = False
+    eng.noise_step = 0
     a = eng.train_step(idx, 2, update=False)
     assert torch.equal(a["y1"], y1) and torch.equal(a["h0"], h0)
     for name, (off, n) in eng.slices.items():
@@ -218,6 +249,7 @@ def test_fused_stem_equals_the_per_layer_kernels(gpu):
     eng.fused_stem = True
     _, de = eng.latent_step(2, update=False)
     eng.fused_stem = False
+    eng.noise_step -= 1
     _, de2 = eng.latent_step(2, update=False)
     close(de, de2, tol=1e-5)
 
@@ -266,3 +298,204 @@ def test_one_launch_step_head_equals_the_three_launches(tag, gpu):
         assert len(ref) > 0 and all(torch.equal(a, b) for a, b in zip(bufs(), ref)), (tag, q)
         assert all(torch.equal(a, b) for a, b in zip(rows, rows_ref))
         assert not any(torch.isnan(t).any().item() for t in bufs())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the engine against the reference's own vectors, directly (not through the autograd operator path)
+# ----------------------------------------------------------------------------------------------------------------
+def _golden_engine(tag, gpu, golden_dir):
+    import os
+    from nvfpcc_amd import network
+    from nvfpcc_amd.engine import TrainEngine
+    from nvfpcc_amd.model import Net
+    from tests.golden_inputs import HYPER
+    cfg = CONFIGS[tag]
+    G = np.load(os.path.join(golden_dir, f"net_{tag}.npz"))
+    network.reset_seed(synthetic_seed())
+    net = Net(None, "Gaussian", cfg["ch"], ",".join(str(c) for c in cfg["channels"]), verbose=False)
+    sd = net.state_dict()
+    perturb_state_(sd, cfg["param_seed"])
+    net.load_state_dict(sd)
+    net = net.to(gpu)
+    gts, dists = make_blocks(cfg["batch"])
+    eng = TrainEngine(net, torch.from_numpy(gts).float().to(gpu), torch.from_numpy(dists).float().to(gpu),
+                      n_points_total=HYPER["n_points"], emb=make_emb(cfg["batch"], cfg["ch"], cfg["emb_seed"]), seed=0,
+                      **H)
+    return cfg, G, eng
+
+
+@pytest.mark.parametrize("tag", ["S", "W"])
+def test_engine_flat_gradients_equal_the_reference_goldens(tag, gpu, golden_dir):
+    """All 28 slices of the engine's flat gradient buffer and the latent gradient against grad_q2/* of
+    tests/golden/net_{S,W}.npz -- produced by the real reference's autograd (tools/gen_golden.py, mode='eval', q=2,
+    NVFPCC.py:196's objective).  Tolerance as tests/test_gpu_net.py: 2e-4 of each tensor's largest entry."""
+    from tests.golden_inputs import sample_index
+    cfg, G, eng = _golden_engine(tag, gpu, golden_dir)
+    ids = torch.arange(cfg["batch"], device=gpu)
+    n_pts = float(eng.counts.sum())
+    gt, dist, gt16, gt8, e = eng.batch_and_prepare(ids, 2)
+    a = eng.forward(e, "eval", ids)
+    de = eng.backward(a, gt, dist, gt16, gt8, n_pts, "eval", ids, want_w=True, want_emb=True)
+    torch.cuda.synchronize()
+    ref_loss = float(G["grad_q2/loss"])
+    assert abs(eng.loss_value() - ref_loss) < 2e-5 * abs(ref_loss)
+
+    def grad_close(mine, ref, what):
+        mine, ref = np.asarray(mine, np.float64), np.asarray(ref, np.float64)
+        err = np.abs(mine - ref).max() / max(np.abs(ref).max(), 1e-9)
+        assert err < 2e-4, (what, err)
+
+    grad_close(de.cpu().numpy(), G["grad_q2/emb"], "emb")
+    assert len(eng.slices) == 28
+    for name, (off, n) in eng.slices.items():
+        ref = G["grad_q2/" + name]
+        mine = eng.flat_g[off:off + n].double().cpu()
+        if tag == "S":
+            grad_close(mine.numpy(), ref.reshape(-1), name)
+        else:           # W stores (mean, abs-sum, 256 sampled entries) per tensor
+            grad_close(mine[sample_index(n, 256)].numpy(), ref[2:], name)
+
+
+def test_step_tail_is_torch_adam_and_keeps_the_epoch_sums(gpu):
+    """nvf_step_tail: Adam with device-resident coefficients == nvf_adam_step == torch.optim.Adam; the epoch
+    accumulators (NVFPCC.py:190-221's sums without per-step syncs) and the non-finite counters behind the NaN guards
+    (NVFPCC.py:199-212)."""
+    from nvfpcc_amd import ops
+    g_ = torch.Generator().manual_seed(3)
+    n = 5000
+    p0 = torch.randn(n, generator=g_).to(gpu)
+    p_a, p_b = p0.clone(), p0.clone()
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=2e-3)
+    m_a, v_a, m_b, v_b = (torch.zeros(n, device=gpu) for _ in range(4))
+    acc = torch.zeros(8, device=gpu)
+    coef = torch.zeros(2, device=gpu)
+    sums = np.zeros(5)
+    for t in range(1, 5):
+        g = torch.randn(n, generator=g_).to(gpu)
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p_a, g, m_a, v_a, 2e-3, t)
+        c = ops.adam_coefficients(2e-3, t)
+        coef.copy_(torch.tensor(c))
+        loss = torch.rand(4, generator=g_).to(gpu)
+        lbits, nbits = torch.rand(1, generator=g_).to(gpu) * 100, torch.rand(7, generator=g_).to(gpu) * 50
+        glat = torch.tensor([0.25], device=gpu)
+        ops.step_tail(p_b, g, m_b, v_b, coef, loss_terms=loss, lbits=lbits, nbits=nbits, g_lat_dev=glat,
+                      lbits_scale=0.5, nbits_scale=0.01, acc=acc)
+        sums[:3] += loss[:3].double().cpu().numpy()
+        sums[3] += lbits.item() * 0.25 * 0.5
+        sums[4] += nbits.double().sum().item() * 0.01
+        assert torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)
+        assert torch.allclose(p_b, p_ref.detach(), rtol=1e-5, atol=1e-6)
+    got = acc.double().cpu().numpy()
+    np.testing.assert_allclose(got[:5], sums, rtol=1e-5)
+    assert got[5] == 0 and got[6] == 0 and got[7] == 4
+    # host-side coefficients give the same update; non-finite gradients / terms are counted, not ignored
+    g = torch.randn(n, generator=g_).to(gpu)
+    g[7], g[4000] = float("nan"), float("inf")
+    bad_loss = torch.tensor([1.0, float("nan"), 2.0, 0.0], device=gpu)
+    ops.step_tail(p_b.clone(), g, m_b.clone(), v_b.clone(), None, ops.adam_coefficients(2e-3, 5), loss_terms=bad_loss,
+                  lbits=torch.ones(1, device=gpu), nbits=torch.ones(7, device=gpu), acc=acc)
+    got = acc.double().cpu().numpy()
+    assert got[5] == 1 and got[6] == 2 and got[7] == 5
+
+
+def test_epoch_driver_graph_and_host_paths_agree_and_nan_guard_raises(gpu):
+    """NVFPCC.py train's epoch (engine.EpochDriver): full mini-batches replayed from the captured graph + the short
+    last batch from the host == every mini-batch launched from the host, bit for bit (parameters, latent table after
+    the latent step, and the epoch's log sums); the NaN guards of NVFPCC.py:199-212 raise from the device counters."""
+    from nvfpcc_amd.engine import EpochDriver
+    results = []
+    for use_graph in (True, False):
+        net, eng, gt, dist, emb = make("S", gpu, nblk=21)
+        drv = EpochDriver(eng, 8, use_graph=use_graph)
+        rng = np.random.default_rng(4)
+        stats = []
+        for epoch, q in enumerate((1, 1, 2)):
+            n = drv.run(rng.permutation(21), q)
+            assert n == 3
+            eng.latent_step(q)
+            stats.append(np.concatenate(eng.read_epoch_stats()))
+        torch.cuda.synchronize()
+        assert (not use_graph) or sorted(drv.graphs) == [(8, 1), (8, 2)]
+        results.append((eng.flat_p.clone(), eng.emb.clone(), np.stack(stats), eng.opt_step, eng.noise_step))
+    (p_g, e_g, s_g, o_g, n_g), (p_h, e_h, s_h, o_h, n_h) = results
+    assert o_g == o_h == 9 and n_g == n_h == 12
+    assert torch.equal(p_g, p_h) and torch.equal(e_g, e_h)
+    np.testing.assert_array_equal(s_g[:, :6], s_h[:, :6])           # counts and sse: same kernels, same order
+    np.testing.assert_allclose(s_g[:, 6:], s_h[:, 6:], rtol=2e-6)   # b_latent: lbits * (g / (lambda w1)) vs lbits / n_pts
+    assert (s_g[:, 6 + 7] == 3).all() and (s_g[:, 1] + s_g[:, 3] == 21 * 32768).all()
+    # a poisoned parameter makes the loss and the gradients non-finite: the epoch read-back raises
+    net, eng, gt, dist, emb = make("S", gpu, nblk=8)
+    drv = EpochDriver(eng, 8, use_graph=True)
+    drv.run(np.arange(8), 2)
+    eng.read_epoch_stats()
+    eng.flat_p[eng.slices["reconstructor.conv2.b"][0]] = float("nan")
+    drv.run(np.arange(8), 2)
+    with pytest.raises(ValueError, match="Problem"):
+        eng.read_epoch_stats()
+
+
+def test_idle_rank_contributes_its_share_of_the_weight_rate_gradient(gpu):
+    """Short last mini-batch under data parallelism (917 mod 16 = 5 blocks on 8 GPUs: three ranks idle): the sum over
+    ALL W ranks -- active and idle -- of the per-rank gradients equals the single-GPU gradient, including the
+    replicated weight-rate term and d/d(sigma, mu) of the weight likelihood model (SURVEY.md 8(e) detail 2)."""
+    net, eng, gt, dist, emb = make("S", gpu, nblk=6)
+    whole = [4, 1]
+    n_pts = float(eng.counts[whole].sum())
+    eng.train_step(whole, 1, update=False, n_pts=n_pts)
+    g_all, step = eng.flat_g.clone(), eng.noise_step
+    W = 4
+    eng.rate_grad_scale = 1.0 / W
+    acc = torch.zeros_like(g_all, dtype=torch.float64)
+    for r in range(W):                         # ranks 0, 1 hold one block each, ranks 2, 3 nothing
+        eng.noise_step = step - 1
+        a = eng.train_step(whole[r::W], 1, update=False, n_pts=n_pts)
+        assert (a is None) == (r >= 2) and eng.noise_step == step
+        acc += eng.flat_g.double()
+    eng.rate_grad_scale = 1.0
+    for name, (off, n) in eng.slices.items():
+        close(acc[off:off + n], g_all[off:off + n], tol=1e-5)
+    off, n = eng.slices["reconstructor.likelihood_model.sigma"]
+    assert g_all[off].abs().item() > 0
+
+
+@pytest.mark.timeout(240)
+def test_4096_resident_blocks_latent_step_and_eval(gpu):
+    """BASELINE.json configs[2]: 4096 synthetic 32^3 blocks resident on one GPU.  Size-independent properties: the
+    latent gradient of the 4096-block step is the concatenation of sixteen 256-block shards (blocks are independent
+    given the decoder; same n_pts, same noise step), the eval forward is bit-identical to batch 1 on sampled blocks,
+    and the loss is finite."""
+    from nvfpcc_amd import network
+    from nvfpcc_amd.engine import TrainEngine
+    from nvfpcc_amd.model import Net
+    N = 4096
+    network.reset_seed(synthetic_seed())
+    net = Net(None, "Gaussian", 3, "8,16,8,8", verbose=False)
+    sd = net.state_dict()
+    perturb_state_(sd, CONFIGS["S"]["param_seed"])
+    net.load_state_dict(sd)
+    net = net.to(gpu)
+    gts, dists = make_blocks(64)
+    reps = N // 64
+    gt = torch.from_numpy(np.tile(gts, (reps, 1, 1, 1, 1))).float().to(gpu)
+    dist = torch.from_numpy(np.tile(dists, (reps, 1, 1, 1, 1))).float().to(gpu)
+    eng = TrainEngine(net, gt, dist, n_points_total=float(gt.sum().item()), emb=make_emb(N, 3, 7), seed=0, **H)
+    a, de = eng.latent_step(2, update=False)
+    loss_terms = eng.last["loss_terms"][:3].cpu().numpy()
+    lbits = a["lbits"].item()
+    assert np.isfinite(loss_terms).all() and np.isfinite(lbits) and torch.isfinite(de).all()
+    assert de.shape == (N, 3, 2, 2, 2) and de.abs().max().item() > 0
+    del a
+    step = eng.noise_step
+    for s in range(16):
+        eng.noise_step = step - 1
+        _, de_s = eng.latent_step(2, lo=256 * s, hi=256 * (s + 1), update=False)
+        close(de_s, de[256 * s:256 * (s + 1)], tol=2e-5)
+    ev = eng.eval_forward(q=2)
+    p_all = ev["p2"]
+    assert p_all.shape == (N, 1, 32, 32, 32) and torch.isfinite(p_all).all()
+    for b in (0, 255, 256, 2049, 4095):
+        one = eng.eval_forward(lo=b, hi=b + 1, q=2)["p2"]
+        assert torch.equal(one[0], p_all[b]), b

@@ -167,6 +167,9 @@ def test_losses_and_metrics(golden_dir):
         np.testing.assert_array_equal(np.array([tpr.item(), tnr.item()]), G[name + "/acc"])  # nan==nan ok
         sse, den = O.sse1(p.detach(), dist, 0.6)
         close([sse.item(), den.item()], G[name + "/sse1"], rtol=1e-6)
+        se = O.squared_error_map(p.detach(), dist, 0.6)            # get_se (loss.py:123-128), encode-side only
+        assert se.shape == (p.shape[0], 2) + tuple(p.shape[2:])
+        close(summary(se), G[name + "/se"], rtol=1e-6)
 
 
 def test_gdn_forward_backward(golden_dir):
@@ -191,6 +194,44 @@ def test_lr_schedule_quirk(golden_dir):
         close(O.lr_at_epoch(1e-3, int(epoch)), lr_dec, rtol=1e-9, atol=0)
         close(5e-3, lr_emb, rtol=1e-12, atol=0)
     assert table[-1, 1] < 1.1e-9  # 1e-3 * 0.01^3
+
+
+def test_cli_lr_schedule_is_the_reference_table(golden_dir):
+    """NVFPCC.lr_at_epoch (what the command line feeds the engine every epoch) against the table the reference's two
+    MultiStepLR objects produce (tools/gen_golden.py, NVFPCC.py:117,126,253-254): x0.01 per milestone."""
+    import NVFPCC
+    table = np.load(os.path.join(golden_dir, "schedule.npz"))["table"]
+    for epoch, lr_dec, _ in table:
+        close(NVFPCC.lr_at_epoch(1e-3, int(epoch)), lr_dec, rtol=1e-9, atol=0)
+    for e in (0, 1, 299, 300, 301, 399, 400, 449, 450, 500):
+        assert NVFPCC.lr_at_epoch(2e-4, e) == O.lr_at_epoch(2e-4, e)
+
+
+def test_quantised_checkpoint_has_the_reference_key_set():
+    """manipulate_weights.quantise keeps exactly the 28 keys of the reference's bypass_key_list + key_list
+    (manipulate_weights.py:19-32): the latent generator incl. its *_init buffers, the entropy coder, the IGDN, the seven
+    trunk layers' kernel + bias, the weight likelihood model -- and neither the two coarse heads nor the trunk's *_init
+    buffers (the decoder re-creates those from its seed file)."""
+    import manipulate_weights as MW
+    P, _ = O.build_state(3, (8, 16, 8, 8), synthetic_seed())
+    perturb_state_(P, 5)
+    qd, lo, hi = MW.quantise(P, 16)
+    trunk = ["up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls"]
+    expect = (["latent_gen.h_analysis_2." + s for s in ("kernel", "b", "kernel_init", "b_init")]
+              + ["latent_gen.gdn_2." + s for s in ("beta", "gamma", "pedestal")]
+              + ["entropy_coder.sigma", "entropy_coder.mu"]
+              + ["reconstructor.activation." + s for s in ("beta", "gamma", "pedestal")]
+              + [f"reconstructor.{n}.{s}" for n in trunk for s in ("kernel", "b")]
+              + ["reconstructor.likelihood_model.sigma", "reconstructor.likelihood_model.mu"])
+    assert len(expect) == 28 and sorted(qd) == sorted(expect)
+    assert type(qd) is dict                                   # a plain dict, as the reference saves it
+    for n in trunk:
+        k = f"reconstructor.{n}.kernel"
+        assert torch.equal(qd[k], torch.round(P[k] * 16) / 16)
+        assert torch.equal(qd[k] * 16, torch.round(qd[k] * 16))
+        assert torch.equal(qd[f"reconstructor.{n}.b"], P[f"reconstructor.{n}.b"])
+    assert lo == min(torch.round(P[f"reconstructor.{n}.kernel"] * 16).min().item() for n in trunk)
+    assert hi == max(torch.round(P[f"reconstructor.{n}.kernel"] * 16).max().item() for n in trunk)
 
 
 def test_adam_restatement_matches_torch():
