@@ -51,7 +51,8 @@ __device__ __forceinline__ float focal_elem(float pv, float gv, float dv, bool h
   const float at = occ ? a1 : a0;
   float w = 1.f;
   if (has_dist) w = dv + (occ ? beta : 0.f);
-  const float Fc = fmaxf(F, 1e-9f);
+  const float Fc = F < 1e-9f ? 1e-9f : F;   // torch.clamp(min=1e-9): same values as fmaxf, but a NaN stays a NaN
+                                            // (loss.py:68, 105; it is what NVFPCC.py:199's NaN check looks for)
   const float om = 1.f - Fc;
   const float lg = logf(Fc);
   float d = 0.f;

@@ -61,6 +61,7 @@ class StepCtx:
         self._mem = ctypes.create_string_buffer(int(lib().nvf_step_ctx_bytes()) + 16)
         addr = ctypes.addressof(self._mem)
         self.ptr = (addr + 15) // 16 * 16
+        self._ws = {}      # workspaces of the passes deferred in this context: their partial sums wait for flush()
         check(lib().nvf_step_ctx_init(self.ptr), "nvf_step_ctx_init")
 
     def begin(self):
@@ -87,13 +88,15 @@ def _ctx(ctx):
 _ws_cache = {}
 
 
-def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch buffer per (device, tag)."""
+def workspace(nbytes, device, tag="ws", ctx=None):
+    """Grow-only scratch buffer per (device, tag) -- per StepCtx when one is given: partial sums parked there until
+    the context's flush must not be overwritten by another engine's step."""
+    cache = _ws_cache if ctx is None else ctx._ws
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
-    buf = _ws_cache.get(key)
+    buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        cache[key] = buf
     return buf
 
 
@@ -330,7 +333,7 @@ def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, db
     B, ch = x0.shape[0], x0.shape[1]
     da0 = torch.empty_like(a0)
     dx0 = torch.empty_like(x0)
-    ws = workspace(lib().nvf_stem_bwd_workspace(B, ch), x0.device, "stem")
+    ws = workspace(lib().nvf_stem_bwd_workspace(B, ch), x0.device, "stem", ctx)
     slabs, nsl = ctypes.c_void_p(), ctypes.c_int()
     check(lib().nvf_stem_bwd_partial(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
                                      _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
@@ -392,7 +395,7 @@ def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs,
     B = ps[0].shape[0]
     dls = [torch.empty_like(p) for p in ps]
     dxs = [torch.empty((B, c) + tuple(p.shape[2:]), device=p.device) for p, c in zip(ps, cs)]
-    ws = workspace(lib().nvf_reduce_workspace(), ps[0].device, "reduce")
+    ws = workspace(lib().nvf_reduce_workspace(), ps[0].device, "reduce", ctx)
     check(lib().nvf_heads3_loss_bwd_data(_parr(ps), _parr(gts), _parr(dists), (ctypes.c_float * 3)(*alphas),
                                          (ctypes.c_float * 3)(*betas), _iarr(slots), _ptr(loss), _parr(dls),
                                          _parr(w_bwds), _parr(dxs), _parr(masks), _iarr(cs),
@@ -535,7 +538,7 @@ class WgradBatch:
         _f32(*outs)
         n, nt = len(jobs), len(tensors)
         total = sum(t.shape[1] for t in tensors)
-        ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum")
+        ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum", self.ctx)
         check(lib().nvf_wgrad_reduce_multi_and_sums(
             (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
             (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n,
@@ -579,7 +582,7 @@ def multi_channel_sum(tensors, outs, ctx=None):
     cs = (ctypes.c_int * n)(*[t.shape[1] for t in tensors])
     sp = (ctypes.c_int * n)(*[t[0, 0].numel() for t in tensors])
     total = sum(t.shape[1] for t in tensors)
-    ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum")
+    ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum", ctx)
     check(lib().nvf_multi_channel_sum(xs, os_, cs, sp, n, B, _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
           "nvf_multi_channel_sum")
 
@@ -674,7 +677,7 @@ def weight_rate_batch(kernels, dks, sigma, mu, bits, dsigma=None, dmu=None, g_de
     ks = (ctypes.c_void_p * n)(*[k.data_ptr() for k in kernels])
     ds = (ctypes.c_void_p * n)(*[(d.data_ptr() if d is not None else None) for d in dks]) if dks is not None else None
     ns = (ctypes.c_int * n)(*[k.numel() for k in kernels])
-    ws = workspace(lib().nvf_weight_rate_batch_workspace(), kernels[0].device, "wrate")
+    ws = workspace(lib().nvf_weight_rate_batch_workspace(), kernels[0].device, "wrate", ctx)
     check(lib().nvf_weight_rate_batch(ks, ds, ns, n, _ptr(sigma), _ptr(mu), _ptr(bits), _ptr(dsigma), _ptr(dmu),
                                       _ptr(g_dev), float(g_host), _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
           "nvf_weight_rate_batch")
@@ -706,7 +709,7 @@ def focal_loss_multi(terms, loss_out, chain_sigmoid=True, ctx=None):
     al = (ctypes.c_float * n)(*[float(t[3]) for t in terms])
     be = (ctypes.c_float * n)(*[float(t[4]) for t in terms])
     ns = (ctypes.c_int64 * n)(*[t[0].numel() for t in terms])
-    ws = workspace(lib().nvf_reduce_workspace(), terms[0][0].device, "reduce")
+    ws = workspace(lib().nvf_reduce_workspace(), terms[0][0].device, "reduce", ctx)
     check(lib().nvf_focal_loss_multi(arr([t[0] for t in terms]), arr([t[1] for t in terms]),
                                      arr([t[2] for t in terms]), arr(dps), al, be, ns, n, _ptr(loss_out),
                                      int(chain_sigmoid), _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
@@ -719,7 +722,7 @@ def metrics(p, gt, dist, thh_acc, thh_sse, out=None, accumulate=False, ctx=None)
     (an open StepCtx.begin) the final pass joins the deferred ones: ``out`` exists after ctx.flush()."""
     _f32(p, gt, dist, out)
     o = out if out is not None else torch.empty(6, device=p.device)
-    ws = workspace(lib().nvf_reduce_workspace(), p.device, "metrics")   # its own buffer: the partials may wait for a flush
+    ws = workspace(lib().nvf_reduce_workspace(), p.device, "metrics", ctx)   # its own buffer: partials may wait for a flush
     check(lib().nvf_metrics(_ptr(p), _ptr(gt), _ptr(dist), float(thh_acc), float(thh_sse), _ptr(o), _ptr(ws),
                             ws.numel(), p.numel(), int(accumulate), _ctx(ctx), _stream()), "nvf_metrics")
     return o

@@ -426,14 +426,23 @@ def test_epoch_driver_graph_and_host_paths_agree_and_nan_guard_raises(gpu):
     np.testing.assert_array_equal(s_g[:, :6], s_h[:, :6])           # counts and sse: same kernels, same order
     np.testing.assert_allclose(s_g[:, 6:], s_h[:, 6:], rtol=2e-6)   # b_latent: lbits * (g / (lambda w1)) vs lbits / n_pts
     assert (s_g[:, 6 + 7] == 3).all() and (s_g[:, 1] + s_g[:, 3] == 21 * 32768).all()
-    # a poisoned parameter makes the loss and the gradients non-finite: the epoch read-back raises
+    # a poisoned parameter (the main head's bias: logit, probability and focal term become NaN) trips the guard at the
+    # epoch read-back; a NaN gradient entry trips the other one
     net, eng, gt, dist, emb = make("S", gpu, nblk=8)
     drv = EpochDriver(eng, 8, use_graph=True)
     drv.run(np.arange(8), 2)
     eng.read_epoch_stats()
-    eng.flat_p[eng.slices["reconstructor.conv2.b"][0]] = float("nan")
+    keep = eng.flat_p.clone()
+    eng.flat_p[eng.slices["reconstructor.conv2_cls.b"][0]] = float("nan")
     drv.run(np.arange(8), 2)
-    with pytest.raises(ValueError, match="Problem"):
+    with pytest.raises(ValueError, match="Problem in loss"):
+        eng.read_epoch_stats()
+    eng.flat_p.copy_(keep)
+    eng.flat_m.zero_(); eng.flat_v.zero_()
+    eng.train_step(np.arange(8), 2, update=False)
+    eng.flat_g[100] = float("inf")
+    eng._tail(float(eng.counts.sum()))
+    with pytest.raises(ValueError, match="Problem with grad"):
         eng.read_epoch_stats()
 
 
