@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["step", "epoch"], default="step",
                     help="epoch: time whole NVFPCC.py-train epochs only (the default run reports both)")
     ap.add_argument("--epochs", type=int, default=10, help="epochs timed for the `epoch` object")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the epoch object (profiling runs: step kernels only)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each (value = the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic")
@@ -345,7 +346,7 @@ def run(args):
     # ---- whole epochs of NVFPCC.py train: mini-batches (graph replay + the short last batch from the host), the
     # full-batch latent step on this rank's shard, the device-side sums of the log line, eval on every 10th epoch
     epoch_obj = None
-    if world >= 1 and (args.mode == "epoch" or not args.no_graph):
+    if (args.mode == "epoch" or not args.no_graph) and not (args.no_epoch and args.mode == "step"):
         N = args.blocks
         drv = EpochDriver(eng, B * world, rank, world, use_graph=not args.no_graph)
         lo, hi = nd.shard_range(N, rank, world)

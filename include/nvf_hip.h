@@ -137,8 +137,23 @@ int nvf_pack_s2k5_mfma(const float* gather_w, int cig, int cog, float* wp, void*
 int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, const float* addend, const float* mask,
                          int batch, int cig, int cog, int din, int dout, int variant, void* stream);
 
+/* ---- matrix-core gather convolutions for 16 / 32 OUTPUT channels (the wide decoder, chanstr 16,32,16,16:
+ * F.conv3d network.py:687 forward and backward-data, and the backward-data of the stride-2 transposed convolutions
+ * network.py:621).  Rows of the MFMA tile are the output channels (no pairing), K = four input channels.  Same
+ * contract as nvf_conv3d_gather; the weights are A fragments of the packed gather weight:
+ *   nvf_pack_g16_mfma(gather_w [cin][k^3][cout] (= w_fwd, or w_bwd for a backward-data pass), cin, cout, k, wp),
+ *   nvf_pack_g16_mfma_floats(cin, cout, k) floats, layout [cout/16][cin/4][tap][lane].
+ * Fixed per-output accumulation order (channel group, kz, ky, kx): independent of batch and tiling.
+ * NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_conv3d_gather). */
+size_t nvf_pack_g16_mfma_floats(int cin, int cout, int k);
+int nvf_pack_g16_mfma(const float* gather_w, int cin, int cout, int k, float* wp, void* stream);
+int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float* bias, float* y, const float* addend,
+                        const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din, int hin,
+                        int win, int dout, int hout, int wout, int act, int variant, void* stream);
+
 /* every MFMA weight packing of a step in one launch (<= 8 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
- * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog) */
+ * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog),
+ * 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout) */
 int nvf_pack_mfma_all(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s, const int* c1s,
                       int n, void* stream);
 

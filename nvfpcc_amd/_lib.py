@@ -38,6 +38,9 @@ PROTOTYPES = {
     "nvf_pack_s2k5_mfma_floats": (Z, [I, I]),
     "nvf_pack_s2k5_mfma": (I, [P, I, I, P, P]),
     "nvf_conv3d_s2k5_mfma": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "nvf_pack_g16_mfma_floats": (Z, [I, I, I]),
+    "nvf_pack_g16_mfma": (I, [P, I, I, I, P, P]),
+    "nvf_conv3d_g16_mfma": (I, [P, P, P, P, P, P] + [I] * 14 + [P]),
     "nvf_pack_mfma_all": (I, [P, P, P, P, P, I, P]),
     "nvf_heads3_fwd": (I, [P, P, P, P, P, P, I, I, P]),
     "nvf_heads3_bwd_data": (I, [P, P, P, P, P, P, I, P]),

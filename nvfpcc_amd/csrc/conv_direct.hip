@@ -557,18 +557,39 @@ extern "C" int nvf_conv3d_gather(const float* x, const float* w, const float* bi
     // ---- wide decoder (chanstr 16,32,16,16)
     NVF_G(0, 16, 16, 4, 1, 33, 36, 4, 9, 7, 4, 2, 0)  // conv2 backward-data
     NVF_G(0, 16, 16, 4, 1, 21, 32, 4, 8, 8, 4, 2, 0)  // conv2 forward
-    NVF_G(0, 16, 16, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0) // conv1 backward-data
-    NVF_G(0, 16, 16, 4, 1, 9, 16, 4, 4, 16, 4, 2, 0)  // conv1 forward
+    // (tile shapes of the small wide layers: tools/wide_sweep.py, batch 16 -- the first choices left most CUs idle)
+    NVF_G(0, 16, 16, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0)  // conv1 backward-data (150 vs 158 us)
+    NVF_G(0, 16, 16, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0)   // conv1 forward (138 vs 155 us)
     NVF_G(0, 16, 1, 3, 1, 17, 32, 8, 4, 16, 4, 4, 0)  // conv2_cls forward
     NVF_G(0, 16, 1, 3, 1, 9, 16, 4, 4, 16, 4, 4, 0)   // conv1_cls forward
     NVF_G(0, 32, 1, 3, 1, 5, 8, 4, 2, 8, 8, 4, 0)     // conv0_cls forward
     NVF_G(0, 1, 16, 3, 1, 17, 32, 4, 8, 8, 4, 1, 0)   // conv2_cls backward-data
     NVF_G(0, 1, 16, 3, 1, 9, 16, 4, 4, 16, 4, 1, 0)   // conv1_cls backward-data
     NVF_G(0, 1, 32, 3, 1, 5, 8, 4, 2, 8, 8, 1, 0)     // conv0_cls backward-data
-    NVF_G(0, 16, 16, 5, 2, 9, 16, 4, 4, 16, 4, 1, 0)  // up2 backward-data
-    NVF_G(0, 16, 32, 5, 2, 5, 8, 2, 4, 8, 8, 2, 0)    // up1 backward-data
-    NVF_GC(0, 32, 16, 5, 2, 3, 4, 2, 2, 4, 4, 4, 0, 2) // conv0 backward-data
+    NVF_GC(0, 16, 16, 5, 2, 9, 16, 2, 8, 8, 2, 2, 0, 8) // up2 backward-data (233 vs 498 us)
+    NVF_GC(0, 16, 32, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 4)  // up1 backward-data (164 vs 376 us)
+    NVF_GC(0, 32, 16, 5, 2, 3, 4, 2, 2, 4, 2, 4, 0, 2)  // conv0 backward-data (136 vs 166 us)
     NVF_GC(0, 16, 8, 5, 2, 2, 2, 2, 1, 2, 2, 8, 0, 1) // up0 backward-data (ch = 8)
+    // wide-decoder tuning candidates (tools/wide_sweep.py)
+    NVF_GC(40, 16, 16, 5, 2, 9, 16, 2, 8, 8, 4, 2, 0, 8)
+    NVF_GC(41, 16, 16, 5, 2, 9, 16, 4, 4, 8, 4, 2, 0, 8)
+    NVF_GC(42, 16, 16, 5, 2, 9, 16, 2, 8, 8, 2, 2, 0, 8)
+    NVF_GC(43, 16, 16, 5, 2, 9, 16, 2, 8, 8, 4, 2, 0, 4)
+    NVF_GC(40, 16, 32, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 8)
+    NVF_GC(41, 16, 32, 5, 2, 5, 8, 2, 4, 8, 2, 2, 0, 8)
+    NVF_GC(42, 16, 32, 5, 2, 5, 8, 2, 4, 4, 4, 4, 0, 8)
+    NVF_GC(43, 16, 32, 5, 2, 5, 8, 2, 4, 8, 4, 2, 0, 4)
+    NVF_GC(40, 32, 16, 5, 2, 3, 4, 2, 2, 4, 4, 8, 0, 1)
+    NVF_GC(41, 32, 16, 5, 2, 3, 4, 2, 2, 4, 2, 4, 0, 2)
+    NVF_GC(42, 32, 16, 5, 2, 3, 4, 2, 2, 4, 4, 8, 0, 2)
+    NVF_GC(40, 16, 16, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 8)
+    NVF_GC(41, 16, 16, 4, 1, 9, 16, 4, 4, 16, 2, 2, 0, 8)
+    NVF_GC(42, 16, 16, 4, 1, 9, 16, 4, 4, 8, 2, 2, 0, 8)
+    NVF_GC(43, 16, 16, 4, 1, 9, 16, 4, 4, 8, 4, 2, 0, 0)
+    NVF_GC(40, 16, 16, 4, 1, 17, 20, 4, 5, 10, 5, 2, 0, 8)
+    NVF_GC(41, 16, 16, 4, 1, 17, 20, 4, 5, 10, 2, 2, 0, 8)
+    NVF_GC(42, 16, 16, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0, 8)
+    NVF_GC(43, 16, 16, 4, 1, 17, 20, 4, 5, 5, 5, 2, 0, 0)
 #undef NVF_G
 #undef NVF_GC
 #undef NVF_GD
@@ -773,9 +794,9 @@ extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float*
     NVF_T(0, 3, 8, 2, 2, 1, 2, 2, 2)      // up0 narrow (ch = 3): 2^3 -> 4^3 (2 cells / axis)
     NVF_T(0, 8, 16, 2, 2, 1, 2, 2, 4)     // up0 wide (ch = 8)
     NVF_T(0, 8, 16, 4, 2, 2, 4, 4, 2)     // conv0 narrow: 4^3 -> 8^3 (4 cells / axis), Cout split 8 ways
-    NVF_T(0, 16, 16, 16, 4, 5, 6, 6, 0)   // up2 wide
-    NVF_T(0, 32, 16, 8, 4, 3, 5, 5, 0)    // up1 wide
-    NVF_T(0, 16, 32, 4, 2, 2, 4, 4, 4)    // conv0 wide
+    NVF_T(0, 16, 16, 16, 2, 9, 6, 3, 8)   // up2 wide (182 vs 480 us at batch 16, tools/wide_sweep.py)
+    NVF_T(0, 32, 16, 8, 2, 5, 5, 2, 4)    // up1 wide (139 vs 643 us)
+    NVF_T(0, 16, 32, 4, 2, 2, 4, 4, 2)    // conv0 wide (55 vs 74 us)
     NVF_T(7, 16, 8, 8, 2, 5, 5, 2, 2)
     NVF_T(8, 16, 8, 8, 2, 5, 5, 1, 4)
     NVF_T(9, 16, 8, 8, 2, 5, 10, 1, 4)
@@ -794,6 +815,18 @@ extern "C" int nvf_convT3d_k5s2_fwd(const float* x, const float* w, const float*
     NVF_T(5, 16, 8, 8, 4, 3, 5, 5, 4)
     NVF_T(2, 8, 16, 4, 2, 2, 4, 4, 2)
     NVF_T(3, 8, 16, 4, 2, 2, 4, 4, 8)
+    // wide-decoder tuning candidates (tools/wide_sweep.py)
+    NVF_T(40, 32, 16, 8, 2, 5, 5, 5, 4)
+    NVF_T(41, 32, 16, 8, 2, 5, 5, 2, 4)
+    NVF_T(42, 32, 16, 8, 2, 5, 10, 1, 4)
+    NVF_T(43, 32, 16, 8, 2, 5, 5, 5, 8)
+    NVF_T(40, 16, 16, 16, 2, 9, 6, 3, 4)
+    NVF_T(41, 16, 16, 16, 2, 9, 6, 3, 8)
+    NVF_T(42, 16, 16, 16, 2, 9, 6, 6, 4)
+    NVF_T(43, 16, 16, 16, 2, 9, 3, 3, 8)
+    NVF_T(40, 16, 32, 4, 2, 2, 4, 2, 4)
+    NVF_T(41, 16, 32, 4, 2, 2, 4, 4, 2)
+    NVF_T(42, 16, 32, 4, 2, 2, 4, 4, 8)
 #undef NVF_T
   }
   if (rc == 1) {

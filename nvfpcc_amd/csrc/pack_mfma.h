@@ -39,6 +39,11 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       const int co = i >> 1, ex = i & 1, ci = 4 * g + k;
       const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
       if (kx < 5) v = src(job, (ci * 125 + (kz * 5 + ky) * 5 + kx) * 8 + co);
+    } else if (kind == 30 || kind == 31) {           // 16-row gather convolution (conv16_mfma.hip): [cog][g][tap][lane]
+      const int k3 = kind == 30 ? 64 : 125, cin = m.c0[job], cout = m.c1[job];
+      const int tap = r % k3; r /= k3;
+      const int g = r % (cin / 4), cg = r / (cin / 4);
+      v = src(job, ((4 * g + k) * k3 + tap) * cout + cg * 16 + i);
     } else {                                         // stride-2 gather (transposed conv backward-data)
       const int cog = m.c1[job], pair = cog == 8, KEX = pair ? 7 : 5;
       const int tx = r % KEX; r /= KEX;
@@ -53,7 +58,8 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
 }
 
 // kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
-// 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog).  Fills m (sources optional: the step head derives them).
+// 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout).
+// Fills m (sources optional: the step head derives them).
 static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
                                  const int* c1s, int n, PackJobs& m) {
   if (!dsts || !kinds || !c0s || !c1s || n <= 0 || n > 8) return NVF_EINVAL;
@@ -63,6 +69,8 @@ static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, c
     if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
     else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
     else if (kinds[j] == 20 && (c1s[j] == 8 || c1s[j] == 16)) m.total[j] = (c0s[j] / 4) * 25 * (c1s[j] == 8 ? 7 : 5) * 64;
+    else if ((kinds[j] == 30 || kinds[j] == 31) && c1s[j] > 0 && c1s[j] % 16 == 0)
+      m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * (kinds[j] == 30 ? 64 : 125) * 64;
     else return NVF_EINVAL;
   }
   m.n = n;

@@ -799,11 +799,20 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
     NVF_W(9, 8, 5, 2, 16, 4, 16, 4, 2, 0)
     NVF_W(0, 16, 5, 2, 8, 4, 8, 4, 2, 0)     // up1 narrow: p = X [16,8^3], q = dY [8,19^3]
     NVF_W(0, 8, 5, 2, 4, 4, 4, 4, 4, 0)      // conv0 narrow: p = X [8,4^3], q = dY [16,8^3]
-    NVF_W(0, 16, 4, 1, 32, 8, 32, 8, 2, 0)   // conv2 wide
+    NVF_W(0, 16, 4, 1, 32, 8, 32, 4, 2, 0)   // conv2 wide (415 vs 547 us at batch 16, tools/wide_sweep.py)
     NVF_W(0, 16, 4, 1, 16, 8, 16, 8, 2, 0)   // conv1 wide
-    NVF_W(0, 16, 5, 2, 16, 4, 16, 4, 2, 0)   // up2 wide
+    NVF_W(0, 16, 5, 2, 16, 2, 16, 4, 2, 0)   // up2 wide (134 vs 156 us)
     NVF_W(0, 32, 5, 2, 8, 4, 8, 4, 2, 0)     // up1 wide
     NVF_W(0, 16, 5, 2, 4, 4, 4, 4, 4, 0)     // conv0 wide
+    // wide-decoder tuning candidates (tools/wide_sweep.py)
+    NVF_W(40, 16, 4, 1, 32, 16, 32, 8, 2, 0)
+    NVF_W(41, 16, 4, 1, 32, 8, 32, 4, 2, 0)
+    NVF_W(42, 16, 4, 1, 32, 8, 32, 8, 4, 0)
+    NVF_W(43, 16, 4, 1, 32, 4, 32, 8, 2, 0)
+    NVF_W(40, 16, 5, 2, 16, 8, 16, 4, 2, 0)
+    NVF_W(41, 16, 5, 2, 16, 4, 16, 8, 2, 0)
+    NVF_W(42, 16, 5, 2, 16, 4, 16, 4, 4, 0)
+    NVF_W(43, 16, 5, 2, 16, 2, 16, 4, 2, 0)
     NVF_W(0, 8, 3, 1, 32, 1, 32, 8, 4, 0)    // conv2_cls: p = X [8,32^3], q = dlogit [1,32^3] (out_mode 1)
     NVF_W(0, 8, 3, 1, 16, 1, 16, 8, 4, 0)    // conv1_cls
     NVF_W(0, 16, 3, 1, 8, 1, 8, 8, 8, 0)     // conv0_cls narrow

@@ -26,6 +26,7 @@ from ._lib import lib, check
 from .network import NoiseState
 
 R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
+_G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wide decoder (0: the VALU tile kernels)
 
 
 def _NAIVE_OFF():
@@ -52,7 +53,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t", "wp_s", "bwd_pair", "bwd_max_batch")
+                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "bwd_pair", "bwd_max_batch")
 
 
 class TrainEngine:
@@ -149,7 +150,7 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = L.wp_t = L.wp_s = None
+            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = None
             L.bwd_pair, L.bwd_max_batch = 2, 0
             if L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
@@ -165,6 +166,13 @@ class TrainEngine:
                     # flattened 18-cell rows (conv2; faster than the VALU kernel only while the batch is small)
                     L.bwd_pair, L.bwd_max_batch = MFMA_BWD[name]
                     L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, L.bwd_pair)), device=self.dev)
+            # wide decoder (16 / 32 channels): the output channels are the MFMA rows (conv16_mfma.hip) -- conv1 / conv2
+            # forward and backward-data, and the backward-data of up2 / up1 (stride-2 gather with cin output channels)
+            if _G16 and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0 and name in ("conv1", "conv2"):
+                L.wp_gf = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
+                L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
+            if _G16 and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
+                L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
             self.layers[name] = L
             t = table[i]
             t["kernel"], t["kernel_init"] = m.kernel.data_ptr(), m.kernel_init.data_ptr()
@@ -185,6 +193,12 @@ class TrainEngine:
         meta += [(row[nm], 0) for nm, L in named if L.wp_t is not None]
         jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for _, L in named if L.wp_s is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_s is not None]
+        # 16-row gather forms: kind 30 (k = 4) / 31 (k = 5), c0 = input channels of the gather, c1 = its output channels
+        jobs += [(L.w_fwd, L.wp_gf, 30, L.cin, L.cout) for _, L in named if L.wp_gf is not None]
+        meta += [(row[nm], 0) for nm, L in named if L.wp_gf is not None]
+        jobs += [(L.w_bwd, L.wp_gb, 30 if L.k == 4 else 31, L.cout, L.cin) for _, L in named if L.wp_gb is not None]
+        meta += [(row[nm], 1) for nm, L in named if L.wp_gb is not None]
+        assert len(jobs) <= 8
         self._mfma_jobs = jobs
         self._mfma_job_layers = meta           # (layer-table row, 0 = w_fwd / 1 = w_bwd) of each job's source
         self._table_host = table
@@ -226,6 +240,9 @@ class TrainEngine:
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
     def _conv(self, L, x, act):
+        if L.wp_gf is not None:
+            osz = tuple(s - 3 for s in x.shape[2:])
+            return ops.conv3d_g16_mfma(x, L.wp_gf, L.b_eff, L.cout, 4, 1, 0, osz, act)
         if L.wp_f is not None:
             # conv1 at large batch: four planes per wave (variant 2: 124 vs 141 us at batch 256).  Every variant runs
             # the same per-output fmaf chain, so the bits -- and encode-at-any-batch == decode-at-batch-1 -- do not change
@@ -310,12 +327,18 @@ class TrainEngine:
         self._bias_jobs.append((g_out, L.gb))
 
     def _dx_conv(self, L, g_out, x_in, mask=None, addend=None):
+        if L.wp_gb is not None:
+            return ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 4, 1, 3, tuple(x_in.shape[2:]), addend=addend,
+                                       mask=mask)
         if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
             return ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, addend=addend, mask=mask)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
                                  addend=addend, mask=mask)
 
     def _dx_convT(self, L, g_out, x_in, mask=None, addend=None):
+        if L.wp_gb is not None:
+            return ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 5, 2, 0, tuple(x_in.shape[2:]), addend=addend,
+                                       mask=mask)
         if L.wp_s is not None:
             # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256)
             var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else None

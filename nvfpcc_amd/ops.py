@@ -274,6 +274,36 @@ def conv3d_s2k5_mfma(g, wp, cog, addend=None, mask=None, out=None, variant=None)
     return dx
 
 
+def pack_g16_mfma(gather_w, cin, cout, k, out=None):
+    """MFMA A-fragments of a packed gather weight [cin][k^3][cout] with cout a multiple of 16 (conv16_mfma.hip)."""
+    _f32(gather_w, out)
+    n = int(lib().nvf_pack_g16_mfma_floats(cin, cout, k))
+    wp = out if out is not None else torch.empty(n, device=gather_w.device)
+    if gather_w.numel() != cin * k ** 3 * cout or wp.numel() != n:
+        raise RuntimeError("pack_g16_mfma: weight size does not match (cin, k, cout)")
+    check(lib().nvf_pack_g16_mfma(_ptr(gather_w), cin, cout, k, _ptr(wp), _stream()), "nvf_pack_g16_mfma")
+    return wp
+
+
+def conv3d_g16_mfma(x, wp, bias, cout, k, stride, pad, out_spatial, act=ACT_NONE, addend=None, mask=None, out=None,
+                    variant=None):
+    """Matrix-core gather convolution with 16 / 32 output channels: same contract as conv3d_gather."""
+    _f32(x, wp, bias, addend, mask)
+    B, cin, di, hi, wi = x.shape
+    do, ho, wo = out_spatial
+    if wp.numel() != int(lib().nvf_pack_g16_mfma_floats(cin, cout, k)):
+        raise RuntimeError("packed weight size does not match (cin, k, cout)")
+    y = out if out is not None else torch.empty((B, cout, do, ho, wo), device=x.device)
+    for t in (addend, mask):
+        if t is not None and t.shape != y.shape:
+            raise RuntimeError("addend/mask shape must equal the output shape")
+    check(lib().nvf_conv3d_g16_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(addend), _ptr(mask), B, cin, cout, k,
+                                    stride, pad, di, hi, wi, do, ho, wo, act,
+                                    _MFMA_VARIANT if variant is None else int(variant), _stream()),
+          "nvf_conv3d_g16_mfma")
+    return y
+
+
 def stem_fwd(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b):
     """Fused up0 -> IGDN -> conv0 + ReLU for chanstr (8, 16, ...): returns (a0, h0, y1)."""
     _f32(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b)

@@ -282,7 +282,7 @@ def test_one_launch_step_head_equals_the_three_launches(tag, gpu):
     quantisation mode."""
     net, eng, gt, dist, emb = make(tag, gpu)
     idx = torch.tensor([4, 1, 5, 1], device=gpu)
-    bufs = lambda: [t for L in eng.layers.values() for t in (L.w_fwd, L.w_bwd, L.b_eff, L.wp_f, L.wp_b, L.wp_t, L.wp_s)
+    bufs = lambda: [t for L in eng.layers.values() for t in (L.w_fwd, L.w_bwd, L.b_eff, L.wp_f, L.wp_b, L.wp_t, L.wp_s, L.wp_gf, L.wp_gb)
                     if t is not None]
     for q in (0, 1, 2):
         eng.noise_step = 7 + q

@@ -257,6 +257,77 @@ def test_conv3d_k4_mfma_forward_and_backward_data(ops, n, B):
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("n,B", [(35, 2), (19, 3)])
+def test_conv3d_g16_mfma_forward_and_backward_data(ops, n, B):
+    """Wide decoder (chanstr 16,32,16,16): conv1 / conv2 on the matrix cores with 16 output channels as the MFMA rows
+    (conv16_mfma.hip) against torch's conv3d and its autograd backward-data (network.py:687); every tile variant gives
+    the same bits, and the results do not depend on the batch they run in."""
+    g = gen(4600 + n + B)
+    x = torch.randn(B, 16, n, n, n, generator=g)
+    w = torch.randn(16, 16, 4, 4, 4, generator=g) / 1024 ** 0.5
+    b = torch.randn(16, generator=g)
+    x.requires_grad_(True)
+    y_ref = F.conv3d(x, w, b)
+    no = n - 3
+    wf, wb = ops.pack_conv_weight(dev(w))
+    wpf, wpb = ops.pack_g16_mfma(wf, 16, 16, 4), ops.pack_g16_mfma(wb, 16, 16, 4)
+    xd = dev(x.detach())
+    y = ops.conv3d_g16_mfma(xd, wpf, dev(b), 16, 4, 1, 0, (no, no, no), ops.ACT_RELU)
+    assert (y.cpu() - F.relu(y_ref).detach()).abs().max() < 2e-5
+    for v in (2, 3, 4):
+        try:
+            yv = ops.conv3d_g16_mfma(xd, wpf, dev(b), 16, 4, 1, 0, (no, no, no), ops.ACT_RELU, variant=v)
+        except RuntimeError:
+            continue
+        assert torch.equal(yv, y), v
+    y1 = ops.conv3d_g16_mfma(xd[1:2].contiguous(), wpf, dev(b), 16, 4, 1, 0, (no, no, no), ops.ACT_RELU)
+    assert torch.equal(y1[0], y[1])
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    mask = torch.randn(x.shape, generator=g)
+    add = torch.randn(x.shape, generator=g)
+    dx = ops.conv3d_g16_mfma(dev(gy), wpb, None, 16, 4, 1, 3, (n, n, n), addend=dev(add), mask=dev(mask))
+    ref = (x.grad + add) * (mask > 0)
+    assert (dx.cpu() - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0)
+    for v in (2, 3, 4):
+        try:
+            dv = ops.conv3d_g16_mfma(dev(gy), wpb, None, 16, 4, 1, 3, (n, n, n), addend=dev(add), mask=dev(mask), variant=v)
+        except RuntimeError:
+            continue
+        assert torch.equal(dv, dx), v
+    # the VALU tile kernel computes the same sums in another order
+    dxv = ops.conv3d_gather(dev(gy), wb, None, 16, 4, 1, 3, (n, n, n), addend=dev(add), mask=dev(mask))
+    assert (dx - dxv).abs().max().item() < 2e-5 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(16, 16, 16), (32, 16, 8)])
+def test_conv_transpose_backward_data_g16_mfma(ops, cin, cout, n):
+    """Backward-data of the wide decoder's up2 (16 -> 16, 16^3 -> 35^3) and up1 (32 -> 16, 8^3 -> 19^3): a stride-2
+    gather convolution with `cin` (16 / 32) output channels on the matrix cores, against torch's autograd."""
+    g = gen(4700 + cin + n)
+    B = 2
+    x = torch.randn(B, cin, n, n, n, generator=g, requires_grad=True)
+    w = torch.randn(cin, cout, 5, 5, 5, generator=g) / (cout * 125 / 8) ** 0.5
+    y_ref = F.conv_transpose3d(x, w, None, 2)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    wf, wb = ops.pack_convT_weight(dev(w))
+    wpb = ops.pack_g16_mfma(wb, cout, cin, 5)              # gather form: `cout` input channels -> `cin` outputs
+    mask = torch.randn(x.shape, generator=g)
+    add = torch.randn(x.shape, generator=g)
+    dx = ops.conv3d_g16_mfma(dev(gy), wpb, None, cin, 5, 2, 0, (n, n, n), addend=dev(add), mask=dev(mask))
+    ref = (x.grad + add) * (mask > 0)
+    assert (dx.cpu() - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0)
+    for v in (2, 3):
+        try:
+            dv = ops.conv3d_g16_mfma(dev(gy), wpb, None, cin, 5, 2, 0, (n, n, n), addend=dev(add), mask=dev(mask), variant=v)
+        except RuntimeError:
+            continue
+        assert torch.equal(dv, dx), v
+    d1 = ops.conv3d_g16_mfma(dev(gy[1:2]), wpb, None, cin, 5, 2, 0, (n, n, n), addend=dev(add[1:2]), mask=dev(mask[1:2]))
+    assert torch.equal(d1[0], dx[1])
+
+
 @pytest.mark.parametrize("cin,cout,pad,opad,n", CONVT_CASES)
 def test_conv_transpose_forward_and_backward_data(ops, cin, cout, pad, opad, n):
     g = gen(cin * 100 + cout + pad)
