@@ -49,6 +49,7 @@ struct G16 {
   static constexpr int NSEG = OZ * NCY * NCX;
   static_assert(NSEG % NW == 0, "tiles split evenly over the waves");
   static constexpr int R = NSEG / NW;
+  static constexpr bool ZUNI = (NCY * NCX) % R == 0;       // every wave's R tiles lie in one output plane
   static constexpr int IZ = (OZ - 1) * S + K, IY = (OY - 1) * S + K, IX = (OX - 1) * S + K;
   static constexpr int find_rs() {
     for (int rs = IX; rs < IX + 64; ++rs)
@@ -124,6 +125,8 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
     }
   };
 
+  // first input plane (tensor coordinates) read by this wave's tiles, when they share one output plane
+  const int zplane = gz0 + ((wave * R) / (C::NCX * C::NCY)) * S;
   f32x4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -154,6 +157,15 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < K * K; ++i) an[i] = wg[((size_t)nslice * K * K + i) * 64];
       }
+      // backward-data runs over a zero-padded gradient: when all tiles of this wave lie in ONE output plane, a kz whose
+      // input plane is padding multiplies zeros only -- skip its K*K*R MFMAs (acc + 0 = acc: same values)
+      const bool skip = C::ZUNI && (zplane + kz < 0 || zplane + kz >= d.din);
+      if (skip) {
+        if (kz + 1 < K) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) bc[r] = ldsb[base[r] + (kz + 1) * PS];
+        }
+      } else
 #pragma unroll
       for (int t = 0; t < K * K; ++t) {
         const int tn = kz * K * K + t + 1;            // next tap of this chunk
@@ -176,26 +188,31 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
 
   // epilogue: lane holds rows co = 4 kq + r4 of column j of each of its tiles
   const size_t ovol = (size_t)d.dout * d.hout * d.wout;
-  const int co0 = cog * 16 + 4 * kq;
-  float bv4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
+  {
+    // (a tile row is CTX consecutive x: every (kq, r4, patch row) writes one CTX * 4-byte segment.  Sending patch-shaped
+    // tiles through LDS to store whole rows was measured SLOWER -- 347 vs 303 us on conv2's backward-data: the kernel
+    // is bound by its MFMAs, the padded border included, not by its stores)
+    const int co0 = cog * 16 + 4 * kq;
+    float bv4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) bv4[r4] = bias[co0 + r4];
-  }
+      for (int r4 = 0; r4 < 4; ++r4) bv4[r4] = bias[co0 + r4];
+    }
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int s = wave * R + r;
-    const int cx = s % C::NCX, cy = (s / C::NCX) % C::NCY, z = s / (C::NCX * C::NCY);
-    const int oz = oz0 + z, oy = oy0 + cy * C::CTY + j / C::CTX, ox = ox0 + cx * C::CTX + j % C::CTX;
-    if (oz >= d.dout || oy >= d.hout || ox >= d.wout) continue;
-    const size_t o = ((size_t)b * d.cout + co0) * ovol + ((size_t)oz * d.hout + oy) * d.wout + ox;
+    for (int r = 0; r < R; ++r) {
+      const int s = wave * R + r;
+      const int cx = s % C::NCX, cy = (s / C::NCX) % C::NCY, z = s / (C::NCX * C::NCY);
+      const int oz = oz0 + z, oy = oy0 + cy * C::CTY + j / C::CTX, ox = ox0 + cx * C::CTX + j % C::CTX;
+      if (oz >= d.dout || oy >= d.hout || ox >= d.wout) continue;
+      const size_t o = ((size_t)b * d.cout + co0) * ovol + ((size_t)oz * d.hout + oy) * d.wout + ox;
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const size_t oo = o + (size_t)r4 * ovol;
-      float v = nvf_act(acc[r][r4] + bv4[r4], d.act);
-      if (addend) v += addend[oo];
-      if (mask) v = mask[oo] > 0.f ? v : 0.f;
-      y[oo] = v;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const size_t oo = o + (size_t)r4 * ovol;
+        float v = nvf_act(acc[r][r4] + bv4[r4], d.act);
+        if (addend) v += addend[oo];
+        if (mask) v = mask[oo] > 0.f ? v : 0.f;
+        y[oo] = v;
+      }
     }
   }
 }
@@ -253,23 +270,36 @@ extern "C" int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float*
 #define NVF_G16(VAR, CI, KS, ST, WLO, WHI, OZ, NCY, NCX, CTY, CTX, NW)                                       \
   if (rc == 1 && variant == VAR && cin == CI && k == KS && stride == ST && wout >= WLO && wout <= WHI)       \
     rc = launch_g16<G16<CI, KS, ST, OZ, NCY, NCX, CTY, CTX, NW>>(x, wp, bias, y, addend, mask, batch, d, s);
-  NVF_G16(0, 16, 4, 1, 21, 32, 4, 8, 2, 1, 16, 8)     // conv2 forward: 4 planes x 8 rows x 32
-  NVF_G16(0, 16, 4, 1, 33, 40, 4, 4, 5, 2, 8, 8)      // conv2 backward-data (35^3): 4 planes x 8 rows x 40
-  NVF_G16(0, 16, 4, 1, 9, 16, 2, 8, 1, 1, 16, 4)      // conv1 forward: 2 planes x 8 rows x 16
-  NVF_G16(0, 16, 4, 1, 17, 20, 1, 5, 5, 4, 4, 5)      // conv1 backward-data (19^3): one plane of 5 x 5 patches
-  NVF_G16(0, 16, 5, 2, 9, 16, 2, 4, 1, 1, 16, 4)      // up2 backward-data (35^3 -> 16^3)
+  // (tile choices: tools/g16_sweep.py at batch 16)
+  NVF_G16(0, 16, 4, 1, 21, 32, 8, 4, 2, 1, 16, 8)     // conv2 forward: 8 planes x 4 rows x 32 (154 us = 111 TF)
+  NVF_G16(0, 16, 4, 1, 33, 40, 7, 1, 9, 4, 4, 7)      // conv2 backward-data (35^3): 7 planes of 1 x 9 patches, one plane per wave (268 us)
+  NVF_G16(0, 16, 4, 1, 9, 16, 2, 8, 1, 1, 16, 8)      // conv1 forward: 2 planes x 8 rows x 16 (26 us)
+  NVF_G16(0, 16, 4, 1, 17, 20, 1, 3, 5, 4, 4, 5)      // conv1 backward-data (19^3): one plane of 3 x 5 patches (87 us)
+  NVF_G16(0, 16, 5, 2, 9, 16, 2, 8, 1, 1, 16, 4)      // up2 backward-data (35^3 -> 16^3) (58 us)
   NVF_G16(0, 16, 5, 2, 5, 8, 1, 4, 1, 2, 8, 4)        // up1 backward-data (19^3 -> 8^3, 32 output channels)
+  NVF_G16(0, 32, 5, 2, 3, 4, 4, 1, 1, 4, 4, 4)        // conv0 backward-data (8^3 -> 4^3, padding 2)
   // tuning alternatives
   NVF_G16(2, 16, 4, 1, 21, 32, 4, 8, 2, 1, 16, 4)
   NVF_G16(3, 16, 4, 1, 21, 32, 2, 8, 2, 1, 16, 4)
   NVF_G16(4, 16, 4, 1, 21, 32, 2, 8, 2, 1, 16, 8)
+  NVF_G16(5, 16, 4, 1, 33, 40, 4, 4, 5, 2, 8, 8)
+  NVF_G16(6, 16, 4, 1, 33, 40, 4, 3, 9, 4, 4, 12)
+  NVF_G16(7, 16, 4, 1, 33, 40, 2, 3, 9, 4, 4, 6)
+  NVF_G16(8, 16, 4, 1, 33, 40, 5, 1, 9, 4, 4, 5)
+  NVF_G16(3, 16, 4, 1, 17, 20, 1, 5, 5, 4, 4, 5)
+  NVF_G16(4, 16, 4, 1, 17, 20, 1, 3, 5, 4, 4, 3)
+  NVF_G16(5, 16, 4, 1, 17, 20, 2, 3, 5, 4, 4, 6)
+  NVF_G16(5, 16, 4, 1, 21, 32, 4, 4, 2, 1, 16, 4)
+  NVF_G16(6, 16, 4, 1, 21, 32, 4, 4, 2, 1, 16, 8)
+  NVF_G16(7, 16, 4, 1, 21, 32, 4, 8, 2, 1, 16, 8)
+  NVF_G16(2, 32, 5, 2, 3, 4, 1, 1, 1, 4, 4, 1)
   NVF_G16(2, 16, 4, 1, 33, 40, 4, 4, 5, 2, 8, 4)
   NVF_G16(3, 16, 4, 1, 33, 40, 2, 4, 5, 2, 8, 4)
   NVF_G16(4, 16, 4, 1, 33, 40, 2, 4, 5, 2, 8, 8)
   NVF_G16(2, 16, 4, 1, 9, 16, 4, 8, 1, 1, 16, 4)
-  NVF_G16(3, 16, 4, 1, 9, 16, 2, 8, 1, 1, 16, 8)
+  NVF_G16(3, 16, 4, 1, 9, 16, 2, 8, 1, 1, 16, 4)
   NVF_G16(2, 16, 4, 1, 17, 20, 2, 5, 5, 4, 4, 5)
-  NVF_G16(2, 16, 5, 2, 9, 16, 2, 8, 1, 1, 16, 4)
+  NVF_G16(2, 16, 5, 2, 9, 16, 2, 4, 1, 1, 16, 4)
   NVF_G16(3, 16, 5, 2, 9, 16, 1, 4, 1, 1, 16, 4)
   NVF_G16(2, 16, 5, 2, 5, 8, 2, 4, 1, 2, 8, 4)
 #undef NVF_G16

@@ -154,3 +154,6 @@ int nvf_head_bwd_data_launch(const float* dl, const float* wb, const float* bias
                              const float* mask, int batch, int c, int s, int act, hipStream_t st);
 int nvf_head_wgrad_launch(const float* dl, const float* x, float* slabs, int max_slabs, int batch, int c, int s,
                           int* nslab, hipStream_t st);
+// ---- matrix-core weight gradients with 16 q-channels (wgrad16_mfma.hip), reached through nvf_wgrad*; 1 = no instantiation
+int nvf_wgrad16_launch(const float* p, const float* q, float* slabs, int batch, int a, int k, int stride, int pad, int dp,
+                       int dq, int max_slabs, int* nslab, hipStream_t s);

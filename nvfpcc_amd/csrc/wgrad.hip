@@ -783,6 +783,16 @@ static int wgrad_dispatch(const float* p, const float* q, float* dw, void* works
         rc = NVF_OK;
       }
     }
+    // wide decoder: 16 q-channels are the MFMA columns, 16 / 32 p-channels the rows (wgrad16_mfma.hip)
+    if (rc == 1 && variant == 0 && b == 16 && a % 16 == 0 && out_mode == 0 && dp == hp && hp == wp && dq == hq &&
+        hq == wq && ((k == 4 && stride == 1 && pad == 0 && dq == dp + 3) || (k == 5 && stride == 2 && pad == 0 && dq == 2 * dp + 3))) {
+      int n = 0;
+      if (nvf_wgrad16_launch(p, q, slabs, batch, a, k, stride, pad, dp, dq, kMaxSlabs, &n, s) == 0) {
+        if (defer_nslab) *defer_nslab = n;
+        else wgrad_reduce<<<(d.jtotal + 63) / 64, 1024, 0, s>>>(slabs, dw, n, d.jtotal, accumulate);
+        rc = NVF_OK;
+      }
+    }
     const bool cube_k4 = a == 8 && b == 8 && k == 4 && stride == 1 && pad == 0 && out_mode == 0 && dp == wp &&
                          hp == wp && dq == wp + 3 && hq == wp + 3 && wq == wp + 3;
     if (rc == 1 && variant == 0 && cube_k4 && wp == 32) rc = launch_wgrad_mfma<MCfg<32, 4, 4>>(p, q, dw, slabs, d, accumulate, s, defer_nslab);

@@ -1,0 +1,179 @@
+// Matrix-core weight gradients for layers with 16 q-channels and 16 / 32 p-channels -- the wide decoder
+// (chanstr 16,32,16,16; autograd backward of F.conv3d network.py:687 and F.conv_transpose3d network.py:621):
+//
+//   dw[a][b][tap] = sum_{n, pos} p[n, a, pos] * q[n, b, S * pos - pad + tap]
+//     conv  (k 4, S 1): p = dY [B,16,n^3],  q = X  [B,16,(n+3)^3]   -> dw[cout][cin][k]
+//     convT (k 5, S 2): p = X  [B,a,n^3],   q = dY [B,16,(2n+3)^3]  -> dw[cin][cout][k]
+//
+// One v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chain) per (tap, four consecutive x positions):
+//   D_tap[a][b] += sum_{k=0..3} A[a][k] * B[k][b],   A[a][k] = p[a, z, y, x0 + k],  B[k][b] = q[b, S(z,y,x0+k) - pad + tap]
+// rows = 16 p-channels, columns = 16 q-channels, every lane useful.  A workgroup has K waves, wave w owns the K*K taps
+// of kz = w (K*K accumulator tiles in registers for the whole launch) and walks its share of the items
+// (batch element, z plane, TY rows); p / q tiles of the next item stream into the second LDS buffer by LDS-DMA while
+// this item's MFMAs issue.  An A fragment (one ds_read_b32) feeds K*K MFMAs, a B fragment one.  Each workgroup leaves
+// one slab of 16 x 16 x K^3 partial sums; the caller's fixed-order reduction (nvf_wgrad_reduce_multi*) adds them.
+#include "nvf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct W16Dims {
+  int batch, ac, dp, dq, pad, items, items_per_wg, tiles_y;
+};
+
+// 32 lanes of a read group: channel c = 0..15 at stride cs, kq = 0..1 at stride s
+constexpr int w16_conflicts(int cs, int s) {
+  int cnt[32] = {};
+  int worst = 0;
+  for (int kq = 0; kq < 2; ++kq)
+    for (int c = 0; c < 16; ++c) {
+      const int bank = (c * cs + kq * s) % 32;
+      if (++cnt[bank] > worst) worst = cnt[bank];
+    }
+  return worst;
+}
+constexpr int w16_stride(int least, int s) {
+  int best = least, bw = 99;
+  for (int cs = least; cs < least + 64; ++cs) {
+    const int w = w16_conflicts(cs, s);
+    if (w < bw) { bw = w; best = cs; }
+  }
+  return best;
+}
+
+template <int K_, int S_, int WP_, int TY_>
+struct W16 {
+  static constexpr int K = K_, S = S_, WP = WP_, TY = TY_, NW = K_, NT = NW * 64, KK = K * K, K3 = K * K * K;
+  static_assert(WP % 4 == 0, "four x positions per MFMA");
+  static constexpr int QY = S * (TY - 1) + K, QX = S * (WP - 1) + K;
+  static constexpr int QRS = QX, QPS = QY * QRS;
+  static constexpr int QCS = w16_stride(K * QPS, S);       // q channel stride (bank spread of the B reads)
+  static constexpr int PCS = w16_stride(TY * WP, 1);       // p channel stride
+  static constexpr int BUF = 16 * QCS + 16 * PCS;
+  static_assert(2 * BUF * 4 <= 160 * 1024, "two item buffers in LDS");
+  static constexpr int QIT = (K * QPS + NT - 1) / NT, PIT = (TY * WP + NT - 1) / NT;   // DMA instructions per channel
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ p, const float* __restrict__ q,
+                                                      float* __restrict__ slabs, W16Dims d) {
+  constexpr int K = C::K, S = C::S, WP = C::WP, TY = C::TY, KK = C::KK, K3 = C::K3, QRS = C::QRS, QPS = C::QPS,
+                QCS = C::QCS, PCS = C::PCS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = kz of this wave's taps
+  const int j = lane & 15, kq = lane >> 4;
+  const int ag = blockIdx.y;                                       // group of 16 p-channels
+  const int first = blockIdx.x * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
+  const size_t pvol = (size_t)d.dp * d.dp * d.dp, qvol = (size_t)d.dq * d.dq * d.dq;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+
+  auto stage = [&](int item, int buf) {
+    const int ty = item % d.tiles_y, t = item / d.tiles_y, z = t % d.dp, n = t / d.dp;
+    const int y0 = ty * TY;
+    const int qz0 = S * z - d.pad, qy0 = S * y0 - d.pad, qx0 = -d.pad;
+    const float* qb = q + (size_t)n * 16 * qvol;
+    const float* pb = p + ((size_t)n * d.ac + ag * 16) * pvol + ((size_t)z * d.dp + y0) * d.dp;
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+      const int cb = buf * C::BUF + c * QCS;
+#pragma unroll
+      for (int i = 0; i < C::QIT; ++i) {
+        const int w0 = (i * C::NW + wave) * 64, w = w0 + lane;
+        const int zz = w / QPS, rem = w - zz * QPS, yy = rem / QRS, xx = rem - yy * QRS;
+        const int gz = qz0 + zz, gy = qy0 + yy, gx = qx0 + xx;
+        const bool live = w < K * QPS;
+        const bool ok = live && gz >= 0 && gz < d.dq && gy >= 0 && gy < d.dq && gx >= 0 && gx < d.dq;
+        if (ok) nvf_glds_lane(qb + (size_t)c * qvol + ((size_t)gz * d.dq + gy) * d.dq + gx, lds0 + (unsigned)(cb + w0) * 4u);
+        else if (live) lds[cb + w] = 0.f;
+      }
+      const int pbase = buf * C::BUF + 16 * QCS + c * PCS;
+#pragma unroll
+      for (int i = 0; i < C::PIT; ++i) {
+        const int w0 = (i * C::NW + wave) * 64, w = w0 + lane;
+        if (w < TY * WP) {
+          const int yy = w / WP;
+          if (y0 + yy < d.dp) nvf_glds_lane(pb + (size_t)c * pvol + w, lds0 + (unsigned)(pbase + w0) * 4u);
+          else lds[pbase + w] = 0.f;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (first < last) stage(first, 0);
+#pragma unroll 1
+  for (int item = first; item < last; ++item) {
+    const int buf = (item - first) & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the item has landed
+    __syncthreads();                                              // ... everyone's; the other buffer is free
+    if (item + 1 < last) stage(item + 1, buf ^ 1);
+    const float* qs = lds + buf * C::BUF + j * QCS + wave * QPS + S * kq;
+    const float* ps = lds + buf * C::BUF + 16 * QCS + j * PCS + kq;
+#pragma unroll 1
+    for (int y = 0; y < TY; ++y) {
+      const float* qr = qs + S * y * QRS;
+      const float* pr = ps + y * WP;
+      float bc[K], bn[K];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) bc[kx] = qr[kx];
+#pragma unroll
+      for (int xg = 0; xg < WP / 4; ++xg) {
+        const float a = pr[4 * xg];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          // next row of taps: (xg, ky + 1), or (xg + 1, 0)
+          const int nky = ky + 1 < K ? ky + 1 : 0, nxg = ky + 1 < K ? xg : xg + 1;
+          if (nxg < WP / 4) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) bn[kx] = qr[nky * QRS + S * 4 * nxg + kx];
+          }
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx)
+            acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[kx], acc[ky * K + kx], 0, 0, 0);
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) bc[kx] = bn[kx];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // slab [ac][16][K^3]: lane holds D[a = 4 kq + r4][b = j] of each of this wave's taps
+  float* slab = slabs + (size_t)blockIdx.x * d.ac * 16 * K3;
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+      slab[((size_t)(ag * 16 + 4 * kq + r4) * 16 + j) * K3 + wave * KK + t] = acc[t][r4];
+}
+
+template <class C>
+int launch_w16(const float* p, const float* q, float* slabs, W16Dims d, int max_slabs, int* nslab, hipStream_t s) {
+  d.tiles_y = (d.dp + C::TY - 1) / C::TY;
+  d.items = d.batch * d.dp * d.tiles_y;
+  int n = d.items < max_slabs ? d.items : max_slabs;
+  d.items_per_wg = (d.items + n - 1) / n;
+  n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+  wgrad16_mfma<C><<<dim3(n, d.ac / 16), C::NT, 0, s>>>(p, q, slabs, d);
+  *nslab = n;
+  return NVF_OK;
+}
+
+}  // namespace
+
+// Partial sums of dw[a][16][k^3] (a = 16 or 32) into `slabs` (*nslab slabs of a * 16 * k^3 floats, <= max_slabs);
+// returns 1 when there is no instantiation for the shape.  Cubic tensors: p [B,a,dp^3], q [B,16,dq^3].
+int nvf_wgrad16_launch(const float* p, const float* q, float* slabs, int batch, int a, int k, int stride, int pad, int dp,
+                       int dq, int max_slabs, int* nslab, hipStream_t s) {
+  W16Dims d{batch, a, dp, dq, pad, 0, 0, 0};
+  if (a % 16 != 0 || max_slabs <= 0) return 1;
+  if (max_slabs > 256) max_slabs = 256;                         // one workgroup per CU and p-channel group
+  if (k == 4 && stride == 1 && dp == 32) return launch_w16<W16<4, 1, 32, 4>>(p, q, slabs, d, max_slabs, nslab, s);
+  if (k == 4 && stride == 1 && dp == 16) return launch_w16<W16<4, 1, 16, 4>>(p, q, slabs, d, max_slabs, nslab, s);
+  if (k == 5 && stride == 2 && dp == 16) return launch_w16<W16<5, 2, 16, 2>>(p, q, slabs, d, max_slabs, nslab, s);
+  // (up1's 8-wide rows give an A fragment only two uses per tap row: 58 us against 48 us for the VALU tile kernel)
+  return 1;
+}

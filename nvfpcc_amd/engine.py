@@ -173,6 +173,8 @@ class TrainEngine:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
             if _G16 and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
+            if _G16 and name == "conv0" and L.cin == 16 and L.cout == 32 and L.pad == 2:
+                L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(32, 16, 5)), device=self.dev)
             self.layers[name] = L
             t = table[i]
             t["kernel"], t["kernel_init"] = m.kernel.data_ptr(), m.kernel_init.data_ptr()
@@ -337,7 +339,7 @@ class TrainEngine:
 
     def _dx_convT(self, L, g_out, x_in, mask=None, addend=None):
         if L.wp_gb is not None:
-            return ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 5, 2, 0, tuple(x_in.shape[2:]), addend=addend,
+            return ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                        mask=mask)
         if L.wp_s is not None:
             # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256)
