@@ -151,8 +151,19 @@ int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float* bias, floa
                         const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din, int hin,
                         int win, int dout, int hout, int wout, int act, int variant, void* stream);
 
-/* every MFMA weight packing of a step in one launch (<= 8 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
- * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog),
+/* ---- matrix-core form of the transposed convolutions k5 s2 with 16 output channels and padding 0 (up1 / up2 of
+ * chanstr 16,32,16,16; F.conv_transpose3d network.py:621): the output channels are the MFMA rows, the eight
+ * sub-pixel parity classes separate accumulators fed by one B fragment.  Same contract as nvf_convT3d_k5s2_fwd;
+ * weights: nvf_pack_convT16_mfma(w_fwd [cin][125][16], cin, 16, wp), nvf_pack_convT16_mfma_floats(cin) floats.
+ * Fixed per-output accumulation order (input-channel group, jy, jx, jz).  NVF_EINVAL = no instantiation. */
+size_t nvf_pack_convT16_mfma_floats(int cin);
+int nvf_pack_convT16_mfma(const float* w_fwd, int cin, int cout, float* wp, void* stream);
+int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const float* bias, float* y, int batch, int cin, int cout,
+                            int din, int act, int variant, void* stream);
+
+/* every MFMA weight packing of a step in one launch (<= 12 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
+ * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 11 = nvf_pack_convT16_mfma (c0 = cin),
+ * 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog),
  * 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout) */
 int nvf_pack_mfma_all(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s, const int* c1s,
                       int n, void* stream);

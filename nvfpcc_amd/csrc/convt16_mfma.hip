@@ -1,0 +1,225 @@
+// Matrix-core forward of the stride-2, 5^3 transposed convolutions with 16 OUTPUT channels and no padding -- the wide
+// decoder's up1 (32 -> 16 channels, 8^3 -> 19^3) and up2 (16 -> 16, 16^3 -> 35^3); F.conv_transpose3d, network.py:621.
+//
+// Sub-pixel form: output o = 2c + e per axis (cell c, parity e) reads inputs i = c - j through taps k = e + 2j
+// (j = 0..2 for e = 0, j = 0..1 for e = 1): all 125 taps do useful work, no inserted zeros.  MFMA mapping
+// (v_mfma_f32_16x16x4_f32, an exact fp32 fmaf chain): rows = the 16 output channels, K = four input channels,
+// columns = 16 consecutive cells of the FLATTENED (cy, cx) cell plane; the eight parity classes (ez, ey, ex) are separate
+// accumulators fed by the same B fragment (27 LDS reads feed 125 MFMAs).  The LDS image of an input plane has row
+// stride = cells per row (= input width + 2) with two zero words in front of every row and zero rows around it, so
+//   address(cell p, jy, jx) = p - jy * NCELL - jx + const
+// is linear in p: any 16 consecutive cells are one conflict-free ds_read_b32, and 18- / 10-cell rows cost no padding
+// columns.  All input channels of the three planes cz-2 .. cz stay in LDS for an item; the A fragments (125 per
+// channel group) stream through two LDS buffers by LDS-DMA, group g + 1 in flight during the MFMAs of group g.
+// Per output the accumulation order is fixed: (channel group, jy, jx, jz) -- independent of batch and tiling.
+#include "nvf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kA16 = 125;     // A fragments per channel group: sum over classes of (3-ez)(3-ey)(3-ex)
+
+__host__ __device__ constexpr int a16_index(int ez, int ey, int ex, int jz, int jy, int jx) {
+  int base = 0;
+  for (int c = 0; c < 4 * ez + 2 * ey + ex; ++c) base += (3 - (c >> 2)) * (3 - ((c >> 1) & 1)) * (3 - (c & 1));
+  return base + (jz * (3 - ey) + jy) * (3 - ex) + jx;
+}
+
+__global__ void pack_convT16_kernel(const float* __restrict__ wf /* [cin][125][16] */, float* __restrict__ wp, int cin) {
+  const int total = (cin / 4) * kA16 * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx % 64, f = (idx / 64) % kA16, g = idx / (64 * kA16);
+    int cls = 0, r = f;
+    for (;; ++cls) {
+      const int n = (3 - (cls >> 2)) * (3 - ((cls >> 1) & 1)) * (3 - (cls & 1));
+      if (r < n) break;
+      r -= n;
+    }
+    const int ez = cls >> 2, ey = (cls >> 1) & 1, ex = cls & 1;
+    const int jx = r % (3 - ex), jy = (r / (3 - ex)) % (3 - ey), jz = r / ((3 - ex) * (3 - ey));
+    const int co = lane & 15, ci = 4 * g + (lane >> 4);
+    const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
+    wp[idx] = wf[(ci * 125 + (kz * 5 + ky) * 5 + kx) * 16 + co];
+  }
+}
+
+template <int CIN_, int NIN_, int NCT_>
+struct T16 {
+  static constexpr int CIN = CIN_, NIN = NIN_, NCT = NCT_;
+  static constexpr int NCELL = NIN + 2;                        // cells per axis; outputs 2 NIN + 3
+  static constexpr int NPT = (NCELL * NCELL + 15) / 16;        // column tiles of a cell plane
+  static constexpr int NW = 4, CPW = NW * NCT;                 // column tiles per workgroup
+  static constexpr int NSPLIT = (NPT + CPW - 1) / CPW;
+  static constexpr int PLANE = (NCELL + 3) * NCELL + 18;       // LDS words per (channel, plane), zero margins
+  static constexpr int cs_for(int v) { while (v % 32 != 16) ++v; return v; }
+  static constexpr int CS = cs_for(3 * PLANE);                 // channel stride: second channel -> banks 16..31
+  static constexpr int NG = CIN / 4;
+  static constexpr int XS = CIN * CS;                          // input image (all channels, three planes)
+  static constexpr int AS = kA16 * 64;                         // A fragments of one channel group
+  static_assert((XS + 2 * AS) * 4 <= 160 * 1024, "LDS");
+  static constexpr int AIT = (AS / 64 + NW - 1) / NW;          // A DMA instructions per wave per group
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void convT16_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int act,
+                                                         int items) {
+  constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
+                NG = T::NG, NOUT = 2 * NIN + 3, AS = T::AS;
+  __shared__ __attribute__((aligned(16))) float xs[T::XS];
+  __shared__ __attribute__((aligned(16))) float as[2 * AS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned as0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)as;
+  constexpr int ITEMS = CIN * 3 * NIN * NIN / 4;               // float4 input loads of an item
+  constexpr int NX4 = (ITEMS + 255) / 256;
+  float4 xv[NX4];
+  auto load_x = [&](int item) {
+    const int cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
+    const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * 256;
+      const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
+      const int zi = cz - 2 + pl;
+      const bool ok = i < ITEMS && zi >= 0 && zi < NIN;
+      xv[u] = ok ? *(const float4*)(xb + (((size_t)c * NIN + zi) * NIN + iy) * NIN + 4 * xq)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_x = [&]() {                                       // planes outside the input are written as zeros
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * 256;
+      if (i < ITEMS) {
+        const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
+        float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + 4 * xq + 2;
+        dst[0] = xv[u].x; dst[1] = xv[u].y; dst[2] = xv[u].z; dst[3] = xv[u].w;
+      }
+    }
+  };
+  auto stage_a = [&](int g, int buf) {                         // 125 fragments of 64 floats: one DMA instruction each
+#pragma unroll
+    for (int i = 0; i < T::AIT; ++i) {
+      const int f = i * T::NW + wave;
+      if (f < kA16) nvf_glds_lane(wp + ((size_t)g * kA16 + f) * 64 + lane, as0 + (unsigned)(buf * AS + f * 64) * 4u);
+    }
+  };
+  if ((int)blockIdx.x < items) load_x(blockIdx.x);
+  for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  stage_a(0, 0);
+  const int j = lane & 15, kq = lane >> 4;
+  const size_t cstride = (size_t)NOUT * NOUT * NOUT;
+  int abuf = 0;
+#pragma unroll 1
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int split = item % T::NSPLIT, cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
+    __syncthreads();                                           // zero fill done / the previous item's reads done
+    store_x();
+    f32x4 acc[NCT][8];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int colbase[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int tl = split * T::CPW + c * T::NW + wave;          // wave-uniform
+      // cell p = 16 tl + j reads plane word (cy - jy + 2) NCELL + cx - jx + 2 = p + 2 NCELL + 2 - jy NCELL - jx
+      // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
+      colbase[c] = kq * CS + 16 * min(tl, NPT - 1) + j + 2 * NCELL + 2;
+    }
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A fragments of group g have landed
+      __syncthreads();                                              // ... everyone's (and the input image is written)
+      // next group's fragments (or the next item's first group) into the other buffer, in flight during the MFMAs
+      if (g + 1 < NG) stage_a(g + 1, abuf ^ 1);
+      else if (item + (int)gridDim.x < items) stage_a(0, abuf ^ 1);
+      // the next item's input planes travel to registers under this item's MFMAs (issued behind the wait above, so
+      // that wait does not expose their latency)
+      if (g == 0 && item + (int)gridDim.x < items) load_x(item + gridDim.x);
+      const float* xg = xs + g * 4 * CS;
+      const float* ag = as + abuf * AS + lane;
+#pragma unroll
+      for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx)
+#pragma unroll
+          for (int jz = 0; jz < 3; ++jz) {
+            float bv[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bv[c] = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // plane cz - jz
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
+              if (jz <= 2 - ez && jy <= 2 - ey && jx <= 2 - ex) {
+                const float a = ag[a16_index(ez, ey, ex, jz, jy, jx) * 64];
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c], acc[c][e], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      abuf ^= 1;
+    }
+    // epilogue: lane holds rows co = 4 kq + r of cell p for each parity class
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int tl = split * T::CPW + c * T::NW + wave;
+      const int p = 16 * tl + j;
+      if (tl >= NPT || p >= NCELL * NCELL) continue;
+      const int cy = p / NCELL, cx = p % NCELL;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int oz = 2 * cz + (e >> 2), oy = 2 * cy + ((e >> 1) & 1), ox = 2 * cx + (e & 1);
+        if (oz >= NOUT || oy >= NOUT || ox >= NOUT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 4 * kq + r;
+          y[((size_t)b * 16 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
+              nvf_act(acc[c][e][r] + (bias ? bias[co] : 0.f), act);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t nvf_pack_convT16_mfma_floats(int cin) { return (size_t)(cin / 4) * kA16 * 64; }
+
+// w_fwd = the [cin][125][16] packed forward weight of a transposed convolution with 16 output channels
+extern "C" int nvf_pack_convT16_mfma(const float* w_fwd, int cin, int cout, float* wp, void* stream) {
+  if (!w_fwd || !wp || cin <= 0 || cin % 4 || cout != 16) return NVF_EINVAL;
+  const int total = (int)nvf_pack_convT16_mfma_floats(cin);
+  pack_convT16_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(w_fwd, wp, cin);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// y[b,co,o] = act(bias[co] + sum_{ci,k : o - k = 2 i} x[b,ci,i] w[ci][k][co]), padding 0, dout = 2 din + 3, 16 output
+// channels.  NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_convT3d_k5s2_fwd).
+extern "C" int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const float* bias, float* y, int batch, int cin,
+                                       int cout, int din, int act, int variant, void* stream) {
+  if (!x || !wp || !y || batch <= 0 || cout != 16) return NVF_EINVAL;
+  hipStream_t s = nvf_stream(stream);
+  int rc = 1;
+#define NVF_T16(VAR, CI, NIN, NCT)                                                                     \
+  if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
+    using T = T16<CI, NIN, NCT>;                                                                       \
+    const int items = batch * T::NCELL * T::NSPLIT;                                                    \
+    convT16_k5s2_mfma<T><<<items < 256 ? items : 256, 256, 0, s>>>(x, wp, bias, y, act, items);        \
+    rc = NVF_OK;                                                                                       \
+  }
+  NVF_T16(0, 16, 16, 2)      // up2: 21 column tiles per cell plane, 8 per workgroup
+  NVF_T16(0, 32, 8, 2)       // up1: all 7 column tiles of a cell plane in one workgroup (52 vs 68 us with 4)
+  NVF_T16(2, 16, 16, 1)
+  NVF_T16(3, 16, 16, 3)
+  NVF_T16(2, 32, 8, 1)
+#undef NVF_T16
+  if (rc == 1) return NVF_EINVAL;
+  NVF_LAUNCH_CHECK();
+  return rc;
+}

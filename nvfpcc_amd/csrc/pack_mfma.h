@@ -4,10 +4,10 @@
 #include "nvf_common.h"
 
 struct PackJobs {
-  const float* src[8];
-  float* dst[8];
-  int32_t kind[8], c0[8], c1[8], total[8];
-  int32_t layer[8], bwd[8];      // step head only: row of the layer table and which layout (0 w_fwd, 1 w_bwd) src is
+  const float* src[12];
+  float* dst[12];
+  int32_t kind[12], c0[12], c1[12], total[12];
+  int32_t layer[12], bwd[12];      // step head only: row of the layer table and which layout (0 w_fwd, 1 w_bwd) src is
   int32_t n;
 };
 
@@ -39,6 +39,17 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       const int co = i >> 1, ex = i & 1, ci = 4 * g + k;
       const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
       if (kx < 5) v = src(job, (ci * 125 + (kz * 5 + ky) * 5 + kx) * 8 + co);
+    } else if (kind == 11) {                         // transposed conv forward, 16 output channels: [g][125][lane]
+      int f = r % 125, cls = 0;
+      const int g = r / 125;
+      for (;; ++cls) {
+        const int n = (3 - (cls >> 2)) * (3 - ((cls >> 1) & 1)) * (3 - (cls & 1));
+        if (f < n) break;
+        f -= n;
+      }
+      const int ez = cls >> 2, ey = (cls >> 1) & 1, ex = cls & 1;
+      const int jx = f % (3 - ex), jy = (f / (3 - ex)) % (3 - ey), jz = f / ((3 - ex) * (3 - ey));
+      v = src(job, ((4 * g + k) * 125 + ((ez + 2 * jz) * 5 + ey + 2 * jy) * 5 + ex + 2 * jx) * 16 + i);
     } else if (kind == 30 || kind == 31) {           // 16-row gather convolution (conv16_mfma.hip): [cog][g][tap][lane]
       const int k3 = kind == 30 ? 64 : 125, cin = m.c0[job], cout = m.c1[job];
       const int tap = r % k3; r /= k3;
@@ -58,16 +69,17 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
 }
 
 // kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
-// 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout).
+// 11 = nvf_pack_convT16_mfma (c0 = cin); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout).
 // Fills m (sources optional: the step head derives them).
 static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
                                  const int* c1s, int n, PackJobs& m) {
-  if (!dsts || !kinds || !c0s || !c1s || n <= 0 || n > 8) return NVF_EINVAL;
+  if (!dsts || !kinds || !c0s || !c1s || n <= 0 || n > 12) return NVF_EINVAL;
   for (int j = 0; j < n; ++j) {
     if (!dsts[j] || c0s[j] <= 0 || c0s[j] % 4) return NVF_EINVAL;
     m.src[j] = srcs ? srcs[j] : nullptr; m.dst[j] = dsts[j]; m.kind[j] = kinds[j]; m.c0[j] = c0s[j]; m.c1[j] = c1s[j];
     if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
     else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
+    else if (kinds[j] == 11) m.total[j] = (c0s[j] / 4) * 125 * 64;
     else if (kinds[j] == 20 && (c1s[j] == 8 || c1s[j] == 16)) m.total[j] = (c0s[j] / 4) * 25 * (c1s[j] == 8 ? 7 : 5) * 64;
     else if ((kinds[j] == 30 || kinds[j] == 31) && c1s[j] > 0 && c1s[j] % 16 == 0)
       m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * (kinds[j] == 30 ? 64 : 125) * 64;

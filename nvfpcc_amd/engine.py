@@ -53,7 +53,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "bwd_pair", "bwd_max_batch")
+                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "wp_t16", "bwd_pair", "bwd_max_batch")
 
 
 class TrainEngine:
@@ -150,7 +150,7 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = None
+            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = None
             L.bwd_pair, L.bwd_max_batch = 2, 0
             if L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
@@ -173,6 +173,8 @@ class TrainEngine:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
             if _G16 and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
+            if _G16 and L.k == 5 and L.cout == 16 and L.pad == 0 and (name, L.cin) in (("up1", 32), ("up2", 16)):
+                L.wp_t16 = torch.empty(int(lib().nvf_pack_convT16_mfma_floats(L.cin)), device=self.dev)
             if _G16 and name == "conv0" and L.cin == 16 and L.cout == 32 and L.pad == 2:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(32, 16, 5)), device=self.dev)
             self.layers[name] = L
@@ -200,7 +202,9 @@ class TrainEngine:
         meta += [(row[nm], 0) for nm, L in named if L.wp_gf is not None]
         jobs += [(L.w_bwd, L.wp_gb, 30 if L.k == 4 else 31, L.cout, L.cin) for _, L in named if L.wp_gb is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_gb is not None]
-        assert len(jobs) <= 8
+        jobs += [(L.w_fwd, L.wp_t16, 11, L.cin, 16) for _, L in named if L.wp_t16 is not None]
+        meta += [(row[nm], 0) for nm, L in named if L.wp_t16 is not None]
+        assert len(jobs) <= 12
         self._mfma_jobs = jobs
         self._mfma_job_layers = meta           # (layer-table row, 0 = w_fwd / 1 = w_bwd) of each job's source
         self._table_host = table
@@ -237,6 +241,8 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ forward
     def _convT(self, L, x, act):
+        if L.wp_t16 is not None:
+            return ops.convT3d_k5s2_mfma16(x, L.wp_t16, L.b_eff, act)
         if L.wp_t is not None:
             return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)

@@ -300,6 +300,36 @@ def test_conv3d_g16_mfma_forward_and_backward_data(ops, n, B):
     assert (dx - dxv).abs().max().item() < 2e-5 * max(ref.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("cin,n,B", [(16, 16, 2), (32, 8, 3), (16, 16, 1)])
+def test_conv_transpose_k5s2_mfma16_forward(ops, cin, n, B):
+    """Wide decoder's up2 / up1 forward on the matrix cores (16 output channels = MFMA rows, eight parity classes,
+    convt16_mfma.hip) against torch's conv_transpose3d; tile variants and batch sizes give the same bits; the packed
+    fragments equal those of the one-launch packer."""
+    g = gen(5200 + cin + n + B)
+    x = torch.randn(B, cin, n, n, n, generator=g)
+    w = torch.randn(cin, 16, 5, 5, 5, generator=g) / (cin * 125 / 8) ** 0.5
+    b = torch.randn(16, generator=g)
+    y_ref = F.relu(F.conv_transpose3d(x, w, b, stride=2))
+    wf, _ = ops.pack_convT_weight(dev(w))
+    wp = ops.pack_convT16_mfma(wf, cin)
+    wp2 = torch.empty_like(wp)
+    ops.pack_mfma_all([(wf, wp2, 11, cin, 16)])
+    assert torch.equal(wp, wp2)
+    y = ops.convT3d_k5s2_mfma16(dev(x), wp, dev(b), ops.ACT_RELU)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert (y.cpu() - y_ref).abs().max() < 2e-5 * max(y_ref.abs().max().item(), 1.0)
+    for v in (2, 3):
+        try:
+            yv = ops.convT3d_k5s2_mfma16(dev(x), wp, dev(b), ops.ACT_RELU, variant=v)
+        except RuntimeError:
+            continue
+        assert torch.equal(yv, y), v
+    y1 = ops.convT3d_k5s2_mfma16(dev(x[B - 1:]), wp, dev(b), ops.ACT_RELU)
+    assert torch.equal(y1[0], y[B - 1])
+    yv = ops.convT3d_k5s2_fwd(dev(x), wf, dev(b), 16, 0, ops.ACT_RELU)
+    assert (y - yv).abs().max().item() < 2e-5 * max(y_ref.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("cin,cout,n", [(16, 16, 16), (32, 16, 8)])
 def test_conv_transpose_backward_data_g16_mfma(ops, cin, cout, n):
     """Backward-data of the wide decoder's up2 (16 -> 16, 16^3 -> 35^3) and up1 (32 -> 16, 8^3 -> 19^3): a stride-2

@@ -32,6 +32,11 @@ def main():
         y = torch.empty(B, cout, no, no, no, device=dev)
         macs = B * cin * n ** 3 * cout * 125
         cases.append((name + ".fwd", macs, lambda: ops.convT3d_k5s2_fwd(x, wf, None, cout, 0, ops.ACT_RELU, out=y)))
+        if cout == 16:
+            wp16 = ops.pack_convT16_mfma(wf, cin)
+            for v in (0, 2, 3):
+                cases.append((name + f".fwd.mfma16.v{v}", macs,
+                              lambda v=v: ops.convT3d_k5s2_mfma16(x, wp16, None, ops.ACT_RELU, out=y, variant=v)))
         dx = torch.empty(B, cin, n, n, n, device=dev)
         cases.append((name + ".bwd_data", macs,
                       lambda: ops.conv3d_gather(gy, wb, None, cin, 5, 2, 0, (n, n, n), mask=x, out=dx)))
