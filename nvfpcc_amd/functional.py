@@ -42,7 +42,14 @@ class Conv3d(Function):
         cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
         wf, wb = ops.pack_conv_weight(w.contiguous())
         osz = tuple(s + 2 * pad - k + 1 for s in x.shape[2:])
-        y = ops.conv3d_gather(x, wf, b, cout, k, 1, pad, osz, act)
+        # the trunk's 4^3 convolutions run on the matrix cores (same kernels as the step engine; the choice depends on
+        # the layer shape only, never on the batch: encode at any batch == decode at batch 1)
+        if k == 4 and pad == 0 and cin == 8 and cout == 8 and x.shape[-1] in (19, 35):
+            y = ops.conv3d_k4_mfma(x, ops.pack_mfma_k4(wf, 8, 0), b, 0, 0, act)
+        elif k == 4 and pad == 0 and cin == 16 and cout == 16 and x.shape[-1] in (19, 35):
+            y = ops.conv3d_g16_mfma(x, ops.pack_g16_mfma(wf, 16, 16, 4), b, 16, 4, 1, 0, osz, act)
+        else:
+            y = ops.conv3d_gather(x, wf, b, cout, k, 1, pad, osz, act)
         ctx.save_for_backward(x, y, wb)
         ctx.cfg = (cin, cout, k, pad, act)
         return y
@@ -70,7 +77,12 @@ class ConvTranspose3dK5S2(Function):
         x = x.contiguous()
         cin, cout = w.shape[0], w.shape[1]
         wf, wb = ops.pack_convT_weight(w.contiguous())
-        y = ops.convT3d_k5s2_fwd(x, wf, b, cout, pad, act)
+        if pad == 0 and cout == 8 and (cin, x.shape[-1]) in ((16, 8), (8, 16)):        # up1 / up2, narrow decoder
+            y = ops.convT3d_k5s2_mfma(x, ops.pack_convT_mfma(wf, cin), b, act)
+        elif pad == 0 and cout == 16 and (cin, x.shape[-1]) in ((32, 8), (16, 16)):    # up1 / up2, wide decoder
+            y = ops.convT3d_k5s2_mfma16(x, ops.pack_convT16_mfma(wf, cin), b, act)
+        else:
+            y = ops.convT3d_k5s2_fwd(x, wf, b, cout, pad, act)
         ctx.save_for_backward(x, y, wb)
         ctx.cfg = (cin, cout, pad, act)
         return y
