@@ -14,8 +14,8 @@ Leaf blocks are independent given the shared decoder and every loss term is a SU
   * weight noise (q = 1) is keyed by (seed, step, layer) and so identical on all ranks; latent noise is
     keyed by (block id, step), so results do not depend on W; the step counter advances once per mini-batch and
     once per latent phase on every rank, idle or not;
-  * inside a replayed HIP graph the all-reduce is a captured node (RCCL is capture-aware), so the hand-over between
-    the compute stream and RCCL's stream costs no event wait at run time (engine.GraphedTrainStep);
+  * the step graph ends before the all-reduce, which torch.distributed runs on RCCL's stream (two event waits per
+    step); NVF_GRAPH_COLLECTIVE=graph captures it as a node of the step graph instead (engine.GraphedTrainStep);
   * latent phase / eval: contiguous block shards, no collective inside the step; one all-gather of the
     updated latent rows per epoch.
 """
@@ -101,7 +101,7 @@ def attach(engine, world, force=False):
         engine.rate_grad_scale = 1.0 / world
         engine.grad_hook = _allreduce_any_world if force and world == 1 else allreduce_sum_
         # gloo (test hook) reduces through host memory, which cannot be captured into a HIP graph
-        engine.collective_mode = "host" if dist.get_backend() == "gloo" else os.environ.get("NVF_GRAPH_COLLECTIVE", "graph")
+        engine.collective_mode = "host" if dist.get_backend() == "gloo" else os.environ.get("NVF_GRAPH_COLLECTIVE", "host")
     return engine
 
 

@@ -648,15 +648,17 @@ class GraphedTrainStep:
     copy: block ids, the noise-step counter, the rate coefficient lambda*w1/n_pts and Adam's two step-dependent
     coefficients (lr / (1 - b1^t), sqrt(1 - b2^t): nvf_step_tail).
 
-    Data parallelism: ``collective`` = "graph" captures the all-reduce of flat_g inside the graph (RCCL is
-    capture-aware: the hand-over between the compute stream and RCCL's stream becomes a graph edge instead of two
-    event waits per step); "host" ends the graph before it and launches hook + tail from the host."""
+    Data parallelism: ``collective`` = "host" (default) ends the graph after the backward pass and launches the
+    all-reduce hook and the optimiser node from the host; "graph" (NVF_GRAPH_COLLECTIVE=graph) captures the all-reduce
+    of flat_g inside the graph, so that the hand-over between the compute stream and RCCL's stream becomes a graph
+    edge instead of two event waits per step -- validated on one GPU with a one-rank RCCL group
+    (bench.py --force-collective); left opt-in until it has run on a multi-GPU node."""
 
     def __init__(self, eng, batch, q, ring=8, collective=None):
         self.eng, self.batch, self.q = eng, batch, q
         dev = eng.dev
         if collective is None:
-            collective = getattr(eng, "collective_mode", None) or os.environ.get("NVF_GRAPH_COLLECTIVE", "graph")
+            collective = getattr(eng, "collective_mode", None) or os.environ.get("NVF_GRAPH_COLLECTIVE", "host")
         self.collective = collective if eng.grad_hook is not None else "none"
         # one device buffer [idx (B x i64) | noise step (u64) | lambda*w1/n_pts (f32 in the low half) | Adam coef (2 x f32)]
         # refreshed by a single pinned-memory copy per step.  The host may run several steps ahead of the GPU, so the
@@ -686,21 +688,17 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             eng.metrics_acc = macc
-            try:
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._body(tail=self.collective != "host")
-            except Exception as exc:           # a collective that cannot be captured: keep it outside the graph
-                if self.collective != "graph":
-                    raise
-                print(f"[nvfpcc_amd] all-reduce not capturable ({type(exc).__name__}: {exc}); launching it from the "
-                      f"host between the step graph and the optimiser", flush=True)
-                self.collective = eng.collective_mode = "host"
-                eng.ctx.cancel()
+            if self.collective == "graph":
+                # RCCL builds its communicator (allocations, IPC handles) on the first collective: that must happen
+                # eagerly -- inside a capture it invalidates the capture, and an invalidated capture cannot be retried
+                # in the same process (measured on MI355X / RCCL 2.26: "operation not permitted when stream is
+                # capturing"), which is why "host" is the default and "graph" an explicit choice
+                with torch.cuda.stream(side):
+                    eng.grad_hook(torch.zeros_like(eng.flat_g))
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._body(tail=False)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body(tail=self.collective != "host")
         finally:
             eng.metrics_acc = macc
             eng._step_dev, eng._g_lat_dev = None, None

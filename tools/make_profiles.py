@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs of four `bench.py` runs into the committed summaries under profiles/.
 
-    rocprofv3 --kernel-trace --stats -d D/stats -o b16 --output-format csv -- python3 bench.py --no-cpu-baseline --steps 50
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d D/fetch ... -- python3 bench.py --no-cpu-baseline --steps 20 --no-graph
+    rocprofv3 --kernel-trace --stats -d D/stats -o b16 --output-format csv -- python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --steps 50
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d D/fetch ... -- python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --steps 20 --no-graph
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d D/write ... (same)
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY \
               SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d D/sq ... (same)
@@ -43,7 +43,7 @@ def main():
     fetch = med_counter(os.path.join(base, "fetch", "b16_counter_collection.csv"), "FETCH_SIZE")
     write = med_counter(os.path.join(base, "write", "b16_counter_collection.csv"), "WRITE_SIZE")
     out = ["# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 20 "
-           "--no-cpu-baseline --no-graph (batch 16)",
+           "--no-cpu-baseline --no-pmc --no-epoch --no-graph (batch 16)",
            "# per-dispatch medians, KB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts "
            "128-B requests at 64 B, MI355X_MICROARCH.md section HBM)",
            "kernel,dispatches,FETCH_SIZE_KB_median,WRITE_SIZE_KB_median,hbm_bytes_corrected"]
@@ -74,7 +74,7 @@ def main():
     for r in csv.DictReader(open(os.path.join(base, "sq", "b16_kernel_trace.csv"))):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     ker = sorted(dur, key=lambda k: -st.median(dur[k]))[:12]
-    lines = ["SQ counters (rocprofv3 --pmc, one pass) of `python3 bench.py --steps 20 --no-cpu-baseline --no-graph`, batch 16; "
+    lines = ["SQ counters (rocprofv3 --pmc, one pass) of `python3 bench.py --steps 20 --no-cpu-baseline --no-pmc --no-epoch --no-graph`, batch 16; "
              "medians per dispatch.",
              "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 "
              "shader engines.", "",
