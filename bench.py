@@ -291,6 +291,11 @@ def run(args):
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 35 and x.shape[1] == c3)
+    # wide decoder: 16 output channels are the MFMA rows (conv16_mfma.hip)
+    probe.wrap(ops, "conv3d_g16_mfma", "conv2_fwd",
+               lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 0 and x.shape[-1] == 35)
+    probe.wrap(ops, "conv3d_g16_mfma", "conv2_bwd_data",
+               lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 3 and x.shape[-1] == 32)
     probe.wrap(ops.WgradBatch, "add", "conv2_bwd_weight",
                lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
     # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
@@ -298,8 +303,11 @@ def run(args):
     # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
     probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs: True)
     # rocprofv3 names of the kernels behind those labels (for the PMC child passes)
+    wide = c3 == 16
     kernel_names = {"wgrad_trunk5": "wgrad_mfma3_kernel", "wgrad_conv2_up2_conv1": "wgrad_mfma3_kernel",
-                    "conv2_fwd": "conv_k4_mfma", "conv2_bwd_data": "conv_k4_mfma", "conv2_bwd_weight": "wgrad_k4_mfma"}
+                    "conv2_fwd": "G16<16, 4, 1, 8, 4, 2, 1, 16, 8>" if wide else "MCv<8, 0, 1, 16, 8, 1, 4, 2, 2>",
+                    "conv2_bwd_data": "G16<16, 4, 1, 7, 1, 9, 4, 4, 7>" if wide else "MCvFlat<8, 18, 7, 4, 2, 2>",
+                    "conv2_bwd_weight": "W16<4, 1, 32, 4>" if wide else "wgrad_k4_mfma"}
 
     def barrier():
         torch.cuda.synchronize()
@@ -368,6 +376,12 @@ def run(args):
         one_epoch(2)
         barrier()
         t0 = time.perf_counter()
+        for _ in range(3):                         # the full-batch latent step alone (this rank's shard)
+            if hi > lo:
+                eng.latent_step(args.q, lo, hi)
+        barrier()
+        latent_ms = timed_max(time.perf_counter() - t0) / 3 * 1e3
+        t0 = time.perf_counter()
         nst = 0
         for ep in range(args.epochs):
             nst = one_epoch(ep)
@@ -378,7 +392,9 @@ def run(args):
                      "blocks_per_s": round(N * args.epochs / de, 1), "minibatches_per_epoch": nst,
                      "includes": "mini-batch steps (graph replay; short last batch host-launched), full-batch latent "
                                  "step, per-epoch stats read-back, eval forward + metrics on every 10th epoch",
-                     "bound_58_steps_plus_10pct_ms": None if step_ms is None else round(1.1 * nst * step_ms, 3)}
+                     "latent_step_ms": round(latent_ms, 3),
+                     "bound_steps_plus_latent_plus_10pct_ms": None if step_ms is None else round(
+                         1.1 * (nst * step_ms + latent_ms), 3)}
         if args.mode == "epoch":
             dt = de
             loss = float("nan")
