@@ -458,8 +458,10 @@ def run(args):
             "higher_is_better": True,
             "scaling": "weak" if args.mode == "step" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "launch": "host" if (graphed is None and args.mode == "step") else
-                                 "hip-graph replay (step head .. Adam in one graph)",
+                       "launch": "host" if (graphed is None and args.mode == "step") else (
+                           "hip-graph replay (step head .. backward), then all-reduce + Adam from the host"
+                           if (graphed is not None and graphed.collective == "host") else
+                           "hip-graph replay (step head .. Adam in one graph)"),
                        "collective": None if eng.grad_hook is None else
                                      ("all-reduce captured in the step graph" if (graphed is not None and graphed.collective == "graph")
                                       else "all-reduce launched from the host"),

@@ -34,34 +34,16 @@ struct MDims {
 // A-fragment packing.  gw is a gather-form weight [cin][64 taps][8] (the w_fwd layout of a conv, or its
 // w_bwd layout for the backward-data pass).  Output: wp[g][ty][tx][lane][tz (padded to KEZP)].
 // ---------------------------------------------------------------------------------------------------
-__global__ void pack_mfma_k4_kernel(const float* __restrict__ gw, float* __restrict__ wp, int cin, int pair) {
-  const int KEZ = pair == 2 ? 5 : 4, KEX = pair == 0 ? 5 : 4;
-  const int total = (cin / 4) * 4 * KEX * KEZ * 64;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    int r = idx;
-    const int lane = r % 64; r /= 64;
-    const int tz = r % KEZ; r /= KEZ;
-    const int tx = r % KEX; r /= KEX;
-    const int ty = r % 4;
-    const int g = r / 4;
-    const int i = lane & 15, cog = i >> 1, s = i & 1, ci = 4 * g + (lane >> 4);
-    const int kz = pair == 2 ? tz - s : tz, ky = ty, kx = pair == 0 ? tx - s : tx;
-    float v = 0.f;
-    if (kz >= 0 && kz < 4 && kx >= 0 && kx < 4) v = gw[(ci * 64 + (kz * 4 + ky) * 4 + kx) * 8 + cog];
-    wp[idx] = v;
-  }
-}
-
 extern "C" size_t nvf_pack_mfma_k4_floats(int cin, int pair_axis) {
   return (size_t)(cin / 4) * 4 * (pair_axis == 0 ? 5 : 4) * (pair_axis == 2 ? 5 : 4) * 64;   // 5120 per channel group
 }
 
+extern "C" int nvf_pack_mfma_k4_multi(const float* const* gather_ws, float* const* wps, const int* cins,
+                                      const int* pair_axes, int n, void* stream);
+
 extern "C" int nvf_pack_mfma_k4(const float* gather_w, int cin, int cout, int pair_axis, float* wp, void* stream) {
-  if (!gather_w || !wp || cin <= 0 || cin % 4 || cout != 8 || (pair_axis != 0 && pair_axis != 2)) return NVF_EINVAL;
-  const int total = (int)nvf_pack_mfma_k4_floats(cin, pair_axis);
-  pack_mfma_k4_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(gather_w, wp, cin, pair_axis);
-  NVF_LAUNCH_CHECK();
-  return NVF_OK;
+  if (cout != 8) return NVF_EINVAL;
+  return nvf_pack_mfma_k4_multi(&gather_w, &wp, &cin, &pair_axis, 1, stream);     // one job of the multi-packer
 }
 
 // several packings in one launch (the step engine packs conv1 / conv2, forward and backward, after every

@@ -11,13 +11,11 @@ class LoadedVoxelDataset(torch.utils.data.Dataset):
 
     def __init__(self, origin_fn, gt_fn, dist_fn, shuffle=True):
         super().__init__()
-        self.origins = np.load(origin_fn)
-        self.gt_grid = np.load(gt_fn)
-        self.dist = np.load(dist_fn)
-        self.N_leaf = self.origins.shape[0]
-        self.N = self.gt_grid.sum()
-        print(f"A total numbero of {self.N} points")
         self.shuffle = shuffle
+        self.origins, self.gt_grid, self.dist = (np.load(fn) for fn in (origin_fn, gt_fn, dist_fn))
+        self.N_leaf = self.origins.shape[0]      # leaf blocks
+        self.N = self.gt_grid.sum()              # occupied voxels = input points (b_net's denominator, NVFPCC.py:162)
+        print(f"[data] {self.N_leaf} leaf blocks, {self.N} points")
 
     def permute(self, idx):
         return (idx * self.MAGIC) % self.N_leaf if self.shuffle else idx

@@ -71,3 +71,29 @@ def test_two_ranks_through_a_real_collective_equal_one_rank(tmp_path):
     assert np.abs(one["stats"][:, [0, 2]] - two["stats"][:, [0, 2]]).max() <= 5       # tp, tn: p within 1e-6 of 0.5
     np.testing.assert_allclose(one["stats"][:, 4:11], two["stats"][:, 4:11], rtol=2e-4)
     assert (two["stats"][:, 13] == 3).all() and (two["stats"][:, 11:13] == 0).all()
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_launches_two_ranks_and_reports_the_live_world_size(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment: the script starts its two ranks itself (here over gloo,
+    both on GPU 0 -- the numbers mean nothing, the path is the driver's N > 1 path: barriers, MAX over ranks, the
+    sharded epoch), and rank 0's JSON line reports the size of the LIVE process group."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    env = dict(os.environ, PYTHONPATH=ROOT, NVF_DIST_BACKEND="gloo", NVF_DEVICE_OVERRIDE="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+                        "--epochs", "1", "--blocks", "61", "--distinct", "61", "--no-pmc", "--no-cpu-baseline"],
+                       env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["scaling"] == "weak" and d["steps"] == 12 and d["value"] > 0 and np.isfinite(d["loss_last_step"])
+    assert d["config"]["collective"] == "all-reduce launched from the host"
+    # 61 blocks at a global mini-batch of 32: one full mini-batch and a short one of 29 (15 + 14 blocks)
+    assert d["epoch"]["minibatches_per_epoch"] == 2 and d["epoch"]["blocks_per_s"] > 0
