@@ -478,20 +478,53 @@ int nvf_head_wgrad_launch(const float* dl, const float* x, float* slabs, int max
   return 1;
 }
 
-// ---- three-head launches (narrow decoder: conv0_cls on [16, 8^3], conv1_cls on [8, 16^3], conv2_cls on [8, 32^3]) ----
-extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, const float* const* biases,
-                              float* const* ps, const int* cs, const int* ss, int batch, int act, void* stream) {
-  if (!xs || !ws || !biases || !ps || !cs || !ss || batch <= 0) return NVF_EINVAL;
-  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
-  using H0 = HCfg<16, 8, 4, 8>; using H1 = HCfg<8, 16, 4, 4>; using H2 = HCfg<8, 32, 4, 8>;
+// ---- three-head launches: conv0_cls, conv1_cls, conv2_cls of the narrow decoder ([16, 8^3], [8, 16^3], [8, 32^3]) or
+// of the wide one ([32, 8^3], [16, 16^3], [16, 32^3]) ----
+static int heads3_tuple(const int* cs, const int* ss) {      // 0 narrow, 1 wide, -1 neither
+  if (ss[0] != 8 || ss[1] != 16 || ss[2] != 32) return -1;
+  if (cs[0] == 16 && cs[1] == 8 && cs[2] == 8) return 0;
+  if (cs[0] == 32 && cs[1] == 16 && cs[2] == 16) return 1;
+  return -1;
+}
+template <class H>
+static constexpr int head_tiles() { return (H::S / H::TZ) * (H::S / H::TY); }
+
+template <class H0, class H1, class H2>
+static int heads3_fwd_t(const float* const* xs, const float* const* ws, const float* const* biases, float* const* ps,
+                        int batch, int act, void* stream) {
+  static_assert(H0::NT == 256 && H1::NT == 256 && H2::NT == 256, "one workgroup size");
   Heads3 m{};
   for (int h = 0; h < 3; ++h) {
     if (!xs[h] || !ws[h] || !ps[h]) return NVF_EINVAL;
     m.a[h] = xs[h]; m.w[h] = ws[h]; m.bias[h] = biases[h]; m.out[h] = ps[h];
   }
-  m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
+  m.n[0] = batch * head_tiles<H0>(); m.n[1] = batch * head_tiles<H1>(); m.n[2] = batch * head_tiles<H2>();
   m.act = act;
   heads3_fwd_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, const float* const* biases,
+                              float* const* ps, const int* cs, const int* ss, int batch, int act, void* stream) {
+  if (!xs || !ws || !biases || !ps || !cs || !ss || batch <= 0) return NVF_EINVAL;
+  const int t = heads3_tuple(cs, ss);
+  if (t == 0) return heads3_fwd_t<HCfg<16, 8, 4, 8>, HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
+  if (t == 1) return heads3_fwd_t<HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 2, 8>>(xs, ws, biases, ps, batch, act, stream);
+  return NVF_EINVAL;
+}
+
+template <class H0, class H1, class H2>
+static int heads3_bwd_data_t(const float* const* dls, const float* const* wbs, float* const* dxs,
+                             const float* const* masks, int batch, void* stream) {
+  static_assert(H0::NT == 256 && H1::NT == 256 && H2::NT == 256, "one workgroup size");
+  Heads3 m{};
+  for (int h = 0; h < 3; ++h) {
+    if (!dls[h] || !wbs[h] || !dxs[h]) return NVF_EINVAL;
+    m.a[h] = dls[h]; m.w[h] = wbs[h]; m.out[h] = dxs[h]; m.mask[h] = masks[h];
+  }
+  m.n[0] = batch * head_tiles<H0>(); m.n[1] = batch * head_tiles<H1>(); m.n[2] = batch * head_tiles<H2>();
+  heads3_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
@@ -500,17 +533,10 @@ extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, co
 extern "C" int nvf_heads3_bwd_data(const float* const* dls, const float* const* wbs, float* const* dxs,
                                    const float* const* masks, const int* cs, const int* ss, int batch, void* stream) {
   if (!dls || !wbs || !dxs || !masks || !cs || !ss || batch <= 0) return NVF_EINVAL;
-  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
-  using H0 = HCfg<16, 8, 4, 8>; using H1 = HCfg<8, 16, 4, 4>; using H2 = HCfg<8, 32, 4, 8>;
-  Heads3 m{};
-  for (int h = 0; h < 3; ++h) {
-    if (!dls[h] || !wbs[h] || !dxs[h]) return NVF_EINVAL;
-    m.a[h] = dls[h]; m.w[h] = wbs[h]; m.out[h] = dxs[h]; m.mask[h] = masks[h];
-  }
-  m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
-  heads3_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m);
-  NVF_LAUNCH_CHECK();
-  return NVF_OK;
+  const int t = heads3_tuple(cs, ss);
+  if (t == 0) return heads3_bwd_data_t<HCfg<16, 8, 4, 8>, HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>>(dls, wbs, dxs, masks, batch, stream);
+  if (t == 1) return heads3_bwd_data_t<HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 4, 8>>(dls, wbs, dxs, masks, batch, stream);
+  return NVF_EINVAL;
 }
 
 struct Heads3Loss { HeadLoss h[3]; };
@@ -533,21 +559,16 @@ extern "C" size_t nvf_reduce_workspace(void);
 // dls[h] = d term_h / d logit_h (also consumed in place: dxs[h] is nvf_heads3_bwd_data of it), loss[slots[h]] = term_h.
 // Heads as in nvf_heads3_fwd; dists[h] may be NULL; batch * 32 workgroups of the big head must fit the reduction
 // workspace (batch <= 32), otherwise NVF_EINVAL and the caller uses nvf_focal_loss_multi + nvf_heads3_bwd_data.
-extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, const float* const* dists,
-                                        const float* alphas, const float* betas, const int* slots, float* loss,
-                                        float* const* dls, const float* const* wbs, float* const* dxs,
-                                        const float* const* masks, const int* cs, const int* ss, int batch,
-                                        void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
-  if (!ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs || !masks || !cs || !ss ||
-      !workspace || batch <= 0)
-    return NVF_EINVAL;
-  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
-  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
-  using H0 = HCfg<16, 8, 4, 8>; using H1 = HCfg<8, 16, 4, 4>; using H2 = HCfg<8, 32, 4, 8>;
+template <class H0, class H1, class H2>
+static int heads3_loss_bwd_data_t(const float* const* ps, const float* const* gts, const float* const* dists,
+                                  const float* alphas, const float* betas, const int* slots, float* loss,
+                                  float* const* dls, const float* const* wbs, float* const* dxs,
+                                  const float* const* masks, int batch, void* workspace, NvfStepCtx* ctx, void* stream) {
+  static_assert(H0::NT == 256 && H1::NT == 256 && H2::NT == 256, "one workgroup size");
   Heads3 m{};
   Heads3Loss f{};
   FocalMulti fm{};
-  m.n[0] = batch * (8 / 4) * (8 / 8); m.n[1] = batch * (16 / 4) * (16 / 4); m.n[2] = batch * (32 / 4) * (32 / 8);
+  m.n[0] = batch * head_tiles<H0>(); m.n[1] = batch * head_tiles<H1>(); m.n[2] = batch * head_tiles<H2>();
   for (int h = 0; h < 3; ++h) {
     if (!ps[h] || !gts[h] || !dls[h] || !wbs[h] || !dxs[h] || slots[h] < 0 || slots[h] > 2 || m.n[h] > kLossMaxWG)
       return NVF_EINVAL;
@@ -563,13 +584,33 @@ extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* con
   return nvf_finals_run_focal(ctx, fm, (const float*)workspace, loss, 3, stream);
 }
 
+extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, const float* const* dists,
+                                        const float* alphas, const float* betas, const int* slots, float* loss,
+                                        float* const* dls, const float* const* wbs, float* const* dxs,
+                                        const float* const* masks, const int* cs, const int* ss, int batch,
+                                        void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
+  if (!ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs || !masks || !cs || !ss ||
+      !workspace || batch <= 0)
+    return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  const int t = heads3_tuple(cs, ss);
+  if (t == 0)
+    return heads3_loss_bwd_data_t<HCfg<16, 8, 4, 8>, HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>>(
+        ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, ctx, stream);
+  if (t == 1)
+    return heads3_loss_bwd_data_t<HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 4, 8>>(
+        ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, ctx, stream);
+  return NVF_EINVAL;
+}
+
 // partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)
-template <class H2>
+template <class H0, class H1, class H2>
 static int launch_heads3_wgrad(const float* const* dls, const float* const* xs, float* const* slabs, int batch,
                                int max_slabs, int* nslabs, void* stream) {
-  using H0 = HWCfg<16, 8, 4, 8, 4>; using H1 = HWCfg<8, 16, 4, 4, 2>;
+  static_assert(H0::NT == 256 && H1::NT == 256 && H2::NT == 256, "one workgroup size");
   Heads3 m{};
-  const int items[3] = {batch * (8 / 4) * (8 / 8), batch * (16 / 4) * (16 / 4), batch * (32 / H2::TZ) * (32 / H2::TY)};
+  const int items[3] = {batch * (H0::S / H0::TZ) * (H0::S / H0::TY), batch * (H1::S / H1::TZ) * (H1::S / H1::TY),
+                        batch * (H2::S / H2::TZ) * (H2::S / H2::TY)};
   for (int h = 0; h < 3; ++h) {
     if (!dls[h] || !xs[h] || !slabs[h]) return NVF_EINVAL;
     m.a[h] = dls[h]; m.w[h] = xs[h]; m.out[h] = slabs[h];
@@ -589,9 +630,14 @@ extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* co
                                         const int* cs, const int* ss, int batch, int max_slabs, int* nslabs,
                                         void* stream) {
   if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
-  if (cs[0] != 16 || ss[0] != 8 || cs[1] != 8 || ss[1] != 16 || cs[2] != 8 || ss[2] != 32) return NVF_EINVAL;
+  const int t = heads3_tuple(cs, ss);
   // the big head in 2 x 8-row tiles: larger tiles (4 x 8, 2 x 16, 8 x 8) re-read less halo but were 10-30 % slower --
   // the kernel is bound by how many staging round trips are in flight, not by bytes
-  return launch_heads3_wgrad<HWCfg<8, 32, 2, 8, 2>>(dls, xs, slabs, batch, max_slabs, nslabs, stream);
+  if (t == 0)
+    return launch_heads3_wgrad<HWCfg<16, 8, 4, 8, 4>, HWCfg<8, 16, 4, 4, 2>, HWCfg<8, 32, 2, 8, 2>>(
+        dls, xs, slabs, batch, max_slabs, nslabs, stream);
+  if (t == 1)
+    return launch_heads3_wgrad<HWCfg<32, 8, 4, 8, 8>, HWCfg<16, 16, 4, 4, 4>, HWCfg<16, 32, 2, 8, 4>>(
+        dls, xs, slabs, batch, max_slabs, nslabs, stream);
+  return NVF_EINVAL;
 }
-

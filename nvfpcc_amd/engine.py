@@ -108,8 +108,10 @@ class TrainEngine:
         self.metrics_acc = None   # float[6] epoch accumulator of tp, ap, tn, an, sse, denom (NVFPCC.py train logging)
         self.epoch_acc = None     # float[8] epoch sums written by nvf_step_tail (enable_epoch_stats)
         self.collective_mode = None   # "graph" / "host": where GraphedTrainStep puts the all-reduce (dist.attach)
-        # the three classifier heads of the narrow decoder go through the one-launch kernels
-        self.heads3 = tuple(net.reconstructor.channels) == (8, 16, 8, 8)
+        # the three classifier heads go through the one-launch kernels (instantiated for the two decoders of BASELINE.json);
+        # the one-launch trunk weight gradients exist for the narrow decoder only
+        self.narrow = tuple(net.reconstructor.channels) == (8, 16, 8, 8)
+        self.heads3 = self.narrow or tuple(net.reconstructor.channels) == (16, 32, 16, 16)
 
     # ------------------------------------------------------------------ parameters
     def _flatten_parameters(self):
@@ -427,7 +429,7 @@ class TrainEngine:
 
         if not self.heads3:
             g5 = self._dx_conv(Ls["conv2_cls"], dl2, a["y5"], mask=a["y5"])
-        wg3 = want_w and self.heads3 and _NAIVE_OFF()      # conv2 / up2 / conv1 weight gradients in one launch
+        wg3 = want_w and self.narrow and _NAIVE_OFF()      # conv2 / up2 / conv1 weight gradients in one launch
         if not wg3:
             side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
         g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])

@@ -126,12 +126,16 @@ def test_conv_transpose_k5s2_mfma_backward_data(ops, cin, n, B):
     assert torch.equal(one[0], dx[1])
 
 
-def test_three_head_launches_equal_the_single_head_kernels(ops):
+HEAD_TUPLES = {"narrow": [(16, 8), (8, 16), (8, 32)], "wide": [(32, 8), (16, 16), (16, 32)]}
+
+
+@pytest.mark.parametrize("which", ["narrow", "wide"])
+def test_three_head_launches_equal_the_single_head_kernels(ops, which):
     """nvf_heads3_* run the same kernel bodies as the per-head calls: forward, backward-data and weight gradients
-    must agree bit for bit."""
+    must agree bit for bit -- for the heads of both decoders (chanstr 8,16,8,8 and 16,32,16,16)."""
     g = gen(7000)
     B = 3
-    shapes = [(16, 8), (8, 16), (8, 32)]
+    shapes = HEAD_TUPLES[which]
     xs = [dev(torch.randn(B, c, s, s, s, generator=g)) for c, s in shapes]
     ws = [torch.randn(1, c, 3, 3, 3, generator=g) * 0.1 for c, s in shapes]
     bs = [dev(torch.randn(1, generator=g)) for _ in shapes]
@@ -752,13 +756,14 @@ def test_two_step_contexts_do_not_interfere(ops):
     assert not torch.equal(got[0]["loss"][:1], got[1]["loss"][:1])
 
 
-def test_heads_loss_and_backward_data_in_one_launch(ops):
+@pytest.mark.parametrize("which", ["narrow", "wide"])
+def test_heads_loss_and_backward_data_in_one_launch(ops, which):
     """nvf_heads3_loss_bwd_data against nvf_focal_loss_multi + nvf_heads3_bwd_data: the logit gradients and the
     heads' input gradients are the same bits (same elementwise code, same stencil order); the three loss sums agree
     to fp32 summation order."""
     torch.manual_seed(11)
     B = 3
-    shapes = [(16, 8), (8, 16), (8, 32)]
+    shapes = HEAD_TUPLES[which]
     ps = [torch.rand(B, 1, s, s, s, device="cuda") for c, s in shapes]
     ps[2][0, 0, :2] = 0.0                      # saturated probabilities hit the 1e-9 clamp
     ps[1][1, 0, 3] = 1.0
@@ -766,7 +771,7 @@ def test_heads_loss_and_backward_data_in_one_launch(ops):
     dist = torch.rand(B, 1, 32, 32, 32, device="cuda")
     ws = [torch.randn(1, c, 3, 3, 3, device="cuda") for c, s in shapes]
     wbs = [ops.pack_conv_weight(w)[1] for w in ws]
-    mask = torch.randn(B, 8, 32, 32, 32, device="cuda")
+    mask = torch.randn(B, shapes[2][0], 32, 32, 32, device="cuda")
     cs = [c for c, s in shapes]
     loss_ref = torch.empty(4, device="cuda")
     dl2, dl0, dl1 = ops.focal_loss_multi([(ps[2], gts[2], dist, 0.9, 1.0), (ps[0], gts[0], None, 0.85, 0.0),
