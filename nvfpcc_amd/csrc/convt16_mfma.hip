@@ -10,9 +10,10 @@
 //   address(cell p, jy, jx) = p - jy * NCELL - jx + const
 // is linear in p: any 16 consecutive cells are one conflict-free ds_read_b32, and 18- / 10-cell rows cost no padding
 // columns.  All input channels of the three planes cz-2 .. cz stay in LDS for an item; the A fragments (125 per
-// channel group) stream through two LDS buffers by LDS-DMA, group g + 1 in flight during the MFMAs of group g.
+// channel group) come straight from the packed weights in L2 into registers, one (jy, jx) tap column ahead of their use.
 // Per output the accumulation order is fixed: (channel group, jy, jx, jz) -- independent of batch and tiling.
 #include "nvf_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -56,22 +57,18 @@ struct T16 {
   static constexpr int CS = cs_for(3 * PLANE);                 // channel stride: second channel -> banks 16..31
   static constexpr int NG = CIN / 4;
   static constexpr int XS = CIN * CS;                          // input image (all channels, three planes)
-  static constexpr int AS = kA16 * 64;                         // A fragments of one channel group
-  static_assert((XS + 2 * AS) * 4 <= 160 * 1024, "LDS");
-  static constexpr int AIT = (AS / 64 + NW - 1) / NW;          // A DMA instructions per wave per group
+  static_assert(XS * 4 <= 80 * 1024, "LDS: two workgroups per CU");
 };
 
 template <class T>
-__global__ __launch_bounds__(256) void convT16_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ y, int act,
                                                          int items) {
   constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
-                NG = T::NG, NOUT = 2 * NIN + 3, AS = T::AS;
+                NG = T::NG, NOUT = 2 * NIN + 3;
   __shared__ __attribute__((aligned(16))) float xs[T::XS];
-  __shared__ __attribute__((aligned(16))) float as[2 * AS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned as0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)as;
   constexpr int ITEMS = CIN * 3 * NIN * NIN / 4;               // float4 input loads of an item
   constexpr int NX4 = (ITEMS + 255) / 256;
   float4 xv[NX4];
@@ -99,24 +96,35 @@ __global__ __launch_bounds__(256) void convT16_k5s2_mfma(const float* __restrict
       }
     }
   };
-  auto stage_a = [&](int g, int buf) {                         // 125 fragments of 64 floats: one DMA instruction each
-#pragma unroll
-    for (int i = 0; i < T::AIT; ++i) {
-      const int f = i * T::NW + wave;
-      if (f < kA16) nvf_glds_lane(wp + ((size_t)g * kA16 + f) * 64 + lane, as0 + (unsigned)(buf * AS + f * 64) * 4u);
-    }
-  };
   if ((int)blockIdx.x < items) load_x(blockIdx.x);
   for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-  stage_a(0, 0);
   const int j = lane & 15, kq = lane >> 4;
   const size_t cstride = (size_t)NOUT * NOUT * NOUT;
-  int abuf = 0;
+  const float* wl = wp + lane;
+  // A fragments of one (jy, jx) tap column: jz = 0..2 x the parity classes that use the tap (<= 20), straight from the
+  // packed weights in L2 into registers, one tap column ahead of the MFMAs that use them (no LDS: the 77 KB input image
+  // leaves room for a second workgroup on the CU, whose MFMAs cover this one's staging and epilogue)
+  float ac[20], an[20];
+  auto load_a = [&](auto jyc, auto jxc, int g, float (&dst)[20]) {
+    constexpr int jy = decltype(jyc)::value, jx = decltype(jxc)::value;
+    int n = 0;
+#pragma unroll
+    for (int jz = 0; jz < 3; ++jz)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
+        if (jz <= 2 - ez && jy <= 2 - ey && jx <= 2 - ex)
+          dst[n++] = wl[((size_t)g * kA16 + a16_index(ez, ey, ex, jz, jy, jx)) * 64];
+      }
+  };
 #pragma unroll 1
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int split = item % T::NSPLIT, cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
     __syncthreads();                                           // zero fill done / the previous item's reads done
     store_x();
+    load_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, ac);
+    __syncthreads();
+    if (item + (int)gridDim.x < items) load_x(item + gridDim.x);   // in flight under this item's MFMAs
     f32x4 acc[NCT][8];
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -132,37 +140,43 @@ __global__ __launch_bounds__(256) void convT16_k5s2_mfma(const float* __restrict
     }
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's A fragments of group g have landed
-      __syncthreads();                                              // ... everyone's (and the input image is written)
-      // next group's fragments (or the next item's first group) into the other buffer, in flight during the MFMAs
-      if (g + 1 < NG) stage_a(g + 1, abuf ^ 1);
-      else if (item + (int)gridDim.x < items) stage_a(0, abuf ^ 1);
-      // the next item's input planes travel to registers under this item's MFMAs (issued behind the wait above, so
-      // that wait does not expose their latency)
-      if (g == 0 && item + (int)gridDim.x < items) load_x(item + gridDim.x);
       const float* xg = xs + g * 4 * CS;
-      const float* ag = as + abuf * AS + lane;
+      auto column = [&](auto jyc, auto jxc, auto nyc, auto nxc, bool last) {
+        constexpr int jy = decltype(jyc)::value, jx = decltype(jxc)::value;
+        // prefetch the next tap column's fragments: (jy, jx + 1) ... or the first column of the next channel group
+        if (!last) load_a(nyc, nxc, g, an);
+        else if (g + 1 < NG) load_a(nyc, nxc, g + 1, an);
+        int n = 0;
 #pragma unroll
-      for (int jy = 0; jy < 3; ++jy)
+        for (int jz = 0; jz < 3; ++jz) {
+          float bv[NCT];
 #pragma unroll
-        for (int jx = 0; jx < 3; ++jx)
+          for (int c = 0; c < NCT; ++c) bv[c] = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // plane cz - jz
 #pragma unroll
-          for (int jz = 0; jz < 3; ++jz) {
-            float bv[NCT];
+          for (int e = 0; e < 8; ++e) {
+            const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
+            if (jz <= 2 - ez && jy <= 2 - ey && jx <= 2 - ex) {
+              const float a = ac[n++];
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) bv[c] = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // plane cz - jz
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
-              if (jz <= 2 - ez && jy <= 2 - ey && jx <= 2 - ex) {
-                const float a = ag[a16_index(ez, ey, ex, jz, jy, jx) * 64];
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c], acc[c][e], 0, 0, 0);
-              }
+              for (int c = 0; c < NCT; ++c) acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c], acc[c][e], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
           }
-      abuf ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < 20; ++i) ac[i] = an[i];
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      column(I0{}, I0{}, I0{}, I1{}, false);
+      column(I0{}, I1{}, I0{}, I2{}, false);
+      column(I0{}, I2{}, I1{}, I0{}, false);
+      column(I1{}, I0{}, I1{}, I1{}, false);
+      column(I1{}, I1{}, I1{}, I2{}, false);
+      column(I1{}, I2{}, I2{}, I0{}, false);
+      column(I2{}, I0{}, I2{}, I1{}, false);
+      column(I2{}, I1{}, I2{}, I2{}, false);
+      column(I2{}, I2{}, I0{}, I0{}, true);
     }
     // epilogue: lane holds rows co = 4 kq + r of cell p for each parity class
 #pragma unroll
@@ -210,7 +224,7 @@ extern "C" int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const fl
   if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
     using T = T16<CI, NIN, NCT>;                                                                       \
     const int items = batch * T::NCELL * T::NSPLIT;                                                    \
-    convT16_k5s2_mfma<T><<<items < 256 ? items : 256, 256, 0, s>>>(x, wp, bias, y, act, items);        \
+    convT16_k5s2_mfma<T><<<items < 512 ? items : 512, 256, 0, s>>>(x, wp, bias, y, act, items);   /* 2 per CU */        \
     rc = NVF_OK;                                                                                       \
   }
   NVF_T16(0, 16, 16, 2)      // up2: 21 column tiles per cell plane, 8 per workgroup

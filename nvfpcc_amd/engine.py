@@ -558,18 +558,17 @@ class TrainEngine:
             raise ValueError("Problem with grad: %d non-finite gradient entries this epoch" % int(both[6 + 6]))
         return both[:6], both[6:]
 
-    def _tail(self, n_pts, coef_dev=None, g_lat_dev=None):
-        """All-reduce hook (data parallelism), then Adam (+ the epoch sums): nvf_step_tail."""
+    def _tail(self, n_pts):
+        """All-reduce hook (data parallelism), then Adam (+ the epoch sums): nvf_step_tail with host coefficients."""
         if self.grad_hook is not None:
             self.grad_hook(self.flat_g)
         self.opt_step += 1
-        coef = (0.0, 0.0) if coef_dev is not None else ops.adam_coefficients(self.lr, self.opt_step)
         t = self.last
         stats = self.epoch_acc is not None
-        ops.step_tail(self.flat_p, self.flat_g, self.flat_m, self.flat_v, coef_dev, coef,
+        ops.step_tail(self.flat_p, self.flat_g, self.flat_m, self.flat_v, None,
+                      ops.adam_coefficients(self.lr, self.opt_step),
                       loss_terms=t["loss_terms"] if stats else None, lbits=t["latent_bits"] if stats else None,
-                      nbits=t["net_bits"] if stats else None, g_lat_dev=g_lat_dev,
-                      lbits_scale=(1.0 / (self.lmbda * self.w1)) if g_lat_dev is not None else 1.0 / n_pts,
+                      nbits=t["net_bits"] if stats else None, lbits_scale=1.0 / n_pts,
                       nbits_scale=1.0 / self.n_points_total, acc=self.epoch_acc)
 
     def _idle_backward(self):
