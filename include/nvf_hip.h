@@ -142,7 +142,8 @@ int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, const float
  * network.py:621).  Rows of the MFMA tile are the output channels (no pairing), K = four input channels.  Same
  * contract as nvf_conv3d_gather; the weights are A fragments of the packed gather weight:
  *   nvf_pack_g16_mfma(gather_w [cin][k^3][cout] (= w_fwd, or w_bwd for a backward-data pass), cin, cout, k, wp),
- *   nvf_pack_g16_mfma_floats(cin, cout, k) floats, layout [cout/16][cin/4][tap][lane].
+ *   nvf_pack_g16_mfma_floats(cin, cout, k) floats, layout [ceil(cout/16)][cin/4][tap][lane]; cout = 8 is accepted too
+ *   (rows 8..15 of the tile are zero weights and are not stored).
  * Fixed per-output accumulation order (channel group, kz, ky, kx): independent of batch and tiling.
  * NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_conv3d_gather). */
 size_t nvf_pack_g16_mfma_floats(int cin, int cout, int k);
@@ -151,18 +152,19 @@ int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float* bias, floa
                         const float* mask, int batch, int cin, int cout, int k, int stride, int pad, int din, int hin,
                         int win, int dout, int hout, int wout, int act, int variant, void* stream);
 
-/* ---- matrix-core form of the transposed convolutions k5 s2 with 16 output channels and padding 0 (up1 / up2 of
- * chanstr 16,32,16,16; F.conv_transpose3d network.py:621): the output channels are the MFMA rows, the eight
- * sub-pixel parity classes separate accumulators fed by one B fragment.  Same contract as nvf_convT3d_k5s2_fwd;
- * weights: nvf_pack_convT16_mfma(w_fwd [cin][125][16], cin, 16, wp), nvf_pack_convT16_mfma_floats(cin) floats.
+/* ---- matrix-core form of the transposed convolutions k5 s2 with 16 / 32 output channels (all four of chanstr
+ * 16,32,16,16: up1 / up2 with padding 0, conv0 / up0 with padding 2 and output_padding 1; F.conv_transpose3d
+ * network.py:621): the output channels are the MFMA rows, the eight sub-pixel parity classes separate accumulators
+ * fed by one B fragment.  Same contract as nvf_convT3d_k5s2_fwd; weights: nvf_pack_convT16_mfma(w_fwd
+ * [cin][125][cout], cin, cout, wp), nvf_pack_convT16_mfma_floats(cin, cout) floats, layout [cout/16][cin/4][125][lane].
  * Fixed per-output accumulation order (input-channel group, jy, jx, jz).  NVF_EINVAL = no instantiation. */
-size_t nvf_pack_convT16_mfma_floats(int cin);
+size_t nvf_pack_convT16_mfma_floats(int cin, int cout);
 int nvf_pack_convT16_mfma(const float* w_fwd, int cin, int cout, float* wp, void* stream);
 int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const float* bias, float* y, int batch, int cin, int cout,
-                            int din, int act, int variant, void* stream);
+                            int pad, int din, int act, int variant, void* stream);
 
 /* every MFMA weight packing of a step in one launch (<= 12 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
- * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 11 = nvf_pack_convT16_mfma (c0 = cin),
+ * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout),
  * 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog),
  * 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout) */
 int nvf_pack_mfma_all(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s, const int* c1s,

@@ -38,9 +38,9 @@ PROTOTYPES = {
     "nvf_pack_s2k5_mfma_floats": (Z, [I, I]),
     "nvf_pack_s2k5_mfma": (I, [P, I, I, P, P]),
     "nvf_conv3d_s2k5_mfma": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
-    "nvf_pack_convT16_mfma_floats": (Z, [I]),
+    "nvf_pack_convT16_mfma_floats": (Z, [I, I]),
     "nvf_pack_convT16_mfma": (I, [P, I, I, P, P]),
-    "nvf_convT3d_k5s2_mfma16": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "nvf_convT3d_k5s2_mfma16": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "nvf_pack_g16_mfma_floats": (Z, [I, I, I]),
     "nvf_pack_g16_mfma": (I, [P, I, I, I, P, P]),
     "nvf_conv3d_g16_mfma": (I, [P, P, P, P, P, P] + [I] * 14 + [P]),

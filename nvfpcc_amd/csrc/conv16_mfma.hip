@@ -83,7 +83,7 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   // work item: (batch element, output-channel group of 16, tile)
-  const int ntile = d.tiles_x * d.tiles_y * d.tiles_z, ncog = d.cout >> 4;
+  const int ntile = d.tiles_x * d.tiles_y * d.tiles_z, ncog = (d.cout + 15) >> 4;
   int wi = blockIdx.x;
   const int tile = wi % ntile; wi /= ntile;
   const int cog = wi % ncog, b = wi / ncog;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
     float bv4[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) bv4[r4] = bias[co0 + r4];
+      for (int r4 = 0; r4 < 4; ++r4) bv4[r4] = co0 + r4 < d.cout ? bias[co0 + r4] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
       const size_t o = ((size_t)b * d.cout + co0) * ovol + ((size_t)oz * d.hout + oy) * d.wout + ox;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
+        if (co0 + r4 >= d.cout) continue;            // rows past an 8-channel output (zero weights) are not stored
         const size_t oo = o + (size_t)r4 * ovol;
         float v = nvf_act(acc[r][r4] + bv4[r4], d.act);
         if (addend) v += addend[oo];
@@ -218,14 +219,14 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
 }
 
 __global__ void pack_g16_kernel(const float* __restrict__ gw, float* __restrict__ wp, int cin, int cout, int k3) {
-  const int total = (cout / 16) * (cin / 4) * k3 * 64;
+  const int total = ((cout + 15) / 16) * (cin / 4) * k3 * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     int r = idx;
     const int lane = r % 64; r /= 64;
     const int tap = r % k3; r /= k3;
     const int g = r % (cin / 4), cog = r / (cin / 4);
     const int ci = 4 * g + (lane >> 4), co = cog * 16 + (lane & 15);
-    wp[idx] = gw[((size_t)ci * k3 + tap) * cout + co];
+    wp[idx] = co < cout ? gw[((size_t)ci * k3 + tap) * cout + co] : 0.f;      // 8 outputs: rows 8..15 are zero
   }
 }
 
@@ -235,21 +236,21 @@ int launch_g16(const float* x, const float* wp, const float* bias, float* y, con
   d.tiles_x = (d.wout + C::OX - 1) / C::OX;
   d.tiles_y = (d.hout + C::OY - 1) / C::OY;
   d.tiles_z = (d.dout + C::OZ - 1) / C::OZ;
-  const long grid = (long)d.tiles_x * d.tiles_y * d.tiles_z * (d.cout / 16) * batch;
+  const long grid = (long)d.tiles_x * d.tiles_y * d.tiles_z * ((d.cout + 15) / 16) * batch;
   conv_g16_mfma<C><<<(unsigned)grid, C::NT, 0, s>>>(x, wp, bias, y, addend, mask, d);
   return NVF_OK;
 }
 
 }  // namespace
 
-// A fragments of a gather-form weight gw [cin][k^3][cout] (cout a multiple of 16): wp[cog][g][tap][lane],
+// A fragments of a gather-form weight gw [cin][k^3][cout] (cout a multiple of 16, or 8: rows 8..15 zero): wp[cog][g][tap][lane],
 // lane = (ci & 3) * 16 + (co & 15)
 extern "C" size_t nvf_pack_g16_mfma_floats(int cin, int cout, int k) {
-  return (size_t)(cout / 16) * (cin / 4) * k * k * k * 64;
+  return (size_t)((cout + 15) / 16) * (cin / 4) * k * k * k * 64;
 }
 
 extern "C" int nvf_pack_g16_mfma(const float* gather_w, int cin, int cout, int k, float* wp, void* stream) {
-  if (!gather_w || !wp || cin <= 0 || cin % 4 || cout <= 0 || cout % 16 || k <= 0) return NVF_EINVAL;
+  if (!gather_w || !wp || cin <= 0 || cin % 4 || cout <= 0 || (cout % 16 && cout != 8) || k <= 0) return NVF_EINVAL;
   const int total = (int)nvf_pack_g16_mfma_floats(cin, cout, k);
   pack_g16_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(gather_w, wp, cin, cout, k * k * k);
   NVF_LAUNCH_CHECK();
@@ -263,7 +264,7 @@ extern "C" int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float*
                                    const float* mask, int batch, int cin, int cout, int k, int stride, int pad,
                                    int din, int hin, int win, int dout, int hout, int wout, int act, int variant,
                                    void* stream) {
-  if (!x || !wp || !y || batch <= 0 || cout <= 0 || cout % 16) return NVF_EINVAL;
+  if (!x || !wp || !y || batch <= 0 || cout <= 0 || (cout % 16 && cout != 8)) return NVF_EINVAL;
   G16Dims d{din, hin, win, dout, hout, wout, pad, act, cout, 0, 0, 0};
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
@@ -278,6 +279,7 @@ extern "C" int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float*
   NVF_G16(0, 16, 5, 2, 9, 16, 2, 8, 1, 1, 16, 4)      // up2 backward-data (35^3 -> 16^3) (58 us)
   NVF_G16(0, 16, 5, 2, 5, 8, 1, 4, 1, 2, 8, 4)        // up1 backward-data (19^3 -> 8^3, 32 output channels)
   NVF_G16(0, 32, 5, 2, 3, 4, 4, 1, 1, 4, 4, 4)        // conv0 backward-data (8^3 -> 4^3, padding 2)
+  NVF_G16(0, 16, 5, 2, 1, 2, 2, 1, 1, 4, 4, 2)        // up0 backward-data (4^3 -> 2^3, padding 2; 8 output channels)
   // tuning alternatives
   NVF_G16(2, 16, 4, 1, 21, 32, 4, 8, 2, 1, 16, 4)
   NVF_G16(3, 16, 4, 1, 21, 32, 2, 8, 2, 1, 16, 4)

@@ -27,10 +27,11 @@ __host__ __device__ constexpr int a16_index(int ez, int ey, int ex, int jz, int 
   return base + (jz * (3 - ey) + jy) * (3 - ex) + jx;
 }
 
-__global__ void pack_convT16_kernel(const float* __restrict__ wf /* [cin][125][16] */, float* __restrict__ wp, int cin) {
-  const int total = (cin / 4) * kA16 * 64;
+__global__ void pack_convT16_kernel(const float* __restrict__ wf /* [cin][125][cout] */, float* __restrict__ wp, int cin,
+                                    int cout) {
+  const int total = (cout / 16) * (cin / 4) * kA16 * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int lane = idx % 64, f = (idx / 64) % kA16, g = idx / (64 * kA16);
+    const int lane = idx % 64, f = (idx / 64) % kA16, gg = idx / (64 * kA16), g = gg % (cin / 4), cog = gg / (cin / 4);
     int cls = 0, r = f;
     for (;; ++cls) {
       const int n = (3 - (cls >> 2)) * (3 - ((cls >> 1) & 1)) * (3 - (cls & 1));
@@ -39,16 +40,19 @@ __global__ void pack_convT16_kernel(const float* __restrict__ wf /* [cin][125][1
     }
     const int ez = cls >> 2, ey = (cls >> 1) & 1, ex = cls & 1;
     const int jx = r % (3 - ex), jy = (r / (3 - ex)) % (3 - ey), jz = r / ((3 - ex) * (3 - ey));
-    const int co = lane & 15, ci = 4 * g + (lane >> 4);
+    const int co = cog * 16 + (lane & 15), ci = 4 * g + (lane >> 4);
     const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
-    wp[idx] = wf[(ci * 125 + (kz * 5 + ky) * 5 + kx) * 16 + co];
+    wp[idx] = wf[(ci * 125 + (kz * 5 + ky) * 5 + kx) * cout + co];
   }
 }
 
-template <int CIN_, int NIN_, int NCT_>
+// PAD_ = 0: outputs 2 NIN + 3 (up1 / up2); PAD_ = 2 (with output_padding 1): outputs 2 NIN, o = 2 c + e - 2 (conv0,
+// up0): the same cells are computed and the out-of-range border is not stored.  COUT_ = 16 or 32 (two row groups).
+template <int CIN_, int NIN_, int NCT_, int PAD_ = 0, int COUT_ = 16>
 struct T16 {
-  static constexpr int CIN = CIN_, NIN = NIN_, NCT = NCT_;
-  static constexpr int NCELL = NIN + 2;                        // cells per axis; outputs 2 NIN + 3
+  static constexpr int CIN = CIN_, NIN = NIN_, NCT = NCT_, PAD = PAD_, COUT = COUT_;
+  static constexpr int NOUT = PAD == 0 ? 2 * NIN + 3 : 2 * NIN;
+  static constexpr int NCELL = NIN + 2;                        // cells per axis
   static constexpr int NPT = (NCELL * NCELL + 15) / 16;        // column tiles of a cell plane
   static constexpr int NW = 4, CPW = NW * NCT;                 // column tiles per workgroup
   static constexpr int NSPLIT = (NPT + CPW - 1) / CPW;
@@ -65,24 +69,28 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
                                                          const float* __restrict__ bias, float* __restrict__ y, int act,
                                                          int items) {
   constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
-                NG = T::NG, NOUT = 2 * NIN + 3;
+                NG = T::NG, NOUT = T::NOUT, PAD = T::PAD, COUT = T::COUT;
   __shared__ __attribute__((aligned(16))) float xs[T::XS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int ITEMS = CIN * 3 * NIN * NIN / 4;               // float4 input loads of an item
+  // input rows travel as float4 where the row length allows (NIN % 4 == 0), as NIN-float rows of scalars otherwise
+  constexpr int VW = NIN % 4 == 0 ? 4 : 1, RV = NIN / VW;      // vector width, vectors per row
+  constexpr int ITEMS = CIN * 3 * NIN * RV;                    // vector loads of an item
   constexpr int NX4 = (ITEMS + 255) / 256;
   float4 xv[NX4];
+  const int cog = blockIdx.y;                                  // group of 16 output channels
   auto load_x = [&](int item) {
     const int cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
     const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
       const int i = tid + u * 256;
-      const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
+      const int xq = i % RV, iy = (i / RV) % NIN, pl = (i / (RV * NIN)) % 3, c = i / (RV * NIN * 3);
       const int zi = cz - 2 + pl;
       const bool ok = i < ITEMS && zi >= 0 && zi < NIN;
-      xv[u] = ok ? *(const float4*)(xb + (((size_t)c * NIN + zi) * NIN + iy) * NIN + 4 * xq)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* src = xb + (((size_t)c * NIN + zi) * NIN + iy) * NIN + VW * xq;
+      if constexpr (VW == 4) xv[u] = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+      else xv[u].x = ok ? src[0] : 0.f;
     }
   };
   auto store_x = [&]() {                                       // planes outside the input are written as zeros
@@ -90,9 +98,10 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
     for (int u = 0; u < NX4; ++u) {
       const int i = tid + u * 256;
       if (i < ITEMS) {
-        const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
-        float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + 4 * xq + 2;
-        dst[0] = xv[u].x; dst[1] = xv[u].y; dst[2] = xv[u].z; dst[3] = xv[u].w;
+        const int xq = i % RV, iy = (i / RV) % NIN, pl = (i / (RV * NIN)) % 3, c = i / (RV * NIN * 3);
+        float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + VW * xq + 2;
+        dst[0] = xv[u].x;
+        if constexpr (VW == 4) { dst[1] = xv[u].y; dst[2] = xv[u].z; dst[3] = xv[u].w; }
       }
     }
   };
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
   for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   const int j = lane & 15, kq = lane >> 4;
   const size_t cstride = (size_t)NOUT * NOUT * NOUT;
-  const float* wl = wp + lane;
+  const float* wl = wp + (size_t)cog * NG * kA16 * 64 + lane;
   // A fragments of one (jy, jx) tap column: jz = 0..2 x the parity classes that use the tap (<= 20), straight from the
   // packed weights in L2 into registers, one tap column ahead of the MFMAs that use them (no LDS: the 77 KB input image
   // leaves room for a second workgroup on the CU, whose MFMAs cover this one's staging and epilogue)
@@ -187,12 +196,12 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
       const int cy = p / NCELL, cx = p % NCELL;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int oz = 2 * cz + (e >> 2), oy = 2 * cy + ((e >> 1) & 1), ox = 2 * cx + (e & 1);
-        if (oz >= NOUT || oy >= NOUT || ox >= NOUT) continue;
+        const int oz = 2 * cz + (e >> 2) - PAD, oy = 2 * cy + ((e >> 1) & 1) - PAD, ox = 2 * cx + (e & 1) - PAD;
+        if (oz < 0 || oy < 0 || ox < 0 || oz >= NOUT || oy >= NOUT || ox >= NOUT) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = 4 * kq + r;
-          y[((size_t)b * 16 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
+          const int co = cog * 16 + 4 * kq + r;
+          y[((size_t)b * COUT + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
               nvf_act(acc[c][e][r] + (bias ? bias[co] : 0.f), act);
         }
       }
@@ -202,36 +211,40 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
 
 }  // namespace
 
-extern "C" size_t nvf_pack_convT16_mfma_floats(int cin) { return (size_t)(cin / 4) * kA16 * 64; }
+extern "C" size_t nvf_pack_convT16_mfma_floats(int cin, int cout) { return (size_t)(cout / 16) * (cin / 4) * kA16 * 64; }
 
-// w_fwd = the [cin][125][16] packed forward weight of a transposed convolution with 16 output channels
+// w_fwd = the [cin][125][cout] packed forward weight of a transposed convolution with 16 or 32 output channels
 extern "C" int nvf_pack_convT16_mfma(const float* w_fwd, int cin, int cout, float* wp, void* stream) {
-  if (!w_fwd || !wp || cin <= 0 || cin % 4 || cout != 16) return NVF_EINVAL;
-  const int total = (int)nvf_pack_convT16_mfma_floats(cin);
-  pack_convT16_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(w_fwd, wp, cin);
+  if (!w_fwd || !wp || cin <= 0 || cin % 4 || cout <= 0 || cout % 16) return NVF_EINVAL;
+  const int total = (int)nvf_pack_convT16_mfma_floats(cin, cout);
+  pack_convT16_kernel<<<(total + 255) / 256, 256, 0, nvf_stream(stream)>>>(w_fwd, wp, cin, cout);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }
 
-// y[b,co,o] = act(bias[co] + sum_{ci,k : o - k = 2 i} x[b,ci,i] w[ci][k][co]), padding 0, dout = 2 din + 3, 16 output
-// channels.  NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_convT3d_k5s2_fwd).
+// y[b,co,o] = act(bias[co] + sum_{ci,k : o + pad - k = 2 i} x[b,ci,i] w[ci][k][co]); pad 0: dout = 2 din + 3; pad 2 (with
+// output_padding 1): dout = 2 din; 16 or 32 output channels.  NVF_EINVAL = no instantiation for this shape (the caller
+// then uses nvf_convT3d_k5s2_fwd).
 extern "C" int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const float* bias, float* y, int batch, int cin,
-                                       int cout, int din, int act, int variant, void* stream) {
-  if (!x || !wp || !y || batch <= 0 || cout != 16) return NVF_EINVAL;
+                                       int cout, int pad, int din, int act, int variant, void* stream) {
+  if (!x || !wp || !y || batch <= 0 || (pad != 0 && pad != 2)) return NVF_EINVAL;
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
-#define NVF_T16(VAR, CI, NIN, NCT)                                                                     \
-  if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
-    using T = T16<CI, NIN, NCT>;                                                                       \
+#define NVF_T16(VAR, CI, CO, PADV, NIN, NCT)                                                           \
+  if (rc == 1 && variant == VAR && cin == CI && cout == CO && pad == PADV && din == NIN) {             \
+    using T = T16<CI, NIN, NCT, PADV, CO>;                                                             \
     const int items = batch * T::NCELL * T::NSPLIT;                                                    \
-    convT16_k5s2_mfma<T><<<items < 512 ? items : 512, 256, 0, s>>>(x, wp, bias, y, act, items);   /* 2 per CU */        \
+    const int cap = 512 / (CO / 16);                       /* two workgroups per CU */                  \
+    convT16_k5s2_mfma<T><<<dim3(items < cap ? items : cap, CO / 16), 256, 0, s>>>(x, wp, bias, y, act, items); \
     rc = NVF_OK;                                                                                       \
   }
-  NVF_T16(0, 16, 16, 2)      // up2: 21 column tiles per cell plane, 8 per workgroup
-  NVF_T16(0, 32, 8, 2)       // up1: all 7 column tiles of a cell plane in one workgroup (52 vs 68 us with 4)
-  NVF_T16(2, 16, 16, 1)
-  NVF_T16(3, 16, 16, 3)
-  NVF_T16(2, 32, 8, 1)
+  NVF_T16(0, 16, 16, 0, 16, 2)   // up2: 21 column tiles per cell plane, 8 per workgroup
+  NVF_T16(0, 32, 16, 0, 8, 2)    // up1: all 7 column tiles of a cell plane in one workgroup
+  NVF_T16(0, 16, 32, 2, 4, 1)    // conv0 (16 -> 32 channels, 4^3 -> 8^3, padding 2)
+  NVF_T16(0, 8, 16, 2, 2, 1)     // up0 (8 -> 16 channels, 2^3 -> 4^3, padding 2)
+  NVF_T16(2, 16, 16, 0, 16, 1)
+  NVF_T16(3, 16, 16, 0, 16, 3)
+  NVF_T16(2, 32, 16, 0, 8, 1)
 #undef NVF_T16
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();

@@ -49,12 +49,13 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       }
       const int ez = cls >> 2, ey = (cls >> 1) & 1, ex = cls & 1;
       const int jx = f % (3 - ex), jy = (f / (3 - ex)) % (3 - ey), jz = f / ((3 - ex) * (3 - ey));
-      v = src(job, ((4 * g + k) * 125 + ((ez + 2 * jz) * 5 + ey + 2 * jy) * 5 + ex + 2 * jx) * 16 + i);
+      const int cout = m.c1[job], g4 = g % (m.c0[job] / 4), cg = g / (m.c0[job] / 4);
+      v = src(job, ((4 * g4 + k) * 125 + ((ez + 2 * jz) * 5 + ey + 2 * jy) * 5 + ex + 2 * jx) * cout + cg * 16 + i);
     } else if (kind == 30 || kind == 31) {           // 16-row gather convolution (conv16_mfma.hip): [cog][g][tap][lane]
       const int k3 = kind == 30 ? 64 : 125, cin = m.c0[job], cout = m.c1[job];
       const int tap = r % k3; r /= k3;
       const int g = r % (cin / 4), cg = r / (cin / 4);
-      v = src(job, ((4 * g + k) * k3 + tap) * cout + cg * 16 + i);
+      if (cg * 16 + i < cout) v = src(job, ((4 * g + k) * k3 + tap) * cout + cg * 16 + i);
     } else {                                         // stride-2 gather (transposed conv backward-data)
       const int cog = m.c1[job], pair = cog == 8, KEX = pair ? 7 : 5;
       const int tx = r % KEX; r /= KEX;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
 }
 
 // kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
-// 11 = nvf_pack_convT16_mfma (c0 = cin); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout).
+// 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout).
 // Fills m (sources optional: the step head derives them).
 static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
                                  const int* c1s, int n, PackJobs& m) {
@@ -79,10 +80,10 @@ static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, c
     m.src[j] = srcs ? srcs[j] : nullptr; m.dst[j] = dsts[j]; m.kind[j] = kinds[j]; m.c0[j] = c0s[j]; m.c1[j] = c1s[j];
     if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
     else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
-    else if (kinds[j] == 11) m.total[j] = (c0s[j] / 4) * 125 * 64;
+    else if (kinds[j] == 11 && c1s[j] > 0 && c1s[j] % 16 == 0) m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * 125 * 64;
     else if (kinds[j] == 20 && (c1s[j] == 8 || c1s[j] == 16)) m.total[j] = (c0s[j] / 4) * 25 * (c1s[j] == 8 ? 7 : 5) * 64;
-    else if ((kinds[j] == 30 || kinds[j] == 31) && c1s[j] > 0 && c1s[j] % 16 == 0)
-      m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * (kinds[j] == 30 ? 64 : 125) * 64;
+    else if ((kinds[j] == 30 || kinds[j] == 31) && c1s[j] > 0 && (c1s[j] % 16 == 0 || c1s[j] == 8))
+      m.total[j] = ((c1s[j] + 15) / 16) * (c0s[j] / 4) * (kinds[j] == 30 ? 64 : 125) * 64;
     else return NVF_EINVAL;
   }
   m.n = n;

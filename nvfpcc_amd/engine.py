@@ -175,8 +175,11 @@ class TrainEngine:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
             if _G16 and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
-            if _G16 and L.k == 5 and L.cout == 16 and L.pad == 0 and (name, L.cin) in (("up1", 32), ("up2", 16)):
-                L.wp_t16 = torch.empty(int(lib().nvf_pack_convT16_mfma_floats(L.cin)), device=self.dev)
+            if _G16 and L.k == 5 and (name, L.cin, L.cout, L.pad) in (("up1", 32, 16, 0), ("up2", 16, 16, 0),
+                                                                      ("conv0", 16, 32, 2), ("up0", 8, 16, 2)):
+                L.wp_t16 = torch.empty(int(lib().nvf_pack_convT16_mfma_floats(L.cin, L.cout)), device=self.dev)
+            if _G16 and name == "up0" and L.cin == 8 and L.cout == 16 and L.pad == 2:     # 16 -> 8 channels, rows 8..15 zero
+                L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 8, 5)), device=self.dev)
             if _G16 and name == "conv0" and L.cin == 16 and L.cout == 32 and L.pad == 2:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(32, 16, 5)), device=self.dev)
             self.layers[name] = L
@@ -204,7 +207,7 @@ class TrainEngine:
         meta += [(row[nm], 0) for nm, L in named if L.wp_gf is not None]
         jobs += [(L.w_bwd, L.wp_gb, 30 if L.k == 4 else 31, L.cout, L.cin) for _, L in named if L.wp_gb is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_gb is not None]
-        jobs += [(L.w_fwd, L.wp_t16, 11, L.cin, 16) for _, L in named if L.wp_t16 is not None]
+        jobs += [(L.w_fwd, L.wp_t16, 11, L.cin, L.cout) for _, L in named if L.wp_t16 is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_t16 is not None]
         assert len(jobs) <= 12
         self._mfma_jobs = jobs
@@ -244,7 +247,7 @@ class TrainEngine:
     # ------------------------------------------------------------------ forward
     def _convT(self, L, x, act):
         if L.wp_t16 is not None:
-            return ops.convT3d_k5s2_mfma16(x, L.wp_t16, L.b_eff, act)
+            return ops.convT3d_k5s2_mfma16(x, L.wp_t16, L.b_eff, act, cout=L.cout, pad=L.pad)
         if L.wp_t is not None:
             return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)

@@ -80,7 +80,7 @@ class ConvTranspose3dK5S2(Function):
         if pad == 0 and cout == 8 and (cin, x.shape[-1]) in ((16, 8), (8, 16)):        # up1 / up2, narrow decoder
             y = ops.convT3d_k5s2_mfma(x, ops.pack_convT_mfma(wf, cin), b, act)
         elif pad == 0 and cout == 16 and (cin, x.shape[-1]) in ((32, 8), (16, 16)):    # up1 / up2, wide decoder
-            y = ops.convT3d_k5s2_mfma16(x, ops.pack_convT16_mfma(wf, cin), b, act)
+            y = ops.convT3d_k5s2_mfma16(x, ops.pack_convT16_mfma(wf, cin, 16), b, act)
         else:
             y = ops.convT3d_k5s2_fwd(x, wf, b, cout, pad, act)
         ctx.save_for_backward(x, y, wb)

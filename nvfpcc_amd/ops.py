@@ -247,24 +247,26 @@ def convT3d_k5s2_mfma(x, wp, bias, act=ACT_NONE, out=None, variant=None):
     return y
 
 
-def pack_convT16_mfma(w_fwd, cin, out=None):
-    """MFMA A-fragments of a k5 s2 transposed-conv weight with 16 output channels, packed forward layout [cin][125][16]."""
+def pack_convT16_mfma(w_fwd, cin, cout=16, out=None):
+    """MFMA A-fragments of a k5 s2 transposed-conv weight with 16 / 32 output channels, packed forward layout
+    [cin][125][cout]."""
     _f32(w_fwd, out)
-    n = int(lib().nvf_pack_convT16_mfma_floats(cin))
+    n = int(lib().nvf_pack_convT16_mfma_floats(cin, cout))
     wp = out if out is not None else torch.empty(n, device=w_fwd.device)
-    if w_fwd.numel() != cin * 125 * 16 or wp.numel() != n:
-        raise RuntimeError("pack_convT16_mfma: weight size does not match (cin, 5, 16)")
-    check(lib().nvf_pack_convT16_mfma(_ptr(w_fwd), cin, 16, _ptr(wp), _stream()), "nvf_pack_convT16_mfma")
+    if w_fwd.numel() != cin * 125 * cout or wp.numel() != n:
+        raise RuntimeError("pack_convT16_mfma: weight size does not match (cin, 5, cout)")
+    check(lib().nvf_pack_convT16_mfma(_ptr(w_fwd), cin, cout, _ptr(wp), _stream()), "nvf_pack_convT16_mfma")
     return wp
 
 
-def convT3d_k5s2_mfma16(x, wp, bias, act=ACT_NONE, out=None, variant=None):
-    """Matrix-core transposed convolution k5 s2 padding 0, 16 output channels (wide decoder)."""
+def convT3d_k5s2_mfma16(x, wp, bias, act=ACT_NONE, out=None, variant=None, cout=16, pad=0):
+    """Matrix-core transposed convolution k5 s2 with 16 / 32 output channels (wide decoder); pad 0 or 2 (+ output
+    padding 1)."""
     _f32(x, wp, bias)
     B, cin, di = x.shape[0], x.shape[1], x.shape[2]
-    do = 2 * di + 3
-    y = out if out is not None else torch.empty((B, 16, do, do, do), device=x.device)
-    check(lib().nvf_convT3d_k5s2_mfma16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, cin, 16, di, act,
+    do = 2 * di + (3 if pad == 0 else 0)
+    y = out if out is not None else torch.empty((B, cout, do, do, do), device=x.device)
+    check(lib().nvf_convT3d_k5s2_mfma16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, cin, cout, pad, di, act,
                                         _MFMA_VARIANT if variant is None else int(variant), _stream()),
           "nvf_convT3d_k5s2_mfma16")
     return y

@@ -304,61 +304,64 @@ def test_conv3d_g16_mfma_forward_and_backward_data(ops, n, B):
     assert (dx - dxv).abs().max().item() < 2e-5 * max(ref.abs().max().item(), 1.0)
 
 
-@pytest.mark.parametrize("cin,n,B", [(16, 16, 2), (32, 8, 3), (16, 16, 1)])
-def test_conv_transpose_k5s2_mfma16_forward(ops, cin, n, B):
-    """Wide decoder's up2 / up1 forward on the matrix cores (16 output channels = MFMA rows, eight parity classes,
-    convt16_mfma.hip) against torch's conv_transpose3d; tile variants and batch sizes give the same bits; the packed
-    fragments equal those of the one-launch packer."""
+@pytest.mark.parametrize("cin,cout,pad,n,B", [(16, 16, 0, 16, 2), (32, 16, 0, 8, 3), (16, 16, 0, 16, 1), (16, 32, 2, 4, 3),
+                                              (8, 16, 2, 2, 5)])
+def test_conv_transpose_k5s2_mfma16_forward(ops, cin, cout, pad, n, B):
+    """Wide decoder's four transposed convolutions on the matrix cores (16 / 32 output channels = MFMA rows, eight
+    parity classes, convt16_mfma.hip): up2 / up1 (padding 0) and conv0 / up0 (padding 2, output_padding 1) against
+    torch's conv_transpose3d; tile variants and batch sizes give the same bits; the packed fragments equal those of
+    the one-launch packer."""
     g = gen(5200 + cin + n + B)
     x = torch.randn(B, cin, n, n, n, generator=g)
-    w = torch.randn(cin, 16, 5, 5, 5, generator=g) / (cin * 125 / 8) ** 0.5
-    b = torch.randn(16, generator=g)
-    y_ref = F.relu(F.conv_transpose3d(x, w, b, stride=2))
+    w = torch.randn(cin, cout, 5, 5, 5, generator=g) / (cin * 125 / 8) ** 0.5
+    b = torch.randn(cout, generator=g)
+    y_ref = F.relu(F.conv_transpose3d(x, w, b, stride=2, padding=pad, output_padding=1 if pad else 0))
     wf, _ = ops.pack_convT_weight(dev(w))
-    wp = ops.pack_convT16_mfma(wf, cin)
+    wp = ops.pack_convT16_mfma(wf, cin, cout)
     wp2 = torch.empty_like(wp)
-    ops.pack_mfma_all([(wf, wp2, 11, cin, 16)])
+    ops.pack_mfma_all([(wf, wp2, 11, cin, cout)])
     assert torch.equal(wp, wp2)
-    y = ops.convT3d_k5s2_mfma16(dev(x), wp, dev(b), ops.ACT_RELU)
+    y = ops.convT3d_k5s2_mfma16(dev(x), wp, dev(b), ops.ACT_RELU, cout=cout, pad=pad)
     assert tuple(y.shape) == tuple(y_ref.shape)
     assert (y.cpu() - y_ref).abs().max() < 2e-5 * max(y_ref.abs().max().item(), 1.0)
     for v in (2, 3):
         try:
-            yv = ops.convT3d_k5s2_mfma16(dev(x), wp, dev(b), ops.ACT_RELU, variant=v)
+            yv = ops.convT3d_k5s2_mfma16(dev(x), wp, dev(b), ops.ACT_RELU, variant=v, cout=cout, pad=pad)
         except RuntimeError:
             continue
         assert torch.equal(yv, y), v
-    y1 = ops.convT3d_k5s2_mfma16(dev(x[B - 1:]), wp, dev(b), ops.ACT_RELU)
+    y1 = ops.convT3d_k5s2_mfma16(dev(x[B - 1:]), wp, dev(b), ops.ACT_RELU, cout=cout, pad=pad)
     assert torch.equal(y1[0], y[B - 1])
-    yv = ops.convT3d_k5s2_fwd(dev(x), wf, dev(b), 16, 0, ops.ACT_RELU)
+    yv = ops.convT3d_k5s2_fwd(dev(x), wf, dev(b), cout, pad, ops.ACT_RELU)
     assert (y - yv).abs().max().item() < 2e-5 * max(y_ref.abs().max().item(), 1.0)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(16, 16, 16), (32, 16, 8)])
-def test_conv_transpose_backward_data_g16_mfma(ops, cin, cout, n):
-    """Backward-data of the wide decoder's up2 (16 -> 16, 16^3 -> 35^3) and up1 (32 -> 16, 8^3 -> 19^3): a stride-2
-    gather convolution with `cin` (16 / 32) output channels on the matrix cores, against torch's autograd."""
+@pytest.mark.parametrize("cin,cout,n,pad", [(16, 16, 16, 0), (32, 16, 8, 0), (16, 32, 4, 2), (8, 16, 2, 2)])
+def test_conv_transpose_backward_data_g16_mfma(ops, cin, cout, n, pad):
+    """Backward-data of the wide decoder's up2 (16 -> 16, 16^3 -> 35^3), up1 (32 -> 16, 8^3 -> 19^3), conv0 (16 -> 32,
+    padding 2) and up0 (8 -> 16, padding 2: 8 output channels, rows 8..15 of the tile zero): a stride-2 gather
+    convolution with `cin` output channels on the matrix cores, against torch's autograd."""
     g = gen(4700 + cin + n)
     B = 2
     x = torch.randn(B, cin, n, n, n, generator=g, requires_grad=True)
     w = torch.randn(cin, cout, 5, 5, 5, generator=g) / (cout * 125 / 8) ** 0.5
-    y_ref = F.conv_transpose3d(x, w, None, 2)
+    y_ref = F.conv_transpose3d(x, w, None, 2, pad, 1 if pad else 0)
     gy = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(gy)
     wf, wb = ops.pack_convT_weight(dev(w))
     wpb = ops.pack_g16_mfma(wb, cout, cin, 5)              # gather form: `cout` input channels -> `cin` outputs
     mask = torch.randn(x.shape, generator=g)
     add = torch.randn(x.shape, generator=g)
-    dx = ops.conv3d_g16_mfma(dev(gy), wpb, None, cin, 5, 2, 0, (n, n, n), addend=dev(add), mask=dev(mask))
+    dx = ops.conv3d_g16_mfma(dev(gy), wpb, None, cin, 5, 2, pad, (n, n, n), addend=dev(add), mask=dev(mask))
     ref = (x.grad + add) * (mask > 0)
     assert (dx.cpu() - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0)
     for v in (2, 3):
         try:
-            dv = ops.conv3d_g16_mfma(dev(gy), wpb, None, cin, 5, 2, 0, (n, n, n), addend=dev(add), mask=dev(mask), variant=v)
+            dv = ops.conv3d_g16_mfma(dev(gy), wpb, None, cin, 5, 2, pad, (n, n, n), addend=dev(add), mask=dev(mask), variant=v)
         except RuntimeError:
             continue
         assert torch.equal(dv, dx), v
-    d1 = ops.conv3d_g16_mfma(dev(gy[1:2]), wpb, None, cin, 5, 2, 0, (n, n, n), addend=dev(add[1:2]), mask=dev(mask[1:2]))
+    d1 = ops.conv3d_g16_mfma(dev(gy[1:2]), wpb, None, cin, 5, 2, pad, (n, n, n), addend=dev(add[1:2]), mask=dev(mask[1:2]))
     assert torch.equal(d1[0], dx[1])
 
 

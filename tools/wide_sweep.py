@@ -33,7 +33,7 @@ def main():
         macs = B * cin * n ** 3 * cout * 125
         cases.append((name + ".fwd", macs, lambda: ops.convT3d_k5s2_fwd(x, wf, None, cout, 0, ops.ACT_RELU, out=y)))
         if cout == 16:
-            wp16 = ops.pack_convT16_mfma(wf, cin)
+            wp16 = ops.pack_convT16_mfma(wf, cin, 16)
             for v in (0, 2, 3):
                 cases.append((name + f".fwd.mfma16.v{v}", macs,
                               lambda v=v: ops.convT3d_k5s2_mfma16(x, wp16, None, ops.ACT_RELU, out=y, variant=v)))
