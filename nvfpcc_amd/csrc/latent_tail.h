@@ -55,12 +55,85 @@ __device__ __forceinline__ void latent_rate_body(const float* __restrict__ x, co
                                                  const float* __restrict__ dx_addend, float* __restrict__ dsigma,
                                                  float* __restrict__ dmu, const float* __restrict__ g_dev, float g_host,
                                                  int batch, int c, int spatial, int mode, uint64_t seed, uint64_t step_in,
-                                                 const uint64_t* __restrict__ step_dev, float* red) {
+                                                 const uint64_t* __restrict__ step_dev, float* red,
+                                                 float* scratch = nullptr, int scratch_floats = 0) {
   const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
   const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   constexpr int NVW = kRateVT / 64;
+  const long nel = (long)batch * spatial;
+  if (scratch && nel <= kRateVT && 3 * c * (nel + NVW) <= scratch_floats) {
+    // Small tensors (a mini-batch of 2^3 latents): every (channel, element) term at once, then the sums in the order
+    // of the channel-major loops below (element e of a channel belongs to virtual wave e / 64, lane e % 64).
+    float* tb_ = scratch;                     // [3][c][nel] bits, dsigma, dmu terms
+    float* rd_ = scratch + 3 * c * nel;       // [3][c][NVW] virtual-wave sums
+    const long cn = (long)c * nel;
+    for (long p = threadIdx.x; p < cn; p += blockDim.x) {
+      const int ch = (int)(p / nel);
+      const long e = p - (long)ch * nel;
+      const long b = e / spatial;
+      const int s = (int)(e % spatial);
+      const long idx = (b * c + ch) * spatial + s;
+      const float sabs = fabsf(sigma[ch]), m = mu[ch];
+      float xv = x[idx];
+      float xr = rintf(xv);
+      if (x_rounded) x_rounded[idx] = xr;
+      float v = xr;
+      if (mode == 0) {
+        float uu;
+        if (u) {
+          uu = u[idx];
+        } else {
+          uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
+          uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + s));
+        }
+        v = xv + (uu - 0.5f);
+      }
+      RateTerm r = rate_term(v, m, sabs, 0.5f, gsign);
+      tb_[p] = r.bits;
+      tb_[cn + p] = r.dsig;
+      tb_[2 * cn + p] = r.dmu;
+      if (dx) dx[idx] = (dx_addend ? dx_addend[idx] : 0.f) + g * r.dv;
+    }
+    __syncthreads();
+    for (int q = wave; q < c * NVW; q += nw) {          // (channel, virtual wave) pairs
+      const int ch = q / NVW, vw = q - ch * NVW;
+      const long e = vw * 64 + lane;
+      const bool in = e < nel;
+      float sb = 0.f, ss = 0.f, sm_ = 0.f;
+      if (in) {
+        sb += tb_[ch * nel + e];
+        ss += tb_[cn + ch * nel + e];
+        sm_ += tb_[2 * cn + ch * nel + e];
+      }
+      sb = nvf_wave_sum(sb);
+      ss = nvf_wave_sum(ss);
+      sm_ = nvf_wave_sum(sm_);
+      if (lane == 0) { rd_[q] = sb; rd_[c * NVW + q] = ss; rd_[2 * c * NVW + q] = sm_; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < c) {
+      const int ch = threadIdx.x;
+      float tb = 0.f, tsg = 0.f, tm = 0.f;
+      for (int i = 0; i < NVW; ++i) tb += rd_[ch * NVW + i];
+      for (int i = 0; i < NVW; ++i) tsg += rd_[c * NVW + ch * NVW + i];
+      for (int i = 0; i < NVW; ++i) tm += rd_[2 * c * NVW + ch * NVW + i];
+      const float sraw = sigma[ch];
+      float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
+      if (dsigma) dsigma[ch] = g * tsg * sgn;
+      if (dmu) dmu[ch] = g * tm;
+      rd_[ch * NVW] = tb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && bits) {
+      float total = 0.f;
+      for (int ch = 0; ch < c; ++ch) total += rd_[ch * NVW];
+      bits[0] = total;
+    }
+    __syncthreads();
+    return;
+  }
   float total_bits = 0.f;
   for (int ch = 0; ch < c; ++ch) {
     const float sraw = sigma[ch], sabs = fabsf(sraw), m = mu[ch];
@@ -123,7 +196,7 @@ __device__ __forceinline__ void latent_fwd_body(const float* __restrict__ e, con
                                                 float* __restrict__ lat_out, float* __restrict__ x_rounded,
                                                 float* __restrict__ bits, int batch, int c, int spatial, int mode,
                                                 uint64_t seed, uint64_t step_in, const uint64_t* __restrict__ step_dev,
-                                                float* s_par) {
+                                                float* s_par, float* scratch = nullptr, int scratch_floats = 0) {
   float* s_w = s_par;            // [64]  w_fwd layout [ci][co]
   float* s_gamma = s_par + 64;   // [64]
   float* s_b = s_par + 128;      // [8]
@@ -141,6 +214,70 @@ __device__ __forceinline__ void latent_fwd_body(const float* __restrict__ e, con
   const uint64_t step = step_in + (step_dev ? step_dev[0] : 0ull);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   constexpr int NVW = kRateVT / 64;
+  const long nel = (long)batch * spatial;
+  if (scratch && nel <= kRateVT && c * (nel + NVW) <= scratch_floats) {
+    // a mini-batch: every (channel, element) at once, then the rate sums in the order of the loops below
+    float* tb_ = scratch;                 // [c][nel] rate terms
+    float* rd_ = scratch + c * nel;       // [c][NVW] virtual-wave sums
+    const long cn = (long)c * nel;
+    for (long p = threadIdx.x; p < cn; p += blockDim.x) {
+      const int ch = (int)(p / nel);
+      const long el = p - (long)ch * nel;
+      const long b = el / spatial;
+      const int sp = (int)(el % spatial);
+      const float sabs = fabsf(sigma[ch]), m = mu[ch];
+      float h[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < c) {
+          float acc = 0.f;
+          for (int i = 0; i < c; ++i) acc = fmaf(e[(b * c + i) * spatial + sp], s_w[i * c + j], acc);
+          h[j] = acc + s_b[j];
+        }
+      }
+      float nrm = s_beta[ch], hc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < c) {
+          nrm = fmaf(s_gamma[ch * c + j], h[j] * h[j], nrm);
+          if (j == ch) hc = h[j];
+        }
+      }
+      const float xv = hc / sqrtf(nrm);
+      const long idx = (b * c + ch) * spatial + sp;
+      h_out[idx] = hc;
+      lat_out[idx] = xv;
+      const float xr = rintf(xv);
+      x_rounded[idx] = xr;
+      float v = xr;
+      if (mode == 0) {
+        const uint64_t blk = block_ids ? (uint64_t)block_ids[b] : (uint64_t)b;
+        const float uu = nvf_uniform01(seed, (blk << 20) ^ step * 0x9E3779B97F4A7C15ull, (uint64_t)(ch * spatial + sp));
+        v = xv + (uu - 0.5f);
+      }
+      tb_[p] = rate_term(v, m, sabs, 0.5f, 0.f).bits;
+    }
+    __syncthreads();
+    for (int q = wave; q < c * NVW; q += nw) {
+      const int ch = q / NVW, vw = q - ch * NVW;
+      const long el = vw * 64 + lane;
+      float sb = 0.f;
+      if (el < nel) sb += tb_[ch * nel + el];
+      sb = nvf_wave_sum(sb);
+      if (lane == 0) rd_[q] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float total = 0.f;
+      for (int ch = 0; ch < c; ++ch) {
+        float tb = 0.f;
+        for (int i = 0; i < NVW; ++i) tb += rd_[ch * NVW + i];
+        total += tb;
+      }
+      bits[0] = total;
+    }
+    return;
+  }
   float total_bits = 0.f;
   for (int ch = 0; ch < c; ++ch) {
     const float sabs = fabsf(sigma[ch]), m = mu[ch];
@@ -250,10 +387,13 @@ struct LatentTail {
 };
 
 constexpr int kTailMaxC = 8, kTailGdnT = 128;
-constexpr int kTailLds = 2 * kTailMaxC * (kTailGdnT + 1) + 48;      // floats of LDS the tail needs
+constexpr int kTailGdnLds = 3 * kTailMaxC * (kTailGdnT + 1) + kTailMaxC * kTailMaxC + kTailMaxC;
+constexpr int kTailRateLds = 3 * kTailMaxC * (128 + kRateVT / 64);      // a mini-batch of 16 blocks at c = 8
+constexpr int kTailLds = (kTailGdnLds > kTailRateLds ? kTailGdnLds : kTailRateLds) + 48;   // floats of LDS the tail needs
 
-// GDN backward of a tensor small enough for one workgroup: the arithmetic of gdn_bwd_kernel with gridDim.x == 1 (the
-// first kTailGdnT threads do the work, every thread takes part in the barriers)
+// GDN backward of a tensor small enough for one workgroup: the arithmetic of gdn_bwd_kernel with gridDim.x == 1.
+// blockDim.x / kTailGdnT threads share a voxel (thread (voxel, cg) owns the channels cg, cg + NG, ...); every thread
+// takes part in the barriers.
 __device__ __forceinline__ void gdn_bwd_one_workgroup(const float* __restrict__ x, const float* __restrict__ beta_hat,
                                                       const float* __restrict__ gamma_hat, const float* __restrict__ dy,
                                                       float* __restrict__ dx, int batch, int c, int spatial, int inverse,
@@ -262,61 +402,77 @@ __device__ __forceinline__ void gdn_bwd_one_workgroup(const float* __restrict__ 
   constexpr int T = kTailGdnT, LD = T + 1;
   float* ts = sm;
   float* xs = sm + c * LD;
+  float* ns = xs + c * LD;                   // norms (kept out of registers: the host kernel wants few of them)
+  float* gam = ns + c * LD;
+  float* bet = gam + c * c;
   const int tid = threadIdx.x;
-  const bool worker = tid < T;
+  const int ng = (int)blockDim.x / T > 0 ? (int)blockDim.x / T : 1;
+  const int vt = tid % T, cg = tid / T;
+  const bool worker = cg < ng && (int)blockDim.x >= T;
   const int ncol = c + c * c;
   const long nvox = (long)batch * spatial;
+  for (int i = tid; i < c * c; i += blockDim.x) gam[i] = gdn_gamma(gamma_hat[i]);
+  for (int i = tid; i < c; i += blockDim.x) bet[i] = gdn_beta(beta_hat[i]);
   float own = 0.f;                           // ncol <= 72 < T: at most one parameter column per thread
   for (long base = 0; base < nvox; base += T) {
-    const long v = base + tid;
+    const long v = base + vt;
     const bool live = worker && v < nvox;
     const long b = live ? v / spatial : 0;
     const int s = live ? (int)(v % spatial) : 0;
     const float* xb = x + b * c * spatial + s;
     const float* gb = dy + b * c * spatial + s;
-    if (worker)
-      for (int ch = 0; ch < c; ++ch) {
-        float t = 0.f, xsq = 0.f;
-        if (live) {
-          float acc = gdn_beta(beta_hat[ch]);
-          for (int j = 0; j < c; ++j) {
-            float xj = xb[(long)j * spatial];
-            acc = fmaf(gdn_gamma(gamma_hat[ch * c + j]), xj * xj, acc);
-          }
-          float nrm = sqrtf(acc);
-          float xv = xb[(long)ch * spatial], g = gb[(long)ch * spatial];
-          t = inverse ? g * xv / nrm : -g * xv / (nrm * nrm * nrm);
-          xsq = xv * xv;
-        }
-        ts[ch * LD + tid] = t;
-        xs[ch * LD + tid] = xsq;
+    if (worker) {
+#pragma unroll 1
+      for (int ch = cg; ch < c; ch += ng) {
+        const float xv = live ? xb[(long)ch * spatial] : 0.f;
+        xs[ch * LD + vt] = xv * xv;
       }
+    }
+    __syncthreads();
+    if (worker) {
+#pragma unroll 1
+      for (int ch = cg; ch < c; ch += ng) {
+        float t = 0.f;
+        if (live) {
+          float acc = bet[ch];
+#pragma unroll 1
+          for (int j = 0; j < c; ++j) acc = fmaf(gam[ch * c + j], xs[j * LD + vt], acc);
+          const float nrm = sqrtf(acc);
+          const float xv = xb[(long)ch * spatial], g = gb[(long)ch * spatial];
+          t = inverse ? g * xv / nrm : -g * xv / (nrm * nrm * nrm);
+          ns[ch * LD + vt] = nrm;
+        }
+        ts[ch * LD + vt] = t;
+      }
+    }
     __syncthreads();
     if (live) {
-      for (int i = 0; i < c; ++i) {
-        float acc = gdn_beta(beta_hat[i]);
-        for (int j = 0; j < c; ++j) acc = fmaf(gdn_gamma(gamma_hat[i * c + j]), xs[j * LD + tid], acc);
-        float nrm = sqrtf(acc);
+#pragma unroll 1
+      for (int i = cg; i < c; i += ng) {
+        const float nrm = ns[i * LD + vt];
         float mix = 0.f;
-        for (int ch = 0; ch < c; ++ch) mix = fmaf(ts[ch * LD + tid], gdn_gamma(gamma_hat[ch * c + i]), mix);
+#pragma unroll 1
+        for (int ch = 0; ch < c; ++ch) mix = fmaf(ts[ch * LD + vt], gam[ch * c + i], mix);
         float xv = xb[(long)i * spatial], g = gb[(long)i * spatial];
         dx[(b * c + i) * spatial + s] = (inverse ? g * nrm : g / nrm) + xv * mix;
       }
     }
-    if (worker && tid < ncol) {
+    if (tid < ncol) {
       const int p = tid;
       float sum = 0.f;
       if (p < c) {
+#pragma unroll 4
         for (int k = 0; k < T; ++k) sum += ts[p * LD + k];
       } else {
         int ch = (p - c) / c, j = (p - c) % c;
+#pragma unroll 4
         for (int k = 0; k < T; ++k) sum = fmaf(ts[ch * LD + k], xs[j * LD + k], sum);
       }
       own += 0.5f * sum;
     }
     __syncthreads();
   }
-  if (worker && tid < ncol) {
+  if (tid < ncol) {
     const int p = tid;
     const float sv = 0.f + own;
     if (p < c) {
@@ -334,9 +490,10 @@ __device__ __forceinline__ void gdn_bwd_one_workgroup(const float* __restrict__ 
 // One workgroup (>= 192 threads, whole waves), lds = kTailLds floats.  Stage results travel through global memory
 // (they are outputs anyway); a fence + barrier separates the stages.
 __device__ __forceinline__ void latent_tail_body(const LatentTail& t, float* lds) {
-  float* red = lds + 2 * kTailMaxC * (kTailGdnT + 1);
+  float* red = lds + kTailLds - 48;
   latent_rate_body(t.lat, nullptr, t.block_ids, t.sigma, t.mu, nullptr, nullptr, t.dlat, t.dx_addend, t.dsigma, t.dmu,
-                   t.g_dev, t.g_host, t.batch, t.c, t.spatial, t.mode, t.seed, t.step, t.step_dev, red);
+                   t.g_dev, t.g_host, t.batch, t.c, t.spatial, t.mode, t.seed, t.step, t.step_dev, red, lds,
+                   kTailLds - 48);
   __threadfence();
   __syncthreads();
   gdn_bwd_one_workgroup(t.h, t.beta_hat, t.gamma_hat, t.dlat, t.dh, t.batch, t.c, t.spatial, 0, t.dbeta_hat,

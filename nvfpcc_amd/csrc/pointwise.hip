@@ -168,67 +168,90 @@ static const int kGdnMaxC = 32;
 static const int kGdnThreads = 128;
 static const int kGdnMaxSlabs = 256;
 
-__global__ __launch_bounds__(kGdnThreads) void gdn_bwd_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ beta_hat,
-                                                              const float* __restrict__ gamma_hat,
-                                                              const float* __restrict__ dy, float* __restrict__ dx,
-                                                              float* __restrict__ slabs, int batch, int c, int spatial,
-                                                              int inverse, int vox_per_wg,
-                                                              float* __restrict__ dbeta_hat,
-                                                              float* __restrict__ dgamma_hat) {
-  extern __shared__ float sm[];             // ts[c][T+1], xs[c][T+1]
-  const int T = kGdnThreads, LD = T + 1;
+// A workgroup walks tiles of kGdnThreads voxels; CG threads share a voxel, thread (voxel, cg) owning the channels
+// cg, cg + CG, ... of it (the per-voxel channel loops are the serial part of this kernel: on the [B, 32, 4^3] tensor
+// of the wide decoder one thread per voxel meant 8 workgroups walking 5000 dependent iterations each).  The
+// re-parametrised beta / gamma sit in LDS.  The arithmetic and its order do not depend on CG.
+template <int CG>
+__global__ __launch_bounds__(kGdnThreads * CG) void gdn_bwd_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ beta_hat,
+                                                                   const float* __restrict__ gamma_hat,
+                                                                   const float* __restrict__ dy, float* __restrict__ dx,
+                                                                   float* __restrict__ slabs, int batch, int c,
+                                                                   int spatial, int inverse, int vox_per_wg,
+                                                                   float* __restrict__ dbeta_hat,
+                                                                   float* __restrict__ dgamma_hat) {
+  extern __shared__ float sm[];             // ts[c][T+1], xs[c][T+1], gam[c][c], bet[c]
+  constexpr int T = kGdnThreads, LD = T + 1, NT = T * CG, MAXK = kGdnMaxC / CG;
   float* ts = sm;
   float* xs = sm + c * LD;
-  const int tid = threadIdx.x;
+  float* gam = xs + c * LD;
+  float* bet = gam + c * c;
+  const int tid = threadIdx.x, vt = tid % T, cg = tid / T;
   const int ncol = c + c * c;
   const long nvox = (long)batch * spatial;
   const long v_lo = (long)blockIdx.x * vox_per_wg;
   long v_hi = v_lo + vox_per_wg;
   if (v_hi > nvox) v_hi = nvox;
-  // per-thread running parameter partials live in LDS-free registers only for the pairs this thread owns
-  float own[(kGdnMaxC + kGdnMaxC * kGdnMaxC + kGdnThreads - 1) / kGdnThreads];
+  for (int i = tid; i < c * c; i += NT) gam[i] = gdn_gamma(gamma_hat[i]);
+  for (int i = tid; i < c; i += NT) bet[i] = gdn_beta(beta_hat[i]);
+  // running parameter partials of the columns this thread owns
+  float own[(kGdnMaxC + kGdnMaxC * kGdnMaxC + NT - 1) / NT];
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(own) / sizeof(float)); ++i) own[i] = 0.f;
 
   for (long base = v_lo; base < v_hi; base += T) {
-    const long v = base + tid;
+    const long v = base + vt;
     const bool live = v < v_hi;
     const long b = live ? v / spatial : 0;
     const int s = live ? (int)(v % spatial) : 0;
     const float* xb = x + b * c * spatial + s;
     const float* gb = dy + b * c * spatial + s;
-    for (int ch = 0; ch < c; ++ch) {
-      float t = 0.f, xsq = 0.f;
-      if (live) {
-        float acc = gdn_beta(beta_hat[ch]);
-        for (int j = 0; j < c; ++j) {
-          float xj = xb[(long)j * spatial];
-          acc = fmaf(gdn_gamma(gamma_hat[ch * c + j]), xj * xj, acc);
-        }
-        float nrm = sqrtf(acc);
-        float xv = xb[(long)ch * spatial], g = gb[(long)ch * spatial];
-        t = inverse ? g * xv / nrm : -g * xv / (nrm * nrm * nrm);
-        xsq = xv * xv;
+    float xr[MAXK], gr[MAXK], nr[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int ch = cg + CG * k;
+      if (ch < c) {
+        xr[k] = live ? xb[(long)ch * spatial] : 0.f;
+        gr[k] = live ? gb[(long)ch * spatial] : 0.f;
+        xs[ch * LD + vt] = xr[k] * xr[k];
       }
-      ts[ch * LD + tid] = t;
-      xs[ch * LD + tid] = xsq;
+    }
+    __syncthreads();      // (also: gam / bet are complete)
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int ch = cg + CG * k;
+      if (ch < c) {
+        float t = 0.f;
+        nr[k] = 1.f;
+        if (live) {
+          float acc = bet[ch];
+          for (int j = 0; j < c; ++j) acc = fmaf(gam[ch * c + j], xs[j * LD + vt], acc);
+          const float nrm = sqrtf(acc);
+          const float xv = xr[k], g = gr[k];
+          t = inverse ? g * xv / nrm : -g * xv / (nrm * nrm * nrm);
+          nr[k] = nrm;
+        }
+        ts[ch * LD + vt] = t;
+      }
     }
     __syncthreads();
     if (live) {
-      for (int i = 0; i < c; ++i) {
-        float acc = gdn_beta(beta_hat[i]);
-        for (int j = 0; j < c; ++j) acc = fmaf(gdn_gamma(gamma_hat[i * c + j]), xs[j * LD + tid], acc);
-        float nrm = sqrtf(acc);
-        float mix = 0.f;
-        for (int ch = 0; ch < c; ++ch) mix = fmaf(ts[ch * LD + tid], gdn_gamma(gamma_hat[ch * c + i]), mix);
-        float xv = xb[(long)i * spatial], g = gb[(long)i * spatial];
-        dx[(b * c + i) * spatial + s] = (inverse ? g * nrm : g / nrm) + xv * mix;
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        const int i = cg + CG * k;
+        if (i < c) {
+          const float nrm = nr[k];
+          float mix = 0.f;
+          for (int ch = 0; ch < c; ++ch) mix = fmaf(ts[ch * LD + vt], gam[ch * c + i], mix);
+          float xv = xr[k], g = gr[k];
+          dx[(b * c + i) * spatial + s] = (inverse ? g * nrm : g / nrm) + xv * mix;
+        }
       }
     }
     // parameter partials: column p < c is dbeta_p, column c + ch*c + j is dgamma_{ch,j}
     int slot = 0;
-    for (int p = tid; p < ncol; p += T, ++slot) {
+    for (int p = tid; p < ncol; p += NT, ++slot) {
       float sum = 0.f;
       if (p < c) {
         for (int k = 0; k < T; ++k) sum += ts[p * LD + k];
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(kGdnThreads) void gdn_bwd_kernel(const float* __res
   int slot = 0;
   if (gridDim.x == 1) {
     // a single workgroup holds the complete sums: finish here (what gdn_bwd_final does for one slab: 0 + s = s)
-    for (int p = tid; p < ncol; p += T, ++slot) {
+    for (int p = tid; p < ncol; p += NT, ++slot) {
       const float sv = 0.f + own[slot];
       if (p < c) {
         const float h = beta_hat[p];
@@ -257,7 +280,7 @@ __global__ __launch_bounds__(kGdnThreads) void gdn_bwd_kernel(const float* __res
     }
     return;
   }
-  for (int p = tid; p < ncol; p += T, ++slot) slabs[(size_t)blockIdx.x * ncol + p] = own[slot];
+  for (int p = tid; p < ncol; p += NT, ++slot) slabs[(size_t)blockIdx.x * ncol + p] = own[slot];
 }
 
 __global__ void gdn_bwd_final(const float* __restrict__ slabs, const float* __restrict__ beta_hat,
@@ -291,10 +314,19 @@ extern "C" int nvf_gdn_bwd(const float* x, const float* beta_hat, const float* g
   long per = (nvox + kGdnMaxSlabs - 1) / kGdnMaxSlabs;
   per = (per + kGdnThreads - 1) / kGdnThreads * kGdnThreads;
   int nslab = (int)((nvox + per - 1) / per);
-  size_t lds = (size_t)2 * c * (kGdnThreads + 1) * sizeof(float);
+  size_t lds = ((size_t)2 * c * (kGdnThreads + 1) + c * c + c) * sizeof(float);
   hipStream_t s = nvf_stream(stream);
-  gdn_bwd_kernel<<<nslab, kGdnThreads, lds, s>>>(x, beta_hat, gamma_hat, dy, dx, (float*)workspace, batch, c, spatial,
-                                                 inverse, (int)per, dbeta_hat, dgamma_hat);
+  // few voxels and many channels (the decoder's IGDN sits on 4^3 grids): spread the channels of a voxel over 8 / 4 threads
+  const bool few = nslab < 128;
+  if (few && c % 8 == 0)
+    gdn_bwd_kernel<8><<<nslab, kGdnThreads * 8, lds, s>>>(x, beta_hat, gamma_hat, dy, dx, (float*)workspace, batch, c,
+                                                         spatial, inverse, (int)per, dbeta_hat, dgamma_hat);
+  else if (few && c % 4 == 0)
+    gdn_bwd_kernel<4><<<nslab, kGdnThreads * 4, lds, s>>>(x, beta_hat, gamma_hat, dy, dx, (float*)workspace, batch, c,
+                                                         spatial, inverse, (int)per, dbeta_hat, dgamma_hat);
+  else
+    gdn_bwd_kernel<1><<<nslab, kGdnThreads, lds, s>>>(x, beta_hat, gamma_hat, dy, dx, (float*)workspace, batch, c,
+                                                      spatial, inverse, (int)per, dbeta_hat, dgamma_hat);
   if (nslab > 1)      // one workgroup (the latent GDN of a mini-batch) finishes the parameter gradients itself
     gdn_bwd_final<<<NVF_GRID(c + c * c, 64), 64, 0, s>>>((const float*)workspace, beta_hat, gamma_hat, dbeta_hat,
                                                          dgamma_hat, nslab, c);
@@ -317,8 +349,9 @@ __global__ __launch_bounds__(1024) void latent_rate_kernel(const float* __restri
                                                            int c, int spatial, int mode, uint64_t seed, uint64_t step_in,
                                                            const uint64_t* __restrict__ step_dev) {
   __shared__ float red[48];
+  __shared__ float scratch[kTailRateLds];
   latent_rate_body(x, u, block_ids, sigma, mu, x_rounded, bits, dx, dx_addend, dsigma, dmu, g_dev, g_host, batch, c,
-                   spatial, mode, seed, step_in, step_dev, red);
+                   spatial, mode, seed, step_in, step_dev, red, scratch, kTailRateLds);
 }
 
 extern "C" int nvf_latent_rate(const float* x, const float* u, const int64_t* block_ids, const float* sigma,
@@ -349,8 +382,9 @@ __global__ __launch_bounds__(1024) void latent_fwd_kernel(const float* __restric
                                                           int batch, int c, int spatial, int mode, uint64_t seed,
                                                           uint64_t step_in, const uint64_t* __restrict__ step_dev) {
   __shared__ float s_par[160];
+  __shared__ float scratch[kTailRateLds / 3];
   latent_fwd_body(e, w, bw, beta_hat, gamma_hat, block_ids, sigma, mu, h_out, lat_out, x_rounded, bits, batch, c, spatial,
-                  mode, seed, step_in, step_dev, s_par);
+                  mode, seed, step_in, step_dev, s_par, scratch, kTailRateLds / 3);
 }
 
 extern "C" int nvf_latent_fwd(const float* e, const float* w_fwd, const float* bias, const float* beta_hat,

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
   if (LATENT && blockIdx.y == C1 / COG) {
     if (blockIdx.x == 0)
       latent_fwd_body(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, L.block_ids, L.sigma, L.mu, L.h_out, L.lat_out,
-                      L.x_rounded, L.bits, L.batch, ch, 8, L.mode, L.seed, L.step, L.step_dev, s_a);
+                      L.x_rounded, L.bits, L.batch, ch, 8, L.mode, L.seed, L.step, L.step_dev, s_a, s_a + 160,
+                      C0 * 64 - 160);
     return;
   }
   __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1

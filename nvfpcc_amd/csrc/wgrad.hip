@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
 }
 
 // ... and with the latent tail (latent_tail.h) as one more workgroup, the first one dispatched
-__global__ __launch_bounds__(1024) void wgrad_reduce_sums_tail(WgReduceMulti r, int r_blocks, MultiSumDesc m,
+__global__ __launch_bounds__(1024, 8) void wgrad_reduce_sums_tail(WgReduceMulti r, int r_blocks, MultiSumDesc m,
                                                                float* __restrict__ part, LatentTail t) {
   __shared__ float sm[kTailLds > 16 * 64 ? kTailLds : 16 * 64];
   if (blockIdx.x == 0) { latent_tail_body(t, sm); return; }

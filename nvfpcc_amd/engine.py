@@ -26,6 +26,7 @@ from ._lib import lib, check
 from .network import NoiseState
 
 R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
+_TAIL = os.environ.get("NVF_TAIL", "1") != "0"   # latent backward as one workgroup of a later launch (0: three launches)
 _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wide decoder (0: the VALU tile kernels)
 
 
@@ -480,7 +481,7 @@ class TrainEngine:
         sd = self._step_dev
         g_lat = self.lmbda * self.w1 / n_pts if self._g_lat_dev is None else 1.0
         g2m = net.latent_gen.gdn_2
-        tail = defer and not want_emb and a["e"].shape[1] <= 8 and _NAIVE_OFF()
+        tail = _TAIL and defer and not want_emb and a["e"].shape[1] <= 8 and _NAIVE_OFF()
         if tail:
             # three dependent launches on [B, ch, 2^3] tensors -> one workgroup of the next weight-gradient launch
             # (or of the slab reduction); dlat / dh / dx0 stay referenced until that launch has been enqueued
