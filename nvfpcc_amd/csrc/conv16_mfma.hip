@@ -47,9 +47,9 @@ struct G16 {
   static constexpr int K3 = K * K * K, NG = CIN / 4, NT = NW * 64;
   static constexpr int OY = NCY * CTY, OX = NCX * CTX;
   static constexpr int NSEG = OZ * NCY * NCX;
-  static_assert(NSEG % NW == 0, "tiles split evenly over the waves");
-  static constexpr int R = NSEG / NW;
-  static constexpr bool ZUNI = (NCY * NCX) % R == 0;       // every wave's R tiles lie in one output plane
+  static constexpr int R = (NSEG + NW - 1) / NW;           // tiles per wave (an uneven split leaves the last wave short:
+  static constexpr bool EVEN = NSEG % NW == 0;             //  its missing tiles repeat tile NSEG - 1 and are not stored)
+  static constexpr bool ZUNI = EVEN && (NCY * NCX) % R == 0;   // every wave's R tiles lie in one output plane
   static constexpr int IZ = (OZ - 1) * S + K, IY = (OY - 1) * S + K, IX = (OX - 1) * S + K;
   static constexpr int find_rs() {
     for (int rs = IX; rs < IX + 64; ++rs)
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
   int base[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int s = wave * R + r;
+    const int s = min(wave * R + r, C::NSEG - 1);
     const int cx = s % C::NCX, cy = (s / C::NCX) % C::NCY, z = s / (C::NCX * C::NCY);
     base[r] = kq * CS + z * S * PS + (cy * C::CTY + j / C::CTX) * S * RS + (cx * C::CTX + j % C::CTX) * S;
   }
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = wave * R + r;
+      if (!C::EVEN && s >= C::NSEG) continue;
       const int cx = s % C::NCX, cy = (s / C::NCX) % C::NCY, z = s / (C::NCX * C::NCY);
       const int oz = oz0 + z, oy = oy0 + cy * C::CTY + j / C::CTX, ox = ox0 + cx * C::CTX + j % C::CTX;
       if (oz >= d.dout || oy >= d.hout || ox >= d.wout) continue;
@@ -272,10 +273,10 @@ extern "C" int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float*
   if (rc == 1 && variant == VAR && cin == CI && k == KS && stride == ST && wout >= WLO && wout <= WHI)       \
     rc = launch_g16<G16<CI, KS, ST, OZ, NCY, NCX, CTY, CTX, NW>>(x, wp, bias, y, addend, mask, batch, d, s);
   // (tile choices: tools/g16_sweep.py at batch 16)
-  NVF_G16(0, 16, 4, 1, 21, 32, 8, 4, 2, 1, 16, 8)     // conv2 forward: 8 planes x 4 rows x 32 (154 us = 111 TF)
-  NVF_G16(0, 16, 4, 1, 33, 40, 7, 1, 9, 4, 4, 7)      // conv2 backward-data (35^3): 7 planes of 1 x 9 patches, one plane per wave (268 us)
+  NVF_G16(0, 16, 4, 1, 21, 32, 8, 4, 2, 1, 16, 8)     // conv2 forward: 8 planes x 4 rows x 32 (158 us = 109 TF in the step)
+  NVF_G16(0, 16, 4, 1, 33, 40, 7, 1, 9, 4, 4, 8)      // conv2 backward-data (35^3): 7 planes of 1 x 9 patches of 4 x 4, the 63 patches over 8 waves
   NVF_G16(0, 16, 4, 1, 9, 16, 2, 8, 1, 1, 16, 8)      // conv1 forward: 2 planes x 8 rows x 16 (26 us)
-  NVF_G16(0, 16, 4, 1, 17, 20, 1, 3, 5, 4, 4, 5)      // conv1 backward-data (19^3): one plane of 3 x 5 patches (87 us)
+  NVF_G16(0, 16, 4, 1, 17, 20, 2, 2, 5, 4, 4, 4)      // conv1 backward-data (19^3): 2 planes x 8 rows x 20 on four waves (58 us; one plane of 3 x 5 patches on five waves: 88)
   NVF_G16(0, 16, 5, 2, 9, 16, 2, 8, 1, 1, 16, 4)      // up2 backward-data (35^3 -> 16^3) (58 us)
   NVF_G16(0, 16, 5, 2, 5, 8, 1, 4, 1, 2, 8, 4)        // up1 backward-data (19^3 -> 8^3, 32 output channels)
   NVF_G16(0, 32, 5, 2, 3, 4, 4, 1, 1, 4, 4, 4)        // conv0 backward-data (8^3 -> 4^3, padding 2)
@@ -304,6 +305,17 @@ extern "C" int nvf_conv3d_g16_mfma(const float* x, const float* wp, const float*
   NVF_G16(2, 16, 5, 2, 9, 16, 2, 4, 1, 1, 16, 4)
   NVF_G16(3, 16, 5, 2, 9, 16, 1, 4, 1, 1, 16, 4)
   NVF_G16(2, 16, 5, 2, 5, 8, 2, 4, 1, 2, 8, 4)
+  NVF_G16(9, 16, 4, 1, 33, 40, 4, 1, 9, 4, 4, 4)      // conv2 bwd: four planes, one per wave, two workgroups per CU
+  NVF_G16(14, 16, 4, 1, 33, 40, 7, 1, 9, 4, 4, 7)
+  NVF_G16(14, 16, 4, 1, 21, 32, 2, 4, 2, 1, 16, 4)     // (160 us in the step)
+  NVF_G16(14, 16, 4, 1, 17, 20, 1, 3, 5, 4, 4, 5)
+  NVF_G16(10, 16, 4, 1, 33, 40, 3, 1, 9, 4, 4, 3)
+  NVF_G16(12, 16, 4, 1, 33, 40, 2, 1, 9, 4, 4, 2)
+  NVF_G16(9, 16, 4, 1, 17, 20, 1, 5, 5, 4, 4, 4)      // conv1 bwd: 25 patches of a plane over 4 / 8 waves
+  NVF_G16(10, 16, 4, 1, 17, 20, 1, 5, 5, 4, 4, 8)
+  NVF_G16(11, 16, 4, 1, 17, 20, 2, 5, 5, 4, 4, 8)
+  NVF_G16(12, 16, 4, 1, 17, 20, 1, 2, 5, 4, 4, 2)     // 8 rows x 20
+  NVF_G16(9, 16, 4, 1, 21, 32, 4, 4, 2, 1, 16, 4)     // conv2 fwd: R = 8 on four waves, two workgroups per CU
 #undef NVF_G16
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();

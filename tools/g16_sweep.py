@@ -17,7 +17,7 @@ from tools.trunk_bench import timeit  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--variants", default="0,2,3,4,5,6,7,8")
+    ap.add_argument("--variants", default="0,2,3,4,5,6,7,8,9,10,11,12,13")
     a = ap.parse_args()
     B, dev = a.batch, torch.device("cuda")
     R = lambda *s: torch.randn(*s, device=dev)
