@@ -7,10 +7,12 @@
 //
 // One v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chain) per (tap, four consecutive x positions):
 //   D_tap[a][b] += sum_{k=0..3} A[a][k] * B[k][b],   A[a][k] = p[a, z, y, x0 + k],  B[k][b] = q[b, S(z,y,x0+k) - pad + tap]
-// rows = 16 p-channels, columns = 16 q-channels, every lane useful.  A workgroup has K waves, wave w owns the K*K taps
-// of kz = w (K*K accumulator tiles in registers for the whole launch) and walks its share of the items
+// rows = 16 p-channels, columns = 16 q-channels, every lane useful.  A workgroup has NW waves, wave w owns a run of the
+// K*K (kz, ky) tap rows (K taps each; its accumulator tiles stay in registers for the whole launch: 8 waves = two per
+// SIMD with 2 rows each for k = 4, 3 or 4 rows for k = 5 -- K waves of one kz each left a SIMD with one wave, or with
+// two of five) and walks its share of the items
 // (batch element, z plane, TY rows); p / q tiles of the next item stream into the second LDS buffer by LDS-DMA while
-// this item's MFMAs issue.  An A fragment (one ds_read_b32) feeds K*K MFMAs, a B fragment one.  Each workgroup leaves
+// this item's MFMAs issue.  An A fragment (one ds_read_b32) feeds a wave's 2 K .. 4 K MFMAs, a B fragment one.  Each workgroup leaves
 // one slab of 16 x 16 x K^3 partial sums; the caller's fixed-order reduction (nvf_wgrad_reduce_multi*) adds them.
 #include "nvf_common.h"
 
@@ -42,10 +44,14 @@ constexpr int w16_stride(int least, int s) {
   return best;
 }
 
-template <int K_, int S_, int WP_, int TY_>
+template <int K_, int S_, int WP_, int TY_, int NW_ = K_>
 struct W16 {
-  static constexpr int K = K_, S = S_, WP = WP_, TY = TY_, NW = K_, NT = NW * 64, KK = K * K, K3 = K * K * K;
+  static constexpr int K = K_, S = S_, WP = WP_, TY = TY_, NW = NW_, NT = NW * 64, KK = K * K, K3 = K * K * K;
   static_assert(WP % 4 == 0, "four x positions per MFMA");
+  // the K*K (kz, ky) tap rows (K taps along x each) are dealt to the waves in runs: wave w owns rows
+  // [w KK / NW, (w + 1) KK / NW) -- MAXR or MAXR - 1 of them
+  static constexpr int MAXR = (KK + NW - 1) / NW;
+  static constexpr bool EVEN = KK % NW == 0;
   static constexpr int QY = S * (TY - 1) + K, QX = S * (WP - 1) + K;
   static constexpr int QRS = QX, QPS = QY * QRS;
   static constexpr int QCS = w16_stride(K * QPS, S);       // q channel stride (bank spread of the B reads)
@@ -55,14 +61,15 @@ struct W16 {
   static constexpr int QIT = (K * QPS + NT - 1) / NT, PIT = (TY * WP + NT - 1) / NT;   // DMA instructions per channel
 };
 
-template <class C>
-__global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ p, const float* __restrict__ q,
-                                                      float* __restrict__ slabs, W16Dims d) {
-  constexpr int K = C::K, S = C::S, WP = C::WP, TY = C::TY, KK = C::KK, K3 = C::K3, QRS = C::QRS, QPS = C::QPS,
+// the whole item loop for a wave that owns NR tap rows starting at row0 (every wave of the workgroup runs the same
+// number of barriers whichever NR it has)
+template <class C, int NR>
+__device__ __forceinline__ void w16_run(const float* __restrict__ p, const float* __restrict__ q,
+                                        float* __restrict__ slabs, const W16Dims& d, float* lds, int row0) {
+  constexpr int K = C::K, S = C::S, WP = C::WP, TY = C::TY, K3 = C::K3, QRS = C::QRS, QPS = C::QPS,
                 QCS = C::QCS, PCS = C::PCS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = kz of this wave's taps
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   const int ag = blockIdx.y;                                       // group of 16 p-channels
   const int first = blockIdx.x * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
@@ -101,9 +108,14 @@ __global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ 
     }
   };
 
-  f32x4 acc[KK];
+  // LDS word of tap row r (kz, ky) relative to the (y, x group) origin of a q tile
+  int roff[NR];
 #pragma unroll
-  for (int t = 0; t < KK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < NR; ++r) roff[r] = ((row0 + r) / K) * QPS + ((row0 + r) % K) * QRS;
+
+  f32x4 acc[NR * K];
+#pragma unroll
+  for (int t = 0; t < NR * K; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (first < last) stage(first, 0);
 #pragma unroll 1
   for (int item = first; item < last; ++item) {
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the item has landed
     __syncthreads();                                              // ... everyone's; the other buffer is free
     if (item + 1 < last) stage(item + 1, buf ^ 1);
-    const float* qs = lds + buf * C::BUF + j * QCS + wave * QPS + S * kq;
+    const float* qs = lds + buf * C::BUF + j * QCS + S * kq;
     const float* ps = lds + buf * C::BUF + 16 * QCS + j * PCS + kq;
 #pragma unroll 1
     for (int y = 0; y < TY; ++y) {
@@ -119,21 +131,21 @@ __global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ 
       const float* pr = ps + y * WP;
       float bc[K], bn[K];
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) bc[kx] = qr[kx];
+      for (int kx = 0; kx < K; ++kx) bc[kx] = qr[roff[0] + kx];
 #pragma unroll
       for (int xg = 0; xg < WP / 4; ++xg) {
         const float a = pr[4 * xg];
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-          // next row of taps: (xg, ky + 1), or (xg + 1, 0)
-          const int nky = ky + 1 < K ? ky + 1 : 0, nxg = ky + 1 < K ? xg : xg + 1;
+        for (int r = 0; r < NR; ++r) {
+          // next row of taps: (xg, r + 1), or (xg + 1, 0)
+          const int nr = r + 1 < NR ? r + 1 : 0, nxg = r + 1 < NR ? xg : xg + 1;
           if (nxg < WP / 4) {
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) bn[kx] = qr[nky * QRS + S * 4 * nxg + kx];
+            for (int kx = 0; kx < K; ++kx) bn[kx] = qr[roff[nr] + S * 4 * nxg + kx];
           }
 #pragma unroll
           for (int kx = 0; kx < K; ++kx)
-            acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[kx], acc[ky * K + kx], 0, 0, 0);
+            acc[r * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[kx], acc[r * K + kx], 0, 0, 0);
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) bc[kx] = bn[kx];
           __builtin_amdgcn_sched_barrier(0);
@@ -144,10 +156,24 @@ __global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ 
   // slab [ac][16][K^3]: lane holds D[a = 4 kq + r4][b = j] of each of this wave's taps
   float* slab = slabs + (size_t)blockIdx.x * d.ac * 16 * K3;
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int t = 0; t < NR * K; ++t)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4)
-      slab[((size_t)(ag * 16 + 4 * kq + r4) * 16 + j) * K3 + wave * KK + t] = acc[t][r4];
+      slab[((size_t)(ag * 16 + 4 * kq + r4) * 16 + j) * K3 + row0 * K + t] = acc[t][r4];
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ p, const float* __restrict__ q,
+                                                      float* __restrict__ slabs, W16Dims d) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = wave * C::KK / C::NW, row1 = (wave + 1) * C::KK / C::NW;
+  if constexpr (C::EVEN) {
+    w16_run<C, C::MAXR>(p, q, slabs, d, lds, row0);
+  } else {
+    if (row1 - row0 == C::MAXR) w16_run<C, C::MAXR>(p, q, slabs, d, lds, row0);
+    else w16_run<C, C::MAXR - 1>(p, q, slabs, d, lds, row0);
+  }
 }
 
 template <class C>
@@ -171,9 +197,9 @@ int nvf_wgrad16_launch(const float* p, const float* q, float* slabs, int batch, 
   W16Dims d{batch, a, dp, dq, pad, 0, 0, 0};
   if (a % 16 != 0 || max_slabs <= 0) return 1;
   if (max_slabs > 256) max_slabs = 256;                         // one workgroup per CU and p-channel group
-  if (k == 4 && stride == 1 && dp == 32) return launch_w16<W16<4, 1, 32, 4>>(p, q, slabs, d, max_slabs, nslab, s);
-  if (k == 4 && stride == 1 && dp == 16) return launch_w16<W16<4, 1, 16, 4>>(p, q, slabs, d, max_slabs, nslab, s);
-  if (k == 5 && stride == 2 && dp == 16) return launch_w16<W16<5, 2, 16, 2>>(p, q, slabs, d, max_slabs, nslab, s);
+  if (k == 4 && stride == 1 && dp == 32) return launch_w16<W16<4, 1, 32, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
+  if (k == 4 && stride == 1 && dp == 16) return launch_w16<W16<4, 1, 16, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
+  if (k == 5 && stride == 2 && dp == 16) return launch_w16<W16<5, 2, 16, 2, 8>>(p, q, slabs, d, max_slabs, nslab, s);
   // (up1's 8-wide rows give an A fragment only two uses per tap row: 58 us against 48 us for the VALU tile kernel)
   return 1;
 }
