@@ -76,35 +76,40 @@ __device__ __forceinline__ void w16_run(const float* __restrict__ p, const float
   const size_t pvol = (size_t)d.dp * d.dp * d.dp, qvol = (size_t)d.dq * d.dq * d.dq;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
 
+  // Staging by LDS-DMA.  The launcher only takes shapes whose q tiles lie inside the tensor (pad 0, dq = S (dp - 1) + K)
+  // and whose p rows divide evenly (dp % TY == 0), so a lane's source offset inside the tile is the same for every item
+  // and channel: it is computed once, an instruction then costs a scalar base and one DMA issue (per-element address
+  // arithmetic and bounds checks had cost 40 of conv2's 172 us).
+  unsigned qoff[C::QIT], poff[C::PIT];
+  bool qlive[C::QIT], plive[C::PIT];
+#pragma unroll
+  for (int i = 0; i < C::QIT; ++i) {
+    const int w = (i * C::NW + wave) * 64 + lane;
+    const int zz = w / QPS, rem = w - zz * QPS, yy = rem / QRS, xx = rem - yy * QRS;
+    qlive[i] = w < K * QPS;
+    qoff[i] = qlive[i] ? (unsigned)((zz * d.dq + yy) * d.dq + xx) * 4u : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < C::PIT; ++i) {
+    const int w = (i * C::NW + wave) * 64 + lane;
+    plive[i] = w < TY * WP;
+    poff[i] = plive[i] ? (unsigned)w * 4u : 0u;
+  }
   auto stage = [&](int item, int buf) {
     const int ty = item % d.tiles_y, t = item / d.tiles_y, z = t % d.dp, n = t / d.dp;
     const int y0 = ty * TY;
-    const int qz0 = S * z - d.pad, qy0 = S * y0 - d.pad, qx0 = -d.pad;
-    const float* qb = q + (size_t)n * 16 * qvol;
+    const float* qb = q + (size_t)n * 16 * qvol + ((size_t)(S * z) * d.dq + S * y0) * d.dq;
     const float* pb = p + ((size_t)n * d.ac + ag * 16) * pvol + ((size_t)z * d.dp + y0) * d.dp;
-#pragma unroll 1
+#pragma unroll 2
     for (int c = 0; c < 16; ++c) {
-      const int cb = buf * C::BUF + c * QCS;
+      const unsigned cb = lds0 + (unsigned)(buf * C::BUF + c * QCS) * 4u;
 #pragma unroll
-      for (int i = 0; i < C::QIT; ++i) {
-        const int w0 = (i * C::NW + wave) * 64, w = w0 + lane;
-        const int zz = w / QPS, rem = w - zz * QPS, yy = rem / QRS, xx = rem - yy * QRS;
-        const int gz = qz0 + zz, gy = qy0 + yy, gx = qx0 + xx;
-        const bool live = w < K * QPS;
-        const bool ok = live && gz >= 0 && gz < d.dq && gy >= 0 && gy < d.dq && gx >= 0 && gx < d.dq;
-        if (ok) nvf_glds_lane(qb + (size_t)c * qvol + ((size_t)gz * d.dq + gy) * d.dq + gx, lds0 + (unsigned)(cb + w0) * 4u);
-        else if (live) lds[cb + w] = 0.f;
-      }
-      const int pbase = buf * C::BUF + 16 * QCS + c * PCS;
+      for (int i = 0; i < C::QIT; ++i)
+        if (qlive[i]) nvf_glds_row(qb + (size_t)c * qvol, qoff[i], cb + (unsigned)((i * C::NW + wave) * 64) * 4u);
+      const unsigned pc = lds0 + (unsigned)(buf * C::BUF + 16 * QCS + c * PCS) * 4u;
 #pragma unroll
-      for (int i = 0; i < C::PIT; ++i) {
-        const int w0 = (i * C::NW + wave) * 64, w = w0 + lane;
-        if (w < TY * WP) {
-          const int yy = w / WP;
-          if (y0 + yy < d.dp) nvf_glds_lane(pb + (size_t)c * pvol + w, lds0 + (unsigned)(pbase + w0) * 4u);
-          else lds[pbase + w] = 0.f;
-        }
-      }
+      for (int i = 0; i < C::PIT; ++i)
+        if (plive[i]) nvf_glds_row(pb + (size_t)c * pvol, poff[i], pc + (unsigned)((i * C::NW + wave) * 64) * 4u);
     }
   };
 
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(C::NT) void wgrad16_mfma(const float* __restrict__ 
 
 template <class C>
 int launch_w16(const float* p, const float* q, float* slabs, W16Dims d, int max_slabs, int* nslab, hipStream_t s) {
-  d.tiles_y = (d.dp + C::TY - 1) / C::TY;
+  if (d.dp % C::TY != 0 || d.dp != C::WP) return 1;
+  d.tiles_y = d.dp / C::TY;
   d.items = d.batch * d.dp * d.tiles_y;
   int n = d.items < max_slabs ? d.items : max_slabs;
   d.items_per_wg = (d.items + n - 1) / n;
@@ -196,6 +202,7 @@ int nvf_wgrad16_launch(const float* p, const float* q, float* slabs, int batch, 
                        int dq, int max_slabs, int* nslab, hipStream_t s) {
   W16Dims d{batch, a, dp, dq, pad, 0, 0, 0};
   if (a % 16 != 0 || max_slabs <= 0) return 1;
+  if (pad != 0 || dq != stride * (dp - 1) + k) return 1;        // q tiles inside the tensor (see the staging)
   if (max_slabs > 256) max_slabs = 256;                         // one workgroup per CU and p-channel group
   if (k == 4 && stride == 1 && dp == 32) return launch_w16<W16<4, 1, 32, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
   if (k == 4 && stride == 1 && dp == 16) return launch_w16<W16<4, 1, 16, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
