@@ -104,24 +104,36 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
   }
 
   // staging by LDS-DMA (global_load_lds_dword: no VGPR destination): wave-instruction i of channel c fills the 64
-  // consecutive LDS words w = (i NW + wave) 64 + lane of that channel's image; words in the row padding are skipped,
-  // words outside the tensor are written as zeros
+  // consecutive LDS words w = (i NW + wave) 64 + lane of that channel's image.  Which element of the tile a lane
+  // fetches, and whether it lies inside the tensor, is the same for every channel and chunk of this workgroup: the
+  // offsets are computed once, the words outside the tensor (and the row padding) are zeroed once in both buffers and
+  // never touched again -- an instruction then costs a scalar base address and one DMA issue.
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
-  auto stage_chunk = [&](int g, int buf) {
-    const float* xc = xb + (size_t)(4 * g) * vol;
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-      const int cbase = buf * C::BUF + c * CS;
+  unsigned soff[NIT];
+  bool sok[NIT];
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int w0 = (i * C::NW + wave) * 64, w = w0 + lane;
-        const int zz = w / PS, rem = w - zz * PS, yy = rem / RS, xx = rem - yy * RS;
-        const int gx = gx0 + xx, gy = gy0 + yy, gz = gz0 + zz;
-        const bool live = w < IZ * PS && xx < IX;
-        const bool ok = live && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din;
-        if (ok) nvf_glds_lane(xc + (size_t)c * vol + ((size_t)gz * d.hin + gy) * d.win + gx, lds0 + (unsigned)(cbase + w0) * 4u);
-        else if (live) lds[cbase + w] = 0.f;
-      }
+  for (int i = 0; i < NIT; ++i) {
+    const int w = (i * C::NW + wave) * 64 + lane;
+    const int zz = w / PS, rem = w - zz * PS, yy = rem / RS, xx = rem - yy * RS;
+    const int gx = gx0 + xx, gy = gy0 + yy, gz = gz0 + zz;
+    const bool live = w < IZ * PS;
+    sok[i] = live && xx < IX && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din;
+    soff[i] = sok[i] ? (unsigned)((zz * d.hin + yy) * d.win + xx) * 4u : 0u;
+    if (live && !sok[i]) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) lds[c * CS + w] = 0.f;          // 2 buffers x 4 channels (BUF = 4 CS)
+    }
+  }
+  const float* xorg = nvf_uniform_ptr(xb + ((ptrdiff_t)gz0 * d.hin + gy0) * d.win + gx0);     // tile origin (may lie in the padding)
+  auto stage_chunk = [&](int g, int buf) {
+    const float* xc = xorg + (size_t)(4 * g) * vol;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned cbase = lds0 + (unsigned)(buf * C::BUF + c * CS) * 4u;
+      const float* src = nvf_uniform_ptr(xc + (size_t)c * vol);
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+        if (sok[i]) nvf_glds_row(src, soff[i], cbase + (unsigned)((i * C::NW + wave) * 64) * 4u);
     }
   };
 

@@ -129,6 +129,12 @@ __device__ __forceinline__ void nvf_lds_row(const float* p, float* out) {
 // One wave-instruction writes LDS[m0 + 4*lane] for every active lane.  M0 is compiler-reserved, so it is
 // saved, set and restored inside the one asm statement that uses it; hipcc does not count these loads,
 // the caller waits with an explicit s_waitcnt vmcnt(0).
+// a pointer the compiler can keep in scalar registers (the "s" operand of nvf_glds_row)
+__device__ __forceinline__ const float* nvf_uniform_ptr(const float* p) {
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const float*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void nvf_glds_row(const float* row_base, unsigned voff_bytes, unsigned lds_byte) {
   unsigned keep;
   asm volatile(
