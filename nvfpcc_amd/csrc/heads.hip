@@ -71,44 +71,89 @@ __device__ __forceinline__ void head_row6(const float* row, int xg, float (&v)[6
   v[5] = xg == XG - 1 ? 0.f : __int_as_float(right);
 }
 
-// ---- forward: p = act(bias + sum_{c,k} x[c, o + k - 1] w[c][k]) -----------------------------------------------
+// ---- forward, channel-pipelined: the tile of ONE input channel (with its y / z halo rows; the x halo comes from the
+// neighbour lanes, head_row6) is staged by LDS-DMA into one of two buffers while the previous channel's 27 taps are
+// being accumulated.  A workgroup needs 8-20 KB of LDS instead of the whole C-channel tile (61-102 KB), so up to
+// eight of them share a CU and one's staging overlaps another's arithmetic; tiles are TZ x TY = 4 x 8 / 8 x 8 whatever
+// C is.  Rows are S words apart (a wave reads 1 KB of consecutive LDS per ds_read_b128, a DMA instruction fills two
+// rows); rows outside the tensor are zeroed once.  Per output the fmaf order is (c, kz, ky, kx) as before.
+template <int C_, int S_, int TZ_, int TY_>
+struct HPCfg {
+  static constexpr int C = C_, S = S_, TZ = TZ_, TY = TY_;
+  static constexpr int XG = S / 4, IZ = TZ + 2, IY = TY + 2;
+  static constexpr int WORDS = IZ * IY * S;            // one channel's tile
+  static constexpr int NACT = TZ * TY * XG;            // one thread per four outputs
+  static constexpr int NT = 256, NW = 4;
+  static constexpr int NIT = (WORDS + NT - 1) / NT;    // DMA instructions per wave per channel
+  static_assert(S % 4 == 0 && NACT <= NT && NACT % 64 == 0 && WORDS % 4 == 0, "tile");
+};
 template <class H>
-struct HFwdSmem { static constexpr int WORDS = H::C * H::IZ * H::IY * H::RS + H::C * 9 * 4; };
+struct HFwdSmem { static constexpr int WORDS = 2 * H::WORDS + H::C * 9 * 4; };
 
 template <class H>
 __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
                                               const float* __restrict__ bias, float* __restrict__ y,
                                               const float* __restrict__ addend, const float* __restrict__ mask, int act,
                                               int bid, float* smem) {
-  constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, RS = H::RS, IZ = H::IZ, IY = H::IY, XG = H::XG, NT = H::NT;
+  constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, IY = H::IY, XG = H::XG, NT = H::NT, NIT = H::NIT,
+                WORDS = H::WORDS;
   float* xs = smem;
-  float* ws = smem + C * IZ * IY * RS;
-  const int tid = threadIdx.x;
+  float* ws = smem + 2 * WORDS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
   const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
   for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
-  head_stage<C, S, IZ, IY, RS, NT>(x + (size_t)b * C * S * S * S, xs, tid, z0, y0);
-  __syncthreads();
-  if (tid >= H::NACT) return;
+  // which element of a channel volume each of this lane's DMA instructions fetches (the same for every channel)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xs;
+  unsigned soff[NIT];
+  bool sok[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int wd = (i * H::NW + wave) * 64 + lane;
+    const int r = wd / S, xx = wd - r * S, yi = r % IY, zi = r / IY;
+    const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
+    const bool live = wd < WORDS;
+    sok[i] = live && gz >= 0 && gz < S && gy >= 0 && gy < S;
+    soff[i] = sok[i] ? (unsigned)((gz * S + gy) * S + xx) * 4u : 0u;
+    if (live && !sok[i]) { xs[wd] = 0.f; xs[WORDS + wd] = 0.f; }
+  }
+  const float* xb = x + (size_t)b * C * S * S * S;
+  auto stage = [&](int c, int buf) {
+    const float* src = nvf_uniform_ptr(xb + (size_t)c * S * S * S);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+      if (sok[i]) nvf_glds_row(src, soff[i], lds0 + (unsigned)(buf * WORDS + (i * H::NW + wave) * 64) * 4u);
+  };
+  stage(0, 0);
+  const bool active = tid < H::NACT;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int c = 0; c < C; ++c)
+  for (int c = 0; c < C; ++c) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of channel c has landed
+    __syncthreads();                                              // ... everyone's; the other buffer is free
+    if (c + 1 < C) stage(c + 1, (c + 1) & 1);
+    if (active) {
+      const float* xc = xs + (c & 1) * WORDS;
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz)
+      for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const float* row = xs + ((size_t)(c * IZ + tz + kz) * IY + ty + ky) * RS + 4 * xg;
-        float v[6];
-        head_row6<XG>(row, xg, v);
-        const float4 wv = *(const float4*)(ws + (c * 9 + kz * 3 + ky) * 4);
-        const float wk[3] = {wv.x, wv.y, wv.z};
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* row = xc + ((tz + kz) * IY + ty + ky) * S + 4 * xg - 4;     // head_row6 reads row + 4
+          float v[6];
+          head_row6<XG>(row, xg, v);
+          const float4 wv = *(const float4*)(ws + (c * 9 + kz * 3 + ky) * 4);
+          const float wk[3] = {wv.x, wv.y, wv.z};
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+          for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + kx], wk[kx], acc[o]);
-      }
+            for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + kx], wk[kx], acc[o]);
+        }
+    }
+  }
+  if (!active) return;
   const float bv = bias ? bias[0] : 0.f;
   const size_t off = (((size_t)b * S + z0 + tz) * S + y0 + ty) * S + 4 * xg;
   float o[4];
@@ -422,16 +467,16 @@ int nvf_head_fwd_launch(const float* x, const float* w, const float* bias, float
                         const float* mask, int batch, int c, int s, int act, hipStream_t st) {
 #define NVF_H(CC, SS, TZ, TY)                                                                                   \
   if (c == CC && s == SS) {                                                                                     \
-    using H = HCfg<CC, SS, TZ, TY>;                                                                             \
+    using H = HPCfg<CC, SS, TZ, TY>;                                                                            \
     head_fwd_kernel<H><<<batch * (SS / TZ) * (SS / TY), H::NT, 0, st>>>(x, w, bias, y, addend, mask, act);      \
     return 0;                                                                                                   \
   }
   NVF_H(8, 32, 4, 8)
-  NVF_H(8, 16, 4, 4)
-  NVF_H(16, 8, 4, 8)
-  NVF_H(16, 32, 2, 8)
-  NVF_H(16, 16, 4, 4)
-  NVF_H(32, 8, 4, 8)
+  NVF_H(8, 16, 8, 8)
+  NVF_H(16, 8, 8, 8)
+  NVF_H(16, 32, 4, 8)
+  NVF_H(16, 16, 8, 8)
+  NVF_H(32, 8, 8, 8)
 #undef NVF_H
   return 1;
 }
@@ -509,8 +554,8 @@ extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, co
                               float* const* ps, const int* cs, const int* ss, int batch, int act, void* stream) {
   if (!xs || !ws || !biases || !ps || !cs || !ss || batch <= 0) return NVF_EINVAL;
   const int t = heads3_tuple(cs, ss);
-  if (t == 0) return heads3_fwd_t<HCfg<16, 8, 4, 8>, HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
-  if (t == 1) return heads3_fwd_t<HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 2, 8>>(xs, ws, biases, ps, batch, act, stream);
+  if (t == 0) return heads3_fwd_t<HPCfg<16, 8, 8, 8>, HPCfg<8, 16, 8, 8>, HPCfg<8, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
+  if (t == 1) return heads3_fwd_t<HPCfg<32, 8, 8, 8>, HPCfg<16, 16, 8, 8>, HPCfg<16, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
   return NVF_EINVAL;
 }
 
