@@ -77,9 +77,10 @@ __device__ __forceinline__ void head_row6(const float* row, int xg, float (&v)[6
 // eight of them share a CU and one's staging overlaps another's arithmetic; tiles are TZ x TY = 4 x 8 / 8 x 8 whatever
 // C is.  Rows are S words apart (a wave reads 1 KB of consecutive LDS per ds_read_b128, a DMA instruction fills two
 // rows); rows outside the tensor are zeroed once.  Per output the fmaf order is (c, kz, ky, kx) as before.
-template <int C_, int S_, int TZ_, int TY_>
+template <int C_, int S_, int TZ_, int TY_, int CPS_ = 1>
 struct HPCfg {
-  static constexpr int C = C_, S = S_, TZ = TZ_, TY = TY_;
+  static constexpr int C = C_, S = S_, TZ = TZ_, TY = TY_, CPS = CPS_;   // CPS channels per pipeline step (small tiles:
+  static_assert(C % CPS == 0, "whole steps");                            //  a step costs ~1 us of latency whatever its size)
   static constexpr int XG = S / 4, IZ = TZ + 2, IY = TY + 2;
   static constexpr int WORDS = IZ * IY * S;            // one channel's tile
   static constexpr int NACT = TZ * TY * XG;            // one thread per four outputs
@@ -88,7 +89,7 @@ struct HPCfg {
   static_assert(S % 4 == 0 && NACT <= NT && NACT % 64 == 0 && WORDS % 4 == 0, "tile");
 };
 template <class H>
-struct HFwdSmem { static constexpr int WORDS = 2 * H::WORDS + H::C * 9 * 4; };
+struct HFwdSmem { static constexpr int WORDS = 2 * H::CPS * H::WORDS + H::C * 9 * 4; };
 
 template <class H>
 __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
@@ -96,9 +97,9 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const
                                               const float* __restrict__ addend, const float* __restrict__ mask, int act,
                                               int bid, float* smem) {
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, IY = H::IY, XG = H::XG, NT = H::NT, NIT = H::NIT,
-                WORDS = H::WORDS;
+                WORDS = H::WORDS, CPS = H::CPS;
   float* xs = smem;
-  float* ws = smem + 2 * WORDS;
+  float* ws = smem + 2 * CPS * WORDS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int TILES_Y = S / TY, TILES_Z = S / TZ;
@@ -117,40 +118,51 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const
     const bool live = wd < WORDS;
     sok[i] = live && gz >= 0 && gz < S && gy >= 0 && gy < S;
     soff[i] = sok[i] ? (unsigned)((gz * S + gy) * S + xx) * 4u : 0u;
-    if (live && !sok[i]) { xs[wd] = 0.f; xs[WORDS + wd] = 0.f; }
+    if (live && !sok[i]) {
+#pragma unroll
+      for (int q = 0; q < 2 * CPS; ++q) xs[q * WORDS + wd] = 0.f;
+    }
   }
   const float* xb = x + (size_t)b * C * S * S * S;
-  auto stage = [&](int c, int buf) {
-    const float* src = nvf_uniform_ptr(xb + (size_t)c * S * S * S);
+  auto stage = [&](int step, int buf) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i)
-      if (sok[i]) nvf_glds_row(src, soff[i], lds0 + (unsigned)(buf * WORDS + (i * H::NW + wave) * 64) * 4u);
+    for (int cc = 0; cc < CPS; ++cc) {
+      const float* src = nvf_uniform_ptr(xb + (size_t)(step * CPS + cc) * S * S * S);
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+        if (sok[i])
+          nvf_glds_row(src, soff[i], lds0 + (unsigned)((buf * CPS + cc) * WORDS + (i * H::NW + wave) * 64) * 4u);
+    }
   };
   stage(0, 0);
   const bool active = tid < H::NACT;
   const int xg = tid % XG, ty = (tid / XG) % TY, tz = tid / (XG * TY);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int c = 0; c < C; ++c) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of channel c has landed
+  for (int step = 0; step < C / CPS; ++step) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of the step has landed
     __syncthreads();                                              // ... everyone's; the other buffer is free
-    if (c + 1 < C) stage(c + 1, (c + 1) & 1);
+    if (step + 1 < C / CPS) stage(step + 1, (step + 1) & 1);
     if (active) {
-      const float* xc = xs + (c & 1) * WORDS;
+#pragma unroll 1
+      for (int cc = 0; cc < CPS; ++cc) {
+        const int c = step * CPS + cc;
+        const float* xc = xs + ((step & 1) * CPS + cc) * WORDS;
 #pragma unroll
-      for (int kz = 0; kz < 3; ++kz)
+        for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const float* row = xc + ((tz + kz) * IY + ty + ky) * S + 4 * xg - 4;     // head_row6 reads row + 4
-          float v[6];
-          head_row6<XG>(row, xg, v);
-          const float4 wv = *(const float4*)(ws + (c * 9 + kz * 3 + ky) * 4);
-          const float wk[3] = {wv.x, wv.y, wv.z};
+          for (int ky = 0; ky < 3; ++ky) {
+            const float* row = xc + ((tz + kz) * IY + ty + ky) * S + 4 * xg - 4;     // head_row6 reads row + 4
+            float v[6];
+            head_row6<XG>(row, xg, v);
+            const float4 wv = *(const float4*)(ws + (c * 9 + kz * 3 + ky) * 4);
+            const float wk[3] = {wv.x, wv.y, wv.z};
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + kx], wk[kx], acc[o]);
-        }
+              for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + kx], wk[kx], acc[o]);
+          }
+      }
     }
   }
   if (!active) return;
@@ -425,11 +437,11 @@ constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b >
 template <class H0, class H1, class H2>
 __global__ __launch_bounds__(256) void heads3_fwd_kernel(Heads3 m) {
   __shared__ __attribute__((aligned(16))) float smem[cmax3(HFwdSmem<H0>::WORDS, HFwdSmem<H1>::WORDS, HFwdSmem<H2>::WORDS)];
-  const int bid = blockIdx.x;                          // the big head's workgroups first: the small ones fill the tail
-  if (bid < m.n[2]) head_fwd_body<H2>(m.a[2], m.w[2], m.bias[2], m.out[2], nullptr, nullptr, m.act, bid, smem);
-  else if (bid < m.n[2] + m.n[1])
-    head_fwd_body<H1>(m.a[1], m.w[1], m.bias[1], m.out[1], nullptr, nullptr, m.act, bid - m.n[2], smem);
-  else head_fwd_body<H0>(m.a[0], m.w[0], m.bias[0], m.out[0], nullptr, nullptr, m.act, bid - m.n[2] - m.n[1], smem);
+  const int bid = blockIdx.x;       // the small heads' few workgroups first: theirs is the longest chain of steps
+  if (bid < m.n[0]) head_fwd_body<H0>(m.a[0], m.w[0], m.bias[0], m.out[0], nullptr, nullptr, m.act, bid, smem);
+  else if (bid < m.n[0] + m.n[1])
+    head_fwd_body<H1>(m.a[1], m.w[1], m.bias[1], m.out[1], nullptr, nullptr, m.act, bid - m.n[0], smem);
+  else head_fwd_body<H2>(m.a[2], m.w[2], m.bias[2], m.out[2], nullptr, nullptr, m.act, bid - m.n[0] - m.n[1], smem);
 }
 
 template <class H0, class H1, class H2>
@@ -465,18 +477,18 @@ __global__ __launch_bounds__(256) void heads3_wgrad_kernel(Heads3 m) {
 // return 1 when there is no instantiation for the shape (the caller falls back to the general kernels)
 int nvf_head_fwd_launch(const float* x, const float* w, const float* bias, float* y, const float* addend,
                         const float* mask, int batch, int c, int s, int act, hipStream_t st) {
-#define NVF_H(CC, SS, TZ, TY)                                                                                   \
+#define NVF_H(CC, SS, TZ, TY, CPS)                                                                              \
   if (c == CC && s == SS) {                                                                                     \
-    using H = HPCfg<CC, SS, TZ, TY>;                                                                            \
+    using H = HPCfg<CC, SS, TZ, TY, CPS>;                                                                       \
     head_fwd_kernel<H><<<batch * (SS / TZ) * (SS / TY), H::NT, 0, st>>>(x, w, bias, y, addend, mask, act);      \
     return 0;                                                                                                   \
   }
-  NVF_H(8, 32, 4, 8)
-  NVF_H(8, 16, 8, 8)
-  NVF_H(16, 8, 8, 8)
-  NVF_H(16, 32, 4, 8)
-  NVF_H(16, 16, 8, 8)
-  NVF_H(32, 8, 8, 8)
+  NVF_H(8, 32, 4, 8, 1)
+  NVF_H(8, 16, 8, 8, 2)
+  NVF_H(16, 8, 8, 8, 4)
+  NVF_H(16, 32, 4, 8, 1)
+  NVF_H(16, 16, 8, 8, 2)
+  NVF_H(32, 8, 8, 8, 4)
 #undef NVF_H
   return 1;
 }
@@ -554,8 +566,8 @@ extern "C" int nvf_heads3_fwd(const float* const* xs, const float* const* ws, co
                               float* const* ps, const int* cs, const int* ss, int batch, int act, void* stream) {
   if (!xs || !ws || !biases || !ps || !cs || !ss || batch <= 0) return NVF_EINVAL;
   const int t = heads3_tuple(cs, ss);
-  if (t == 0) return heads3_fwd_t<HPCfg<16, 8, 8, 8>, HPCfg<8, 16, 8, 8>, HPCfg<8, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
-  if (t == 1) return heads3_fwd_t<HPCfg<32, 8, 8, 8>, HPCfg<16, 16, 8, 8>, HPCfg<16, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
+  if (t == 0) return heads3_fwd_t<HPCfg<16, 8, 8, 8, 4>, HPCfg<8, 16, 8, 8, 2>, HPCfg<8, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
+  if (t == 1) return heads3_fwd_t<HPCfg<32, 8, 8, 8, 4>, HPCfg<16, 16, 8, 8, 2>, HPCfg<16, 32, 4, 8>>(xs, ws, biases, ps, batch, act, stream);
   return NVF_EINVAL;
 }
 
