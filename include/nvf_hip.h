@@ -193,12 +193,12 @@ int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, co
 int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs, float* const* slabs, const int* cs,
                              const int* ss, int batch, int max_slabs, int* nslabs, void* stream);
 
-/* ---- fused stem for chanstr c0 = 8, c1 = 16, ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) -------------
+/* ---- fused stem for chanstr (c0, c1) = (8, 16) or (16, 32), ch <= 8 (network.py:4759-4760; gdn_3d.py:137-159) ----
  * forward : a0 = up0(x0) (convT k5 s2 p2 op1), h0 = IGDN(a0), y1 = ReLU(conv0(h0)); all three are outputs.
  * backward: from g1 = dL/d(conv0 pre-activation): da0 (= dL/d a0, after the IGDN backward) and dx0; when
  *           dbeta_hat, dgamma_hat and dw_up0 are all non-NULL also the IGDN parameter gradients and up0's weight
- *           gradient [ch][8][5][5][5] (overwritten).  Intermediates in LDS; the workspace (always required)
- *           also holds conv0's backward-data partials, batch x 8 x 512 floats.
+ *           gradient [ch][c0][5][5][5] (overwritten).  Intermediates in LDS; the workspace (always required,
+ *           nvf_stem_bwd_workspace_for bytes) also holds conv0's backward-data partials, batch x c1/2 x c0 x 64 floats.
  * Weights are the packed layouts: *_w_fwd = [cin][125][cout], *_w_bwd = [cout][125][cin]. */
 int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
                  const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
@@ -213,7 +213,8 @@ int nvf_stem_latent_fwd(const float* e, const float* lat_w_fwd, const float* lat
                         const uint64_t* step_dev, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
                         const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
                         float* y1, int batch, int ch, int c0, int c1, void* stream);
-size_t nvf_stem_bwd_workspace(int batch, int ch);
+size_t nvf_stem_bwd_workspace(int batch, int ch);                           /* (c0, c1) = (8, 16) */
+size_t nvf_stem_bwd_workspace_for(int batch, int ch, int c0, int c1);       /* 0: no kernel for (c0, c1) */
 int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                  const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
                  float* dbeta_hat, float* dgamma_hat, float* dw_up0, void* workspace, size_t workspace_bytes,

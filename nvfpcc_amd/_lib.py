@@ -52,6 +52,7 @@ PROTOTYPES = {
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "nvf_stem_latent_fwd": (I, [P] * 12 + [I, U, U, P] + [P] * 9 + [I, I, I, I, P]),
     "nvf_stem_bwd_workspace": (Z, [I, I]),
+    "nvf_stem_bwd_workspace_for": (Z, [I, I, I, I]),
     "nvf_stem_bwd": (I, [P] * 13 + [Z, I, I, I, I, P]),
     "nvf_stem_bwd_partial": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P, P]),
     "nvf_wgrad_workspace": (Z, [I] * 7),

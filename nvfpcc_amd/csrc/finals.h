@@ -120,19 +120,21 @@ struct StemGdnFinal {
   int32_t nslab, c0;
 };
 
-__device__ __forceinline__ void stem_gdn_final_body(const StemGdnFinal& f, int p) {
+// thread p0 of `stride` takes the columns p0, p0 + stride, ... (c0 + c0^2 columns: 72 narrow, 272 wide)
+__device__ __forceinline__ void stem_gdn_final_body(const StemGdnFinal& f, int p0, int stride) {
   const int ncol = f.c0 + f.c0 * f.c0;
-  if (p >= ncol) return;
-  float s = 0.f;
-  for (int g = 0; g < f.nslab; ++g) s += f.slab_gdn[(size_t)g * ncol + p];
-  if (p < f.c0) {
-    const float h = f.beta_hat[p];
-    const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
-    f.dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
-  } else {
-    const float h = f.gamma_hat[p - f.c0];
-    const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
-    f.dgamma_hat[p - f.c0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+  for (int p = p0; p < ncol; p += stride) {
+    float s = 0.f;
+    for (int g = 0; g < f.nslab; ++g) s += f.slab_gdn[(size_t)g * ncol + p];
+    if (p < f.c0) {
+      const float h = f.beta_hat[p];
+      const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
+      f.dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+    } else {
+      const float h = f.gamma_hat[p - f.c0];
+      const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
+      f.dgamma_hat[p - f.c0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+    }
   }
 }
 
@@ -163,7 +165,7 @@ struct FinalsArgs {
 // own final pass as usual.
 struct NvfStepCtx;
 bool nvf_finals_push_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm);
-// queue the stem's IGDN final pass or, when nothing is being deferred, launch it on `stream` (c0 + c0^2 <= 128)
+// queue the stem's IGDN final pass or, when nothing is being deferred, launch it on `stream` (any c0)
 int nvf_finals_run_stem_gdn(NvfStepCtx* ctx, const StemGdnFinal& f, void* stream);
 // queue the focal final pass or, when nothing is being deferred, launch it on `stream`
 int nvf_finals_run_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);

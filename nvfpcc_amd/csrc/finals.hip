@@ -19,7 +19,7 @@ __global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a, int sum_block
   } else if (blockIdx.x == 1) {
     if (a.has_r && tid < 64)
       weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost, tid);
-    if (a.has_g && tid >= 64) stem_gdn_final_body(a.g, tid - 64);
+    if (a.has_g && tid >= 64) stem_gdn_final_body(a.g, tid - 64, 128);
   } else if (a.has_s && tid < 64) {
     multi_channel_sum_final_body(a.s, a.s_part, ((int)blockIdx.x - 2) * 64 + tid);
   }
@@ -57,10 +57,9 @@ bool nvf_finals_push_rate(NvfStepCtx* ctx, const WeightRateBatch& b, const float
   return true;
 }
 
-__global__ void stem_gdn_final_kernel(StemGdnFinal f) { stem_gdn_final_body(f, threadIdx.x); }
+__global__ void stem_gdn_final_kernel(StemGdnFinal f) { stem_gdn_final_body(f, threadIdx.x, 128); }
 
 int nvf_finals_run_stem_gdn(NvfStepCtx* ctx, const StemGdnFinal& f, void* stream) {
-  if (f.c0 + f.c0 * f.c0 > 128) return NVF_EINVAL;
   if (nvf_ctx_ok(ctx) && ctx->deferring && !ctx->args.has_g) {
     ctx->args.g = f; ctx->args.has_g = 1;
     return NVF_OK;

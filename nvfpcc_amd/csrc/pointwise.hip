@@ -964,22 +964,22 @@ __device__ __forceinline__ int layout_to_kernel_index(const NvfLayerDesc& d, int
 
 __global__ void step_head_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q, uint64_t seed,
                                  uint64_t step, const uint64_t* __restrict__ step_dev, PackJobs pk, GatherMulti g,
-                                 const int64_t* __restrict__ idx, int rows, int gwg) {
-  int bid = blockIdx.x;
-  if (bid < 16 * nlayers) { prepare_weights_body(table, q, seed, step, step_dev, bid >> 4, bid & 15, 16); return; }
-  bid -= 16 * nlayers;
-  if (bid < 16 * pk.n) {
-    const int job = bid >> 4;
+                                 const int64_t* __restrict__ idx, int rows, int gwg, int wpl) {
+  int bid = blockIdx.x;        // wpl workgroups per layer / pack job
+  if (bid < wpl * nlayers) { prepare_weights_body(table, q, seed, step, step_dev, bid / wpl, bid % wpl, wpl); return; }
+  bid -= wpl * nlayers;
+  if (bid < wpl * pk.n) {
+    const int job = bid / wpl;
     const NvfLayerDesc d = table[pk.layer[job]];
     const int qq = d.quantised ? q : 0, bwd = pk.bwd[job];
     const uint64_t st = step + (step_dev ? step_dev[0] : 0ull);
     const uint64_t sid = (st << 8) | (uint64_t)d.layer_id;
-    pack_mfma_body(pk, job, bid & 15, 16, [&](int, int si) {
+    pack_mfma_body(pk, job, bid % wpl, wpl, [&](int, int si) {
       return effective_weight(d, layout_to_kernel_index(d, bwd, si), qq, seed, sid);
     });
     return;
   }
-  bid -= 16 * pk.n;
+  bid -= wpl * pk.n;
   gather_rows_multi_body(g, idx, rows, bid / gwg, bid % gwg, gwg);
 }
 
@@ -1005,8 +1005,12 @@ extern "C" int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t
   long wg = 0;
   const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
   if (rc != NVF_OK) return rc;
-  step_head_kernel<<<16 * nlayers + 16 * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
-      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg);
+  // 16 workgroups per layer and pack job; 64 for the wide decoder's kernels (up to 64 000 weights each: 31 -> us)
+  int wpl = 16;
+  for (int j = 0; j < npack; ++j)
+    if (pack_c0s && pack_c1s && pack_c0s[j] * pack_c1s[j] >= 256) wpl = 64;
+  step_head_kernel<<<wpl * nlayers + wpl * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
+      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

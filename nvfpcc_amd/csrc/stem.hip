@@ -1,6 +1,7 @@
-// Fused "stem" of the NVF decoder for chanstr c0 = 8, c1 = 16 (latent channels ch <= 8):
+// Fused "stem" of the NVF decoder for chanstr (c0, c1) = (8, 16) -- the narrow decoder -- and (16, 32) -- the wide
+// one (latent channels ch <= 8); kernels are templates on <C0, C1>, C0 * 64 threads per workgroup:
 //
-//   forward :  x0 [ch,2^3] --up0 (convT k5 s2 p2)--> a0 [8,4^3] --IGDN--> h0 --conv0 (convT k5 s2 p2)+ReLU--> y1 [16,8^3]
+//   forward :  x0 [ch,2^3] --up0 (convT k5 s2 p2)--> a0 [C0,4^3] --IGDN--> h0 --conv0 (convT k5 s2 p2)+ReLU--> y1 [C1,8^3]
 //   backward:  g1 = dL/d(conv0 pre-activation) --> dh0 --> IGDN backward (da0, d beta, d gamma) --> dx0,
 //              plus up0's weight gradient
 //
@@ -16,7 +17,7 @@
 #include "latent_tail.h"
 
 namespace {
-constexpr int C0 = 8, C1 = 16, MAXCH = 8;
+constexpr int MAXCH = 8;
 
 __device__ __forceinline__ float st_beta(float bh) {
   float m = fmaxf(bh, NVF_BETA_BOUND);
@@ -30,7 +31,7 @@ __device__ __forceinline__ float st_gamma(float gh) {
 
 // conv0 for one output parity class (EZ,EY,EX): lane = cell, COG output channels in registers, taps unrolled so
 // the LDS reads of a whole input channel are in flight together.  Weights come from the LDS copy s_w[ci*125+tap][COG].
-template <int EZ, int EY, int EX, int COG>
+template <int C0, int C1, int EZ, int EY, int EX, int COG>
 __device__ __forceinline__ void stem_conv0_class(const float* s_h, const float* s_w, const float* __restrict__ b1,
                                                  float* __restrict__ y1, int b, int co0, int v) {
   const int mz = (v >> 4) + 1, my = ((v >> 2) & 3) + 1, mx = (v & 3) + 1;   // cells 1..4 (pad 2)
@@ -82,36 +83,41 @@ struct StemLatent {
   int32_t mode, batch;
 };
 
-template <int COG, bool LATENT>
-__global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w0,
-                                                       const float* __restrict__ b0,
-                                                       const float* __restrict__ beta_hat,
-                                                       const float* __restrict__ gamma_hat,
-                                                       const float* __restrict__ w1, const float* __restrict__ b1,
-                                                       float* __restrict__ a0, float* __restrict__ h0,
-                                                       float* __restrict__ y1, int ch, StemLatent L) {
+template <int C0, int C1, int COG, bool LATENT>
+__global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w0,
+                                                           const float* __restrict__ b0,
+                                                           const float* __restrict__ beta_hat,
+                                                           const float* __restrict__ gamma_hat,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           float* __restrict__ a0, float* __restrict__ h0,
+                                                           float* __restrict__ y1, int ch, StemLatent L) {
+  constexpr int NT = C0 * 64, NCG = C0 / 8;      // NCG groups of eight waves (one per parity class) in the conv0 phase,
+  constexpr int PARTS = C1 / (COG * NCG);        //  each with its own COG output channels
   __shared__ float s_x[MAXCH * 8];
   __shared__ float s_a[C0 * 64];
-  if (LATENT && blockIdx.y == C1 / COG) {
+  __shared__ __attribute__((aligned(16))) float s_w0[MAXCH * 125 * C0];
+  if (LATENT && blockIdx.y == PARTS) {
     if (blockIdx.x == 0)
       latent_fwd_body(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, L.block_ids, L.sigma, L.mu, L.h_out, L.lat_out,
-                      L.x_rounded, L.bits, L.batch, ch, 8, L.mode, L.seed, L.step, L.step_dev, s_a, s_a + 160,
-                      C0 * 64 - 160);
+                      L.x_rounded, L.bits, L.batch, ch, 8, L.mode, L.seed, L.step, L.step_dev, s_a, s_w0,
+                      MAXCH * 125 * C0);
     return;
   }
   __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1
-  __shared__ __attribute__((aligned(16))) float s_w0[MAXCH * 125 * C0];
-  __shared__ __attribute__((aligned(16))) float s_w1[C0 * 125 * COG];
+  __shared__ __attribute__((aligned(16))) float s_w1[NCG * C0 * 125 * COG];
   __shared__ float s_beta[C0], s_gamma[C0 * C0];
-  const int b = blockIdx.x, part = blockIdx.y, co0 = part * COG, tid = threadIdx.x;
+  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
   if (tid < ch * 8)
     s_x[tid] = LATENT ? latent_x_rounded(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, b, tid >> 3, tid & 7, ch, 8)
                       : x0[(size_t)b * ch * 8 + tid];
   if (tid >= 64 && tid < 64 + C0) s_beta[tid - 64] = st_beta(beta_hat[tid - 64]);
   if (tid >= 128 && tid < 128 + C0 * C0) s_gamma[tid - 128] = st_gamma(gamma_hat[tid - 128]);
-  for (int e = tid; e < C0 * 216; e += 512) s_h[e] = 0.f;
-  for (int e = tid; e < ch * 125 * C0; e += 512) s_w0[e] = w0[e];
-  for (int e = tid; e < C0 * 125 * COG; e += 512) s_w1[e] = w1[(size_t)(e / COG) * C1 + co0 + e % COG];
+  for (int e = tid; e < C0 * 216; e += NT) s_h[e] = 0.f;
+  for (int e = tid; e < ch * 125 * C0; e += NT) s_w0[e] = w0[e];
+  for (int e = tid; e < NCG * C0 * 125 * COG; e += NT) {
+    const int cg = e / (C0 * 125 * COG), r = e - cg * (C0 * 125 * COG);
+    s_w1[e] = w1[(size_t)(r / COG) * C1 + (part * NCG + cg) * COG + r % COG];
+  }
   __syncthreads();
   const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
   {  // up0: a0[co = c, o] = b0 + sum_ci sum_{k : o + 2 - k = 2 i} x0[ci, i] w0[ci][k][co]
@@ -153,30 +159,45 @@ __global__ __launch_bounds__(512) void stem_fwd_kernel(const float* __restrict__
     s_h[c * 216 + ((oz + 1) * 6 + (oy + 1)) * 6 + ox + 1] = hv;
   }
   __syncthreads();
-  // conv0: one wave per output parity class, one lane per cell
-  switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-    case 0: stem_conv0_class<0, 0, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    case 1: stem_conv0_class<0, 0, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    case 2: stem_conv0_class<0, 1, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    case 3: stem_conv0_class<0, 1, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    case 4: stem_conv0_class<1, 0, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    case 5: stem_conv0_class<1, 0, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    case 6: stem_conv0_class<1, 1, 0, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
-    default: stem_conv0_class<1, 1, 1, COG>(s_h, s_w1, b1, y1, b, co0, v); break;
+  // conv0: one wave per output parity class (and channel group), one lane per cell
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wv >> 3, co0 = (part * NCG + cg) * COG;
+  const float* sw = s_w1 + cg * (C0 * 125 * COG);
+  switch (wv & 7) {
+    case 0: stem_conv0_class<C0, C1, 0, 0, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    case 1: stem_conv0_class<C0, C1, 0, 0, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    case 2: stem_conv0_class<C0, C1, 0, 1, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    case 3: stem_conv0_class<C0, C1, 0, 1, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    case 4: stem_conv0_class<C0, C1, 1, 0, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    case 5: stem_conv0_class<C0, C1, 1, 0, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    case 6: stem_conv0_class<C0, C1, 1, 1, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
+    default: stem_conv0_class<C0, C1, 1, 1, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
   }
 }
+
+template <int C0, int C1, bool LATENT>
+static int launch_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
+                           const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
+                           float* y1, int batch, int ch, const StemLatent& L, void* stream) {
+  constexpr int COG = 4, PARTS = C1 / (COG * (C0 / 8));
+  stem_fwd_kernel<C0, C1, COG, LATENT><<<dim3(batch, PARTS + (LATENT ? 1 : 0)), C0 * 64, 0, nvf_stream(stream)>>>(
+      x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch, L);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+static bool stem_shape(int c0, int c1) { return (c0 == 8 && c1 == 16) || (c0 == 16 && c1 == 32); }
 
 extern "C" int nvf_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
                             const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0,
                             float* h0, float* y1, int batch, int ch, int c0, int c1, void* stream) {
   if (!x0 || !up0_w_fwd || !up0_b || !beta_hat || !gamma_hat || !conv0_w_fwd || !conv0_b || !a0 || !h0 || !y1)
     return NVF_EINVAL;
-  if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
-  constexpr int COG = 4;
-  stem_fwd_kernel<COG, false><<<dim3(batch, C1 / COG), 512, 0, nvf_stream(stream)>>>(
-      x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch, StemLatent{});
-  NVF_LAUNCH_CHECK();
-  return NVF_OK;
+  if (batch <= 0 || ch <= 0 || ch > MAXCH || !stem_shape(c0, c1)) return NVF_EINVAL;
+  if (c0 == 8)
+    return launch_stem_fwd<8, 16, false>(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1,
+                                         batch, ch, StemLatent{}, stream);
+  return launch_stem_fwd<16, 32, false>(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1,
+                                        batch, ch, StemLatent{}, stream);
 }
 
 // nvf_latent_fwd (e -> h, lat, x_rounded, bits) and nvf_stem_fwd (x_rounded -> a0, h0, y1) in ONE launch; same results
@@ -191,38 +212,40 @@ extern "C" int nvf_stem_latent_fwd(const float* e, const float* lat_w_fwd, const
   if (!e || !lat_w_fwd || !lat_bias || !lat_beta_hat || !lat_gamma_hat || !sigma || !mu || !h || !lat || !x_rounded ||
       !bits || !up0_w_fwd || !up0_b || !beta_hat || !gamma_hat || !conv0_w_fwd || !conv0_b || !a0 || !h0 || !y1)
     return NVF_EINVAL;
-  if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1 || (mode != 0 && mode != 1)) return NVF_EINVAL;
-  constexpr int COG = 4;
+  if (batch <= 0 || ch <= 0 || ch > MAXCH || !stem_shape(c0, c1) || (mode != 0 && mode != 1)) return NVF_EINVAL;
   StemLatent L{e, lat_w_fwd, lat_bias, lat_beta_hat, lat_gamma_hat, block_ids, sigma, mu, h, lat, x_rounded, bits,
                step_dev, seed, step, mode, batch};
-  stem_fwd_kernel<COG, true><<<dim3(batch, C1 / COG + 1), 512, 0, nvf_stream(stream)>>>(
-      nullptr, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch, L);
-  NVF_LAUNCH_CHECK();
-  return NVF_OK;
+  if (c0 == 8)
+    return launch_stem_fwd<8, 16, true>(nullptr, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0,
+                                        y1, batch, ch, L, stream);
+  return launch_stem_fwd<16, 32, true>(nullptr, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1,
+                                       batch, ch, L, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
 static const int kStemMaxSlabs = 256;
-static const int kStemNcol = C0 + C0 * C0;          // IGDN parameter partials
-static const int kStemWMax = MAXCH * C0 * 125;      // up0 weight-gradient slab
+constexpr int stem_ncol(int c0) { return c0 + c0 * c0; }          // IGDN parameter partials
+constexpr int kStemWMax = MAXCH * 125;                            // up0 weight-gradient slab: kStemWMax * C0 floats
 
 // conv0 backward-data, split over (block, output-channel pair): part[b][cp][ci][i] = sum over the pair's two co and
-// all 125 taps of g1[co, 2 i - 2 + k] w1[ci][co][k].  256 threads: wave = input-channel pair, lane = position i.
-// The pair's gradients (zero-padded) and weights sit in LDS; each lane runs the same fmaf chain (cc, kz, ky, kx
-// ascending) the single-workgroup version ran, so the partials and their fixed-order sum are unchanged bit for bit.
-__global__ __launch_bounds__(256) void stem_bwd_dh_kernel(const float* __restrict__ g1,
-                                                          const float* __restrict__ w1b /* [co16][125][ci8] */,
-                                                          float* __restrict__ part) {
+// all 125 taps of g1[co, 2 i - 2 + k] w1[ci][co][k].  C0 / 2 waves: wave = input-channel pair, lane = position i.
+// The pair's gradients (zero-padded) and weights sit in LDS; each lane runs the fmaf chain (cc, kz, ky, kx ascending),
+// the partials are added in ascending pair order by stem_bwd_kernel.
+template <int C0, int C1>
+__global__ __launch_bounds__(C0 * 32) void stem_bwd_dh_kernel(const float* __restrict__ g1,
+                                                              const float* __restrict__ w1b /* [co][125][ci] */,
+                                                              float* __restrict__ part) {
+  constexpr int NT = C0 * 32;
   __shared__ float s_g[2 * 1331];                                   // [cc][11][11][11], index q + 2
   __shared__ __attribute__((aligned(16))) float s_w[2 * 125 * C0];  // [cc][k][ci]
   const int b = blockIdx.x, cp = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < 2 * 1331; e += 256) s_g[e] = 0.f;
-  for (int e = tid; e < 2 * 125 * C0; e += 256) s_w[e] = w1b[(size_t)cp * 2 * 125 * C0 + e];
+  for (int e = tid; e < 2 * 1331; e += NT) s_g[e] = 0.f;
+  for (int e = tid; e < 2 * 125 * C0; e += NT) s_w[e] = w1b[(size_t)cp * 2 * 125 * C0 + e];
   __syncthreads();
-  for (int e = tid; e < 2 * 512; e += 256) {
+  for (int e = tid; e < 2 * 512; e += NT) {
     const int cc = e >> 9, q = e & 511;
     s_g[cc * 1331 + (((q >> 6) + 2) * 11 + ((q >> 3) & 7) + 2) * 11 + (q & 7) + 2] =
         g1[((size_t)b * C1 + 2 * cp) * 512 + e];
@@ -246,41 +269,43 @@ __global__ __launch_bounds__(256) void stem_bwd_dh_kernel(const float* __restric
           acc1 = fmaf(gv, w.y, acc1);
         }
   }
-  float* o = part + (((size_t)b * 8 + cp) * C0 + 2 * wv) * 64 + lane;
+  float* o = part + (((size_t)b * (C1 / 2) + cp) * C0 + 2 * wv) * 64 + lane;
   o[0] = acc0;
   o[64] = acc1;
 }
 
-__global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__ part, const float* __restrict__ x0,
-                                                       const float* __restrict__ a0,
-                                                       const float* __restrict__ w0b /* [co8][125][ch] */,
-                                                       const float* __restrict__ beta_hat,
-                                                       const float* __restrict__ gamma_hat, float* __restrict__ da0,
-                                                       float* __restrict__ dx0, float* __restrict__ slab_gdn,
-                                                       float* __restrict__ slab_w, int batch, int ch, int want_w) {
-  __shared__ float s_dh[512], s_a[512], s_n[512], s_t[512];
+template <int C0, int C1>
+__global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restrict__ part, const float* __restrict__ x0,
+                                                           const float* __restrict__ a0,
+                                                           const float* __restrict__ w0b /* [co][125][ch] */,
+                                                           const float* __restrict__ beta_hat,
+                                                           const float* __restrict__ gamma_hat, float* __restrict__ da0,
+                                                           float* __restrict__ dx0, float* __restrict__ slab_gdn,
+                                                           float* __restrict__ slab_w, int batch, int ch, int want_w) {
+  constexpr int NT = C0 * 64, NCOL = stem_ncol(C0), NOWN = (kStemWMax * C0 + NT - 1) / NT;
+  __shared__ float s_dh[NT], s_a[NT], s_n[NT], s_t[NT];
   __shared__ float s_da[C0 * 343];      // da0 with a two-voxel halo: [co][7][7][7], index q + 2
   __shared__ float s_x[MAXCH * 8];
   __shared__ float s_w0[C0 * 125 * MAXCH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = tid >> 6, v = lane, iz = v >> 4, iy = (v >> 2) & 3, ix = v & 3;
-  for (int e = tid; e < C0 * 343; e += 512) s_da[e] = 0.f;
-  for (int e = tid; e < C0 * 125 * ch; e += 512) s_w0[e] = w0b[e];
-  float own_gdn = 0.f;                  // thread p < 72 owns IGDN partial p
-  float own_w[(kStemWMax + 511) / 512]; // up0 weight-gradient outputs j = tid + 512 r
+  for (int e = tid; e < C0 * 343; e += NT) s_da[e] = 0.f;
+  for (int e = tid; e < C0 * 125 * ch; e += NT) s_w0[e] = w0b[e];
+  float own_gdn = 0.f;                  // thread p < NCOL owns IGDN partial p
+  float own_w[NOWN];                    // up0 weight-gradient outputs j = tid + NT r
 #pragma unroll
-  for (int r = 0; r < (kStemWMax + 511) / 512; ++r) own_w[r] = 0.f;
+  for (int r = 0; r < NOWN; ++r) own_w[r] = 0.f;
   const int jtotal = ch * C0 * 125;
   __syncthreads();
 
   for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-    s_a[tid] = a0[(size_t)b * C0 * 64 + tid];
+    s_a[tid] = a0[(size_t)b * NT + tid];
     if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
     {
-      // dh0 = the eight channel-pair partials of conv0's backward-data, added in ascending order
+      // dh0 = the channel-pair partials of conv0's backward-data, added in ascending order
       float dh = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) dh += part[((size_t)b * 8 + w) * 512 + tid];
+      for (int w = 0; w < C1 / 2; ++w) dh += part[((size_t)b * (C1 / 2) + w) * NT + tid];
       s_dh[tid] = dh;
     }
     __syncthreads();
@@ -301,9 +326,9 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
       float mix = 0.f;
       for (int cc = 0; cc < C0; ++cc) mix = fmaf(s_t[cc * 64 + v], st_gamma(gamma_hat[cc * C0 + c]), mix);
       const float d = s_dh[tid] * s_n[tid] + s_a[tid] * mix;
-      da0[(size_t)b * C0 * 64 + tid] = d;
+      da0[(size_t)b * NT + tid] = d;
       s_da[c * 343 + ((iz + 2) * 7 + iy + 2) * 7 + ix + 2] = d;
-      if (want_w && tid < kStemNcol) {   // parameter partials: p < 8: d beta_p ; else d gamma_{cc,j}
+      if (want_w && tid < NCOL) {   // parameter partials: p < C0: d beta_p ; else d gamma_{cc,j}
         float sum = 0.f;
         if (tid < C0) {
           for (int k = 0; k < 64; ++k) sum += s_t[tid * 64 + k];
@@ -318,9 +343,9 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
       }
     }
     __syncthreads();
-    // ---- up0 backward-data: dx0[ci, i] = sum_co sum_k da0[co, 2 i - 2 + k] w0[ci][co][k]; 8 lanes (co) per output
-    if (tid < ch * 64) {
-      const int out = tid >> 3, co = tid & 7, ci = out >> 3, i = out & 7;
+    // ---- up0 backward-data: dx0[ci, i] = sum_co sum_k da0[co, 2 i - 2 + k] w0[ci][co][k]; C0 lanes (co) per output
+    if (tid < ch * 8 * C0) {
+      const int out = tid / C0, co = tid % C0, ci = out >> 3, i = out & 7;
       const int jz = i >> 2, jy = (i >> 1) & 1, jx = i & 1;
       const float* dp = s_da + co * 343 + ((2 * jz) * 7 + 2 * jy) * 7 + 2 * jx;
       const float* wp = s_w0 + co * 125 * ch + ci;
@@ -332,16 +357,15 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
 #pragma unroll
           for (int kx = 0; kx < 5; ++kx)
             acc = fmaf(dp[(kz * 7 + ky) * 7 + kx], wp[((kz * 5 + ky) * 5 + kx) * ch], acc);
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
+#pragma unroll
+      for (int m = 1; m < C0; m <<= 1) acc += __shfl_xor(acc, m, 64);
       if (co == 0) dx0[(size_t)b * ch * 8 + out] = acc;
     }
     // ---- up0 weight gradient: dW0[ci][co][k] += sum_i x0[ci, i] da0[co, 2 i - 2 + k]
     if (want_w) {
 #pragma unroll
-      for (int r = 0; r < (kStemWMax + 511) / 512; ++r) {
-        const int j = tid + 512 * r;
+      for (int r = 0; r < NOWN; ++r) {
+        const int j = tid + NT * r;
         if (j < jtotal) {
           const int k = j % 125, co = (j / 125) % C0, ci = j / (125 * C0);
           const int kz = k / 25, ky = (k / 5) % 5, kx = k % 5;
@@ -357,36 +381,21 @@ __global__ __launch_bounds__(512) void stem_bwd_kernel(const float* __restrict__
     __syncthreads();
   }
   if (want_w) {
-    if (tid < kStemNcol) slab_gdn[(size_t)blockIdx.x * kStemNcol + tid] = own_gdn;
+    if (tid < NCOL) slab_gdn[(size_t)blockIdx.x * NCOL + tid] = own_gdn;
 #pragma unroll
-    for (int r = 0; r < (kStemWMax + 511) / 512; ++r) {
-      const int j = tid + 512 * r;
+    for (int r = 0; r < NOWN; ++r) {
+      const int j = tid + NT * r;
       if (j < jtotal) slab_w[(size_t)blockIdx.x * jtotal + j] = own_w[r];
     }
   }
 }
 
-// IGDN parameter gradients from the slabs: fixed-order sum, re-parametrisation chain rule, LowerBound rule
 // Both finals of the stem backward in one launch: the last workgroup turns the IGDN slabs into parameter gradients
 // (fixed-order sum, re-parametrisation chain rule, LowerBound rule), the others add up0's weight-gradient slabs.
-__global__ __launch_bounds__(256) void stem_finals(const float* __restrict__ slab_gdn, const float* __restrict__ beta_hat,
-                                                   const float* __restrict__ gamma_hat, float* __restrict__ dbeta_hat,
-                                                   float* __restrict__ dgamma_hat, const float* __restrict__ slab_w,
+__global__ __launch_bounds__(256) void stem_finals(StemGdnFinal f, const float* __restrict__ slab_w,
                                                    float* __restrict__ dw, int nslab, int jtotal) {
   if (blockIdx.x == gridDim.x - 1) {
-    const int p = threadIdx.x;
-    if (p >= kStemNcol) return;
-    float s = 0.f;
-    for (int g = 0; g < nslab; ++g) s += slab_gdn[(size_t)g * kStemNcol + p];
-    if (p < C0) {
-      const float h = beta_hat[p];
-      const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
-      dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
-    } else {
-      const float h = gamma_hat[p - C0];
-      const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
-      dgamma_hat[p - C0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
-    }
+    stem_gdn_final_body(f, threadIdx.x, 256);
     return;
   }
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,9 +405,29 @@ __global__ __launch_bounds__(256) void stem_finals(const float* __restrict__ sla
   dw[j] = s;
 }
 
-extern "C" size_t nvf_stem_bwd_workspace(int batch, int ch) {
-  return ((size_t)kStemMaxSlabs * (kStemNcol + (size_t)ch * C0 * 125) + (size_t)(batch > 0 ? batch : 0) * 8 * 512) *
-         sizeof(float);
+// workspace of nvf_stem_bwd / nvf_stem_bwd_partial: IGDN slabs, up0 weight-gradient slabs, conv0 backward-data partials
+static size_t stem_ws_floats(int batch, int ch, int c0, int c1) {
+  return (size_t)kStemMaxSlabs * (stem_ncol(c0) + (size_t)ch * c0 * 125) + (size_t)(batch > 0 ? batch : 0) * (c1 / 2) * c0 * 64;
+}
+extern "C" size_t nvf_stem_bwd_workspace(int batch, int ch) { return stem_ws_floats(batch, ch, 8, 16) * sizeof(float); }
+extern "C" size_t nvf_stem_bwd_workspace_for(int batch, int ch, int c0, int c1) {
+  return stem_shape(c0, c1) ? stem_ws_floats(batch, ch, c0, c1) * sizeof(float) : 0;
+}
+
+template <int C0, int C1>
+static int launch_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
+                           const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
+                           void* workspace, int batch, int ch, int want_w, float** slab_gdn_out, float** slab_w_out,
+                           int* nslab_out, hipStream_t s) {
+  const int nslab = batch < kStemMaxSlabs ? batch : kStemMaxSlabs;
+  float* slab_gdn = (float*)workspace;
+  float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * stem_ncol(C0);
+  float* part = slab_w + (size_t)kStemMaxSlabs * ch * C0 * 125;
+  stem_bwd_dh_kernel<C0, C1><<<dim3(batch, C1 / 2), C0 * 32, 0, s>>>(g1, conv0_w_bwd, part);
+  stem_bwd_kernel<C0, C1><<<nslab, C0 * 64, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn,
+                                                    slab_w, batch, ch, want_w);
+  *slab_gdn_out = slab_gdn; *slab_w_out = slab_w; *nslab_out = nslab;
+  return NVF_OK;
 }
 
 extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
@@ -406,22 +435,22 @@ extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, c
                             float* dx0, float* dbeta_hat, float* dgamma_hat, float* dw_up0, void* workspace,
                             size_t workspace_bytes, int batch, int ch, int c0, int c1, void* stream) {
   if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0) return NVF_EINVAL;
-  if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
+  if (batch <= 0 || ch <= 0 || ch > MAXCH || !stem_shape(c0, c1)) return NVF_EINVAL;
   const int want_w = dbeta_hat && dgamma_hat && dw_up0;
-  if (!workspace || workspace_bytes < nvf_stem_bwd_workspace(batch, ch)) return NVF_EWORKSPACE;
-  const int nslab = batch < kStemMaxSlabs ? batch : kStemMaxSlabs;
-  float* slab_gdn = (float*)workspace;
-  float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * kStemNcol;
-  float* part = slab_w + (size_t)kStemMaxSlabs * ch * C0 * 125;
+  if (!workspace || workspace_bytes < stem_ws_floats(batch, ch, c0, c1) * sizeof(float)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  stem_bwd_dh_kernel<<<dim3(batch, 8), 256, 0, s>>>(g1, conv0_w_bwd, part);
-  stem_bwd_kernel<<<nslab, 512, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn, slab_w,
-                                        batch, ch, want_w);
+  float *slab_gdn, *slab_w;
+  int nslab;
+  if (c0 == 8)
+    launch_stem_bwd<8, 16>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, workspace, batch, ch,
+                           want_w, &slab_gdn, &slab_w, &nslab, s);
+  else
+    launch_stem_bwd<16, 32>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, workspace, batch, ch,
+                            want_w, &slab_gdn, &slab_w, &nslab, s);
   if (want_w) {
-    const int jtotal = ch * C0 * 125;
-    static_assert(kStemNcol <= 256, "one workgroup covers the IGDN columns");
-    stem_finals<<<(jtotal + 255) / 256 + 1, 256, 0, s>>>(slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, slab_w,
-                                                         dw_up0, nslab, jtotal);
+    const int jtotal = ch * c0 * 125;
+    StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab, c0};
+    stem_finals<<<(jtotal + 255) / 256 + 1, 256, 0, s>>>(f, slab_w, dw_up0, nslab, jtotal);
   }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -439,19 +468,20 @@ extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const floa
   if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0 || !dbeta_hat ||
       !dgamma_hat || !dw_slabs || !nslabs)
     return NVF_EINVAL;
-  if (batch <= 0 || ch <= 0 || ch > MAXCH || c0 != C0 || c1 != C1) return NVF_EINVAL;
-  if (!workspace || workspace_bytes < nvf_stem_bwd_workspace(batch, ch)) return NVF_EWORKSPACE;
-  const int nslab = batch < kStemMaxSlabs ? batch : kStemMaxSlabs;
-  float* slab_gdn = (float*)workspace;
-  float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * kStemNcol;
-  float* part = slab_w + (size_t)kStemMaxSlabs * ch * C0 * 125;
+  if (batch <= 0 || ch <= 0 || ch > MAXCH || !stem_shape(c0, c1)) return NVF_EINVAL;
+  if (!workspace || workspace_bytes < stem_ws_floats(batch, ch, c0, c1) * sizeof(float)) return NVF_EWORKSPACE;
   hipStream_t s = nvf_stream(stream);
-  stem_bwd_dh_kernel<<<dim3(batch, 8), 256, 0, s>>>(g1, conv0_w_bwd, part);
-  stem_bwd_kernel<<<nslab, 512, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn, slab_w,
-                                        batch, ch, 1);
+  float *slab_gdn, *slab_w;
+  int nslab;
+  if (c0 == 8)
+    launch_stem_bwd<8, 16>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, workspace, batch, ch, 1,
+                           &slab_gdn, &slab_w, &nslab, s);
+  else
+    launch_stem_bwd<16, 32>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, workspace, batch, ch, 1,
+                            &slab_gdn, &slab_w, &nslab, s);
   NVF_LAUNCH_CHECK();
   *dw_slabs = slab_w;
   *nslabs = nslab;
-  StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab, C0};
+  StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab, c0};
   return nvf_finals_run_stem_gdn(ctx, f, stream);
 }

@@ -27,6 +27,7 @@ from .network import NoiseState
 
 R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
 _TAIL = os.environ.get("NVF_TAIL", "1") != "0"   # latent backward as one workgroup of a later launch (0: three launches)
+_STEM = os.environ.get("NVF_STEM", "1") != "0"   # fused stem launches (0: per-layer kernels)
 _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wide decoder (0: the VALU tile kernels)
 
 
@@ -100,7 +101,8 @@ class TrainEngine:
         # shortens the step (0.828 ms either way) -- every kernel fills the chip on its own -- so the default is
         # one stream; NVF_OVERLAP=1 turns the two-stream schedule back on.
         self.allow_overlap = os.environ.get("NVF_OVERLAP", "0") == "1"
-        self.fused_stem = tuple(net.reconstructor.channels[:2]) == (8, 16) and net.entropy_coder.sigma.shape[1] <= 8
+        self.fused_stem = (tuple(net.reconstructor.channels[:2]) in ((8, 16), (16, 32))
+                           and net.entropy_coder.sigma.shape[1] <= 8 and _STEM)
         self.fused_latent_stem = True      # latent generator + quantiser ride in the stem's forward launch
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts

@@ -330,14 +330,15 @@ def conv3d_g16_mfma(x, wp, bias, cout, k, stride, pad, out_spatial, act=ACT_NONE
 
 
 def stem_fwd(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b):
-    """Fused up0 -> IGDN -> conv0 + ReLU for chanstr (8, 16, ...): returns (a0, h0, y1)."""
+    """Fused up0 -> IGDN -> conv0 + ReLU for chanstr (8, 16, ...) or (16, 32, ...): returns (a0, h0, y1)."""
     _f32(x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b)
     B, ch = x0.shape[0], x0.shape[1]
-    a0 = torch.empty((B, 8, 4, 4, 4), device=x0.device)
-    h0 = torch.empty((B, 8, 4, 4, 4), device=x0.device)
-    y1 = torch.empty((B, 16, 8, 8, 8), device=x0.device)
+    c0, c1 = up0_b.numel(), conv0_b.numel()
+    a0 = torch.empty((B, c0, 4, 4, 4), device=x0.device)
+    h0 = torch.empty((B, c0, 4, 4, 4), device=x0.device)
+    y1 = torch.empty((B, c1, 8, 8, 8), device=x0.device)
     check(lib().nvf_stem_fwd(_ptr(x0), _ptr(up0_w_fwd), _ptr(up0_b), _ptr(beta_hat), _ptr(gamma_hat),
-                             _ptr(conv0_w_fwd), _ptr(conv0_b), _ptr(a0), _ptr(h0), _ptr(y1), B, ch, 8, 16,
+                             _ptr(conv0_w_fwd), _ptr(conv0_b), _ptr(a0), _ptr(h0), _ptr(y1), B, ch, c0, c1,
                              _stream()), "nvf_stem_fwd")
     return a0, h0, y1
 
@@ -354,14 +355,15 @@ def stem_latent_fwd(e, lat_w_fwd, lat_bias, lat_beta_hat, lat_gamma_hat, sigma, 
         raise ValueError("stem_latent_fwd: latents are [B, ch, 2, 2, 2]")
     h, lat, xr = torch.empty_like(e), torch.empty_like(e), torch.empty_like(e)
     bits = torch.empty(1, device=e.device)
-    a0 = torch.empty((B, 8, 4, 4, 4), device=e.device)
-    h0 = torch.empty((B, 8, 4, 4, 4), device=e.device)
-    y1 = torch.empty((B, 16, 8, 8, 8), device=e.device)
+    c0, c1 = up0_b.numel(), conv0_b.numel()
+    a0 = torch.empty((B, c0, 4, 4, 4), device=e.device)
+    h0 = torch.empty((B, c0, 4, 4, 4), device=e.device)
+    y1 = torch.empty((B, c1, 8, 8, 8), device=e.device)
     check(lib().nvf_stem_latent_fwd(_ptr(e), _ptr(lat_w_fwd), _ptr(lat_bias), _ptr(lat_beta_hat), _ptr(lat_gamma_hat),
                                     _ptr(block_ids), _ptr(sigma), _ptr(mu), _ptr(h), _ptr(lat), _ptr(xr), _ptr(bits),
                                     0 if mode == "train" else 1, int(seed), int(step), _ptr(step_dev), _ptr(up0_w_fwd),
                                     _ptr(up0_b), _ptr(beta_hat), _ptr(gamma_hat), _ptr(conv0_w_fwd), _ptr(conv0_b),
-                                    _ptr(a0), _ptr(h0), _ptr(y1), B, ch, 8, 16, _stream()), "nvf_stem_latent_fwd")
+                                    _ptr(a0), _ptr(h0), _ptr(y1), B, ch, c0, c1, _stream()), "nvf_stem_latent_fwd")
     return h, lat, xr, bits, a0, h0, y1
 
 
@@ -372,10 +374,11 @@ def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=
     B, ch = x0.shape[0], x0.shape[1]
     da0 = torch.empty_like(a0)
     dx0 = torch.empty_like(x0)
-    ws = workspace(lib().nvf_stem_bwd_workspace(B, ch), x0.device, "stem")
+    c0, c1 = a0.shape[1], g1.shape[1]
+    ws = workspace(lib().nvf_stem_bwd_workspace_for(B, ch, c0, c1), x0.device, "stem")
     check(lib().nvf_stem_bwd(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
                              _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
-                             _ptr(dw_up0), _ptr(ws), ws.numel(), B, ch, 8, 16, _stream()), "nvf_stem_bwd")
+                             _ptr(dw_up0), _ptr(ws), ws.numel(), B, ch, c0, c1, _stream()), "nvf_stem_bwd")
     return da0, dx0
 
 
@@ -388,11 +391,12 @@ def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, db
     B, ch = x0.shape[0], x0.shape[1]
     da0 = torch.empty_like(a0)
     dx0 = torch.empty_like(x0)
-    ws = workspace(lib().nvf_stem_bwd_workspace(B, ch), x0.device, "stem", ctx)
+    c0, c1 = a0.shape[1], g1.shape[1]
+    ws = workspace(lib().nvf_stem_bwd_workspace_for(B, ch, c0, c1), x0.device, "stem", ctx)
     slabs, nsl = ctypes.c_void_p(), ctypes.c_int()
     check(lib().nvf_stem_bwd_partial(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
                                      _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
-                                     ctypes.byref(slabs), ctypes.byref(nsl), _ptr(ws), ws.numel(), B, ch, 8, 16,
+                                     ctypes.byref(slabs), ctypes.byref(nsl), _ptr(ws), ws.numel(), B, ch, c0, c1,
                                      _ctx(ctx), _stream()), "nvf_stem_bwd_partial")
     wg.jobs.append((slabs.value, dw_up0.data_ptr(), nsl.value, dw_up0.numel()))
     return da0, dx0
