@@ -207,6 +207,6 @@ int nvf_wgrad16_launch(const float* p, const float* q, float* slabs, int batch, 
   if (k == 4 && stride == 1 && dp == 32) return launch_w16<W16<4, 1, 32, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
   if (k == 4 && stride == 1 && dp == 16) return launch_w16<W16<4, 1, 16, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
   if (k == 5 && stride == 2 && dp == 16) return launch_w16<W16<5, 2, 16, 2, 8>>(p, q, slabs, d, max_slabs, nslab, s);
-  // (up1's 8-wide rows give an A fragment only two uses per tap row: 58 us against 48 us for the VALU tile kernel)
+  // (up1's 8-wide rows give an A fragment only two uses per tap row: 50 us against 36 us for the VALU tile kernel)
   return 1;
 }
