@@ -195,14 +195,19 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
       if (tl >= NPT || p >= NCELL * NCELL) continue;
       const int cy = p / NCELL, cx = p % NCELL;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int oz = 2 * cz + (e >> 2) - PAD, oy = 2 * cy + ((e >> 1) & 1) - PAD, ox = 2 * cx + (e & 1) - PAD;
-        if (oz < 0 || oy < 0 || ox < 0 || oz >= NOUT || oy >= NOUT || ox >= NOUT) continue;
+      for (int e = 0; e < 8; e += 2) {          // the two x parities of a cell are adjacent outputs: one 8-byte store
+        const int oz = 2 * cz + (e >> 2) - PAD, oy = 2 * cy + ((e >> 1) & 1) - PAD, ox = 2 * cx - PAD;
+        if (oz < 0 || oy < 0 || oz >= NOUT || oy >= NOUT) continue;
+        const bool in0 = ox >= 0 && ox < NOUT, in1 = ox + 1 >= 0 && ox + 1 < NOUT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = cog * 16 + 4 * kq + r;
-          y[((size_t)b * COUT + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
-              nvf_act(acc[c][e][r] + (bias ? bias[co] : 0.f), act);
+          const float bv = bias ? bias[co] : 0.f;
+          float* o = y + ((size_t)b * COUT + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox;
+          const float v0 = nvf_act(acc[c][e][r] + bv, act), v1 = nvf_act(acc[c][e + 1][r] + bv, act);
+          if (in0 && in1) *(nvf_f2u*)o = nvf_f2u{v0, v1};
+          else if (in0) o[0] = v0;
+          else if (in1) o[1] = v1;
         }
       }
     }

@@ -136,11 +136,13 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
           const int oz = 2 * cz + ez, oy = 2 * cy + ey;
           if (oz >= NOUT || oy >= NOUT) continue;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = 2 * kq + (r >> 1), ox = 2 * cx + (r & 1);
-            if (ox < NOUT)
-              y[((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox] =
-                  nvf_act(res[c][ez][ey][r] + (bias ? bias[co] : 0.f), act);
+          for (int r = 0; r < 4; r += 2) {        // rows r, r + 1 = the two x parities of a cell: one 8-byte store
+            const int co = 2 * kq + (r >> 1), ox = 2 * cx;
+            const float bv = bias ? bias[co] : 0.f;
+            float* o = y + ((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox;
+            const float v0 = nvf_act(res[c][ez][ey][r] + bv, act), v1 = nvf_act(res[c][ez][ey][r + 1] + bv, act);
+            if (ox + 1 < NOUT) *(nvf_f2u*)o = nvf_f2u{v0, v1};
+            else if (ox < NOUT) o[0] = v0;
           }
         }
     }

@@ -18,6 +18,9 @@ __device__ __forceinline__ float nvf_act(float v, int act) {
   return v;
 }
 
+// two floats at any 4-byte phase (rows of 35 or 19 floats): the compiler may use one 8-byte access, not an aligned one
+struct __attribute__((packed, aligned(4))) nvf_f2u { float a, b; };
+
 // ---- Philox4x32-10 counter RNG ------------------------------------------------
 // key = seed (64 bit), counter = (index lo, index hi, stream lo, stream hi).
 __device__ __forceinline__ void nvf_philox(uint64_t seed, uint64_t stream_id, uint64_t index, uint32_t out[4]) {
