@@ -277,8 +277,13 @@ __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], con
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[c][q][r] + bv[r >> 1], 0.f);
       } else if (EPI == 1) {
         float m[4];
+        if (C::PAIR == 0 && second) {
+          const nvf_f2u m0 = *(const nvf_f2u*)(mask + o), m1 = *(const nvf_f2u*)(mask + o + cstride);
+          m[0] = m0.a; m[1] = m0.b; m[2] = m1.a; m[3] = m1.b;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = ((r & 1) && !second) ? 0.f : mask[o + (r >> 1) * cstride + (r & 1) * pstep];
+          for (int r = 0; r < 4; ++r) m[r] = ((r & 1) && !second) ? 0.f : mask[o + (r >> 1) * cstride + (r & 1) * pstep];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? acc[c][q][r] : 0.f;
       } else {
@@ -291,9 +296,9 @@ __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], con
           if (mask) v[r] = mask[oo] > 0.f ? v[r] : 0.f;
         }
       }
-      if (C::PAIR == 0 && second && ((d.wout & 1) == 0)) {      // the pair is adjacent in x and 8-byte aligned
-        *(float2*)(y + o) = make_float2(v[0], v[1]);
-        *(float2*)(y + o + cstride) = make_float2(v[2], v[3]);
+      if (C::PAIR == 0 && second) {      // the pair is adjacent in x: one 8-byte store at any 4-byte phase (35-wide rows)
+        *(nvf_f2u*)(y + o) = nvf_f2u{v[0], v[1]};
+        *(nvf_f2u*)(y + o + cstride) = nvf_f2u{v[2], v[3]};
       } else {
         y[o] = v[0];
         y[o + cstride] = v[2];
