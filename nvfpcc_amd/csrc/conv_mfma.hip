@@ -463,6 +463,8 @@ extern "C" int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* 
   NVF_MF(4, 8, 33, 36, 18, 7, 4, 1, 4)
   NVF_MF(0, 8, 17, 20, 10, 8, 5, 1, 4)     // conv1 backward-data: 19 wide = 10 cells; 8 rows = 5 column tiles
   NVF_MF(2, 8, 17, 20, 10, 8, 5, 1, 2)
+  NVF_MF(3, 8, 17, 20, 10, 19, 4, 2, 1)    // whole 19 x 20 planes (12 column tiles), 2 planes per workgroup: 36.5 us
+  NVF_MF(4, 8, 17, 20, 10, 19, 4, 1, 2)    // 31.5 us (the z-pair mapping above: 28.1)
 #undef NVF_MF
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();
