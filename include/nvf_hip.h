@@ -223,11 +223,14 @@ int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, const float*
 /* nvf_stem_bwd minus its final launch (training step): up0's weight-gradient slabs (*dw_slabs: *nslabs slabs of
  * ch * c0 * 125 floats inside `workspace`) are left to the caller's slab reduction (nvf_wgrad_reduce_multi*), the
  * IGDN parameter gradients to the deferred final passes (nvf_finals_begin; launched at once otherwise).  Same sums,
- * same order as nvf_stem_bwd. */
+ * same order as nvf_stem_bwd.  h0 and dw_conv0_slabs (both or neither): the launch that computes conv0's backward-data
+ * also leaves conv0's weight gradient (bwd-weight of network.py:621 for conv0) as `batch` slabs of c0 * c1 * 125 floats
+ * ([ci][co][k], one per block, inside `workspace`) for the same reduction. */
 int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                          const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
                          float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs, void* workspace,
-                         size_t workspace_bytes, int batch, int ch, int c0, int c1, NvfStepCtx* ctx, void* stream);
+                         size_t workspace_bytes, int batch, int ch, int c0, int c1, const float* h0,
+                         float** dw_conv0_slabs, NvfStepCtx* ctx, void* stream);
 
 /* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
  * dw[a][b][k] (+)= sum_{n,i} p[n,a,i] * q[n,b, stride*i - pad + k]      (out_mode 0)

@@ -54,7 +54,7 @@ PROTOTYPES = {
     "nvf_stem_bwd_workspace": (Z, [I, I]),
     "nvf_stem_bwd_workspace_for": (Z, [I, I, I, I]),
     "nvf_stem_bwd": (I, [P] * 13 + [Z, I, I, I, I, P]),
-    "nvf_stem_bwd_partial": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P, P]),
+    "nvf_stem_bwd_partial": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P, P, P, P]),
     "nvf_wgrad_workspace": (Z, [I] * 7),
     "nvf_wgrad": (I, [P, P, P, P, Z] + [I] * 15 + [P]),
     "nvf_wgrad_partial": (I, [P, P, P, P, Z] + [I] * 14 + [P, P]),

@@ -233,10 +233,14 @@ constexpr int kStemWMax = MAXCH * 125;                            // up0 weight-
 // all 125 taps of g1[co, 2 i - 2 + k] w1[ci][co][k].  C0 / 2 waves: wave = input-channel pair, lane = position i.
 // The pair's gradients (zero-padded) and weights sit in LDS; each lane runs the fmaf chain (cc, kz, ky, kx ascending),
 // the partials are added in ascending pair order by stem_bwd_kernel.
-template <int C0, int C1>
+// WG0: the workgroup also leaves its two output channels' share of conv0's weight gradient for this block,
+//   slab0[b][ci][co][k] = sum_i h0[b, ci, i] g1[b, co, 2 i - 2 + k]   (i ascending; the caller's slab reduction adds the blocks),
+// from the gradient tile it already holds -- a separate launch over 4^3 inputs was 18 us of latency for 0.13 GFLOP.
+template <int C0, int C1, bool WG0>
 __global__ __launch_bounds__(C0 * 32) void stem_bwd_dh_kernel(const float* __restrict__ g1,
                                                               const float* __restrict__ w1b /* [co][125][ci] */,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, const float* __restrict__ h0,
+                                                              float* __restrict__ slab0) {
   constexpr int NT = C0 * 32;
   __shared__ float s_g[2 * 1331];                                   // [cc][11][11][11], index q + 2
   __shared__ __attribute__((aligned(16))) float s_w[2 * 125 * C0];  // [cc][k][ci]
@@ -272,6 +276,23 @@ __global__ __launch_bounds__(C0 * 32) void stem_bwd_dh_kernel(const float* __res
   float* o = part + (((size_t)b * (C1 / 2) + cp) * C0 + 2 * wv) * 64 + lane;
   o[0] = acc0;
   o[64] = acc1;
+  if (WG0) {
+    __syncthreads();                                   // the weights are no longer read: their LDS holds h0[b] now
+    float* s_h = s_w;
+    for (int e = tid; e < C0 * 64; e += NT) s_h[e] = h0[(size_t)b * C0 * 64 + e];
+    __syncthreads();
+    for (int jj = tid; jj < C0 * 2 * 125; jj += NT) {
+      const int k = jj % 125, cc = (jj / 125) & 1, ci = jj / 250;
+      const int kz = k / 25, ky = (k / 5) % 5, kx = k % 5;
+      const float* gp = s_g + cc * 1331 + (kz * 11 + ky) * 11 + kx;
+      const float* hp = s_h + ci * 64;
+      float a = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i)
+        a = fmaf(hp[i], gp[((2 * (i >> 4)) * 11 + 2 * ((i >> 2) & 3)) * 11 + 2 * (i & 3)], a);
+      slab0[((size_t)b * C0 + ci) * C1 * 125 + (2 * cp + cc) * 125 + k] = a;
+    }
+  }
 }
 
 template <int C0, int C1>
@@ -407,7 +428,9 @@ __global__ __launch_bounds__(256) void stem_finals(StemGdnFinal f, const float* 
 
 // workspace of nvf_stem_bwd / nvf_stem_bwd_partial: IGDN slabs, up0 weight-gradient slabs, conv0 backward-data partials
 static size_t stem_ws_floats(int batch, int ch, int c0, int c1) {
-  return (size_t)kStemMaxSlabs * (stem_ncol(c0) + (size_t)ch * c0 * 125) + (size_t)(batch > 0 ? batch : 0) * (c1 / 2) * c0 * 64;
+  const size_t nb = batch > 0 ? batch : 0;
+  return (size_t)kStemMaxSlabs * (stem_ncol(c0) + (size_t)ch * c0 * 125) + nb * (c1 / 2) * c0 * 64 +
+         nb * c0 * c1 * 125;                            // + conv0's weight-gradient slabs (one per block)
 }
 extern "C" size_t nvf_stem_bwd_workspace(int batch, int ch) { return stem_ws_floats(batch, ch, 8, 16) * sizeof(float); }
 extern "C" size_t nvf_stem_bwd_workspace_for(int batch, int ch, int c0, int c1) {
@@ -418,12 +441,17 @@ template <int C0, int C1>
 static int launch_stem_bwd(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                            const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
                            void* workspace, int batch, int ch, int want_w, float** slab_gdn_out, float** slab_w_out,
-                           int* nslab_out, hipStream_t s) {
+                           int* nslab_out, hipStream_t s, const float* h0 = nullptr, float** slab0_out = nullptr) {
   const int nslab = batch < kStemMaxSlabs ? batch : kStemMaxSlabs;
   float* slab_gdn = (float*)workspace;
   float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * stem_ncol(C0);
   float* part = slab_w + (size_t)kStemMaxSlabs * ch * C0 * 125;
-  stem_bwd_dh_kernel<C0, C1><<<dim3(batch, C1 / 2), C0 * 32, 0, s>>>(g1, conv0_w_bwd, part);
+  float* slab0 = part + (size_t)batch * (C1 / 2) * C0 * 64;
+  if (h0 && slab0_out) {
+    stem_bwd_dh_kernel<C0, C1, true><<<dim3(batch, C1 / 2), C0 * 32, 0, s>>>(g1, conv0_w_bwd, part, h0, slab0);
+    *slab0_out = slab0;
+  } else
+    stem_bwd_dh_kernel<C0, C1, false><<<dim3(batch, C1 / 2), C0 * 32, 0, s>>>(g1, conv0_w_bwd, part, nullptr, nullptr);
   stem_bwd_kernel<C0, C1><<<nslab, C0 * 64, 0, s>>>(part, x0, a0, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, slab_gdn,
                                                     slab_w, batch, ch, want_w);
   *slab_gdn_out = slab_gdn; *slab_w_out = slab_w; *nslab_out = nslab;
@@ -459,14 +487,16 @@ extern "C" int nvf_stem_bwd(const float* g1, const float* x0, const float* a0, c
 // nvf_stem_bwd without its final launch: up0's weight-gradient slabs are left to the caller's slab reduction
 // (*dw_slabs = nslabs slabs of ch * c0 * 125 floats inside `workspace`, to be added into dw_up0 by
 // nvf_wgrad_reduce_multi*), the IGDN parameter gradients go to the deferred final passes (nvf_finals_begin; launched
-// at once when nothing is being deferred).  Same sums in the same order as nvf_stem_bwd.
+// at once when nothing is being deferred).  Same sums in the same order as nvf_stem_bwd.  h0 / dw_conv0_slabs (both or
+// neither): also leave conv0's weight gradient as `batch` slabs of c0 * c1 * 125 floats ([ci][co][k], one per block)
+// inside `workspace` for the same reduction.
 extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
                                     const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0,
                                     float* dx0, float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs,
                                     void* workspace, size_t workspace_bytes, int batch, int ch, int c0, int c1,
-                                    NvfStepCtx* ctx, void* stream) {
+                                    const float* h0, float** dw_conv0_slabs, NvfStepCtx* ctx, void* stream) {
   if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0 || !dbeta_hat ||
-      !dgamma_hat || !dw_slabs || !nslabs)
+      !dgamma_hat || !dw_slabs || !nslabs || (h0 != nullptr) != (dw_conv0_slabs != nullptr))
     return NVF_EINVAL;
   if (batch <= 0 || ch <= 0 || ch > MAXCH || !stem_shape(c0, c1)) return NVF_EINVAL;
   if (!workspace || workspace_bytes < stem_ws_floats(batch, ch, c0, c1) * sizeof(float)) return NVF_EWORKSPACE;
@@ -475,10 +505,10 @@ extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const floa
   int nslab;
   if (c0 == 8)
     launch_stem_bwd<8, 16>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, workspace, batch, ch, 1,
-                           &slab_gdn, &slab_w, &nslab, s);
+                           &slab_gdn, &slab_w, &nslab, s, h0, dw_conv0_slabs);
   else
     launch_stem_bwd<16, 32>(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, da0, dx0, workspace, batch, ch, 1,
-                            &slab_gdn, &slab_w, &nslab, s);
+                            &slab_gdn, &slab_w, &nslab, s, h0, dw_conv0_slabs);
   NVF_LAUNCH_CHECK();
   *dw_slabs = slab_w;
   *nslabs = nslab;

@@ -454,8 +454,11 @@ class TrainEngine:
         if ev_t0 is not None:
             main.wait_event(ev_t0)
         g1 = self._dx_convT(Ls["up1"], g2, a["y1"], mask=a["y1"], addend=t0)
+        stem_wg0 = want_w and self.fused_stem and defer and not wg3   # conv0's weight gradient rides in the stem's backward
         if wg3:                                      # up1 and conv0 weight gradients: with the other three, below
             self._bias_jobs += [(g2, Ls["up1"].gb), (g1, Ls["conv0"].gb)]
+        elif stem_wg0:
+            self._bias_jobs.append((g1, Ls["conv0"].gb))
         else:
             side_wgrad(self._wgrad_convT, Ls["conv0"], g1, a["h0"])
         ig = net.reconstructor.activation
@@ -464,7 +467,8 @@ class TrainEngine:
         if self.fused_stem and defer:        # its final launch is shared with the slab reduction / the final passes
             da0, dx0 = ops.stem_bwd_partial(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta,
                                             ig.gamma, gview("reconstructor.activation.beta"), gamma_view,
-                                            Ls["up0"].gk, self._wg, ctx=ctx)
+                                            Ls["up0"].gk, self._wg, ctx=ctx, h0=a["h0"] if stem_wg0 else None,
+                                            dw_conv0=Ls["conv0"].gk if stem_wg0 else None)
             self._bias_jobs.append((da0, Ls["up0"].gb))
         elif self.fused_stem:
             da0, dx0 = ops.stem_bwd(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta, ig.gamma,

@@ -383,22 +383,28 @@ def stem_bwd(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out=
 
 
 def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, wg,
-                     ctx=None):
+                     ctx=None, h0=None, dw_conv0=None):
     """stem_bwd whose final launch is shared: up0's weight-gradient slabs become a job of the WgradBatch ``wg``
-    (dw_up0 exists after wg.finish*), the IGDN parameter gradients a deferred final pass.  Returns (da0, dx0)."""
+    (dw_up0 exists after wg.finish*), the IGDN parameter gradients a deferred final pass.  With ``h0`` and
+    ``dw_conv0``: conv0's weight gradient too (one slab per block, another job of ``wg``).  Returns (da0, dx0)."""
     import ctypes
-    _f32(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0)
+    _f32(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, h0, dw_conv0)
+    if (h0 is None) != (dw_conv0 is None):
+        raise ValueError("stem_bwd_partial: h0 and dw_conv0 go together")
     B, ch = x0.shape[0], x0.shape[1]
     da0 = torch.empty_like(a0)
     dx0 = torch.empty_like(x0)
     c0, c1 = a0.shape[1], g1.shape[1]
     ws = workspace(lib().nvf_stem_bwd_workspace_for(B, ch, c0, c1), x0.device, "stem", ctx)
-    slabs, nsl = ctypes.c_void_p(), ctypes.c_int()
+    slabs, nsl, slabs0 = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_void_p()
     check(lib().nvf_stem_bwd_partial(_ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd), _ptr(beta_hat),
                                      _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out), _ptr(dgamma_out),
                                      ctypes.byref(slabs), ctypes.byref(nsl), _ptr(ws), ws.numel(), B, ch, c0, c1,
-                                     _ctx(ctx), _stream()), "nvf_stem_bwd_partial")
+                                     _ptr(h0), ctypes.byref(slabs0) if h0 is not None else None, _ctx(ctx), _stream()),
+          "nvf_stem_bwd_partial")
     wg.jobs.append((slabs.value, dw_up0.data_ptr(), nsl.value, dw_up0.numel()))
+    if h0 is not None:
+        wg.jobs.append((slabs0.value, dw_conv0.data_ptr(), B, dw_conv0.numel()))
     return da0, dx0
 
 
