@@ -281,16 +281,30 @@ __global__ __launch_bounds__(C0 * 32) void stem_bwd_dh_kernel(const float* __res
     float* s_h = s_w;
     for (int e = tid; e < C0 * 64; e += NT) s_h[e] = h0[(size_t)b * C0 * 64 + e];
     __syncthreads();
-    for (int jj = tid; jj < C0 * 2 * 125; jj += NT) {
-      const int k = jj % 125, cc = (jj / 125) & 1, ci = jj / 250;
-      const int kz = k / 25, ky = (k / 5) % 5, kx = k % 5;
-      const float* gp = s_g + cc * 1331 + (kz * 11 + ky) * 11 + kx;
+    // thread = (input channel, kz, ky): ten sums (two output channels x five kx) share every h0 read
+    for (int jj = tid; jj < C0 * 25; jj += NT) {
+      const int ci = jj / 25, r = jj % 25, kz = r / 5, ky = r % 5;
+      const float* gp = s_g + (kz * 11 + ky) * 11;
       const float* hp = s_h + ci * 64;
-      float a = 0.f;
-#pragma unroll 8
-      for (int i = 0; i < 64; ++i)
-        a = fmaf(hp[i], gp[((2 * (i >> 4)) * 11 + 2 * ((i >> 2) & 3)) * 11 + 2 * (i & 3)], a);
-      slab0[((size_t)b * C0 + ci) * C1 * 125 + (2 * cp + cc) * 125 + k] = a;
+      float a[2][5];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) a[cc][kx] = 0.f;
+#pragma unroll 4
+      for (int i = 0; i < 64; ++i) {
+        const float hv = hp[i];
+        const int base = ((2 * (i >> 4)) * 11 + 2 * ((i >> 2) & 3)) * 11 + 2 * (i & 3);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) a[cc][kx] = fmaf(hv, gp[cc * 1331 + base + kx], a[cc][kx]);
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+          slab0[((size_t)b * C0 + ci) * C1 * 125 + (2 * cp + cc) * 125 + r * 5 + kx] = a[cc][kx];
     }
   }
 }
