@@ -324,8 +324,11 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
   __shared__ float s_w0[C0 * 125 * MAXCH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = tid >> 6, v = lane, iz = v >> 4, iy = (v >> 2) & 3, ix = v & 3;
+  __shared__ float s_bet[C0], s_gam[C0 * C0];            // re-parametrised IGDN parameters (were scalar-load chains)
   for (int e = tid; e < C0 * 343; e += NT) s_da[e] = 0.f;
   for (int e = tid; e < C0 * 125 * ch; e += NT) s_w0[e] = w0b[e];
+  for (int e = tid; e < C0 * C0; e += NT) s_gam[e] = st_gamma(gamma_hat[e]);
+  if (tid < C0) s_bet[tid] = st_beta(beta_hat[tid]);
   float own_gdn = 0.f;                  // thread p < NCOL owns IGDN partial p
   float own_w[NOWN];                    // up0 weight-gradient outputs j = tid + NT r
 #pragma unroll
@@ -347,10 +350,11 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
     {
       const float dh = s_dh[tid];
       // IGDN forward quantities of this voxel/channel: n_c, t_c = dh_c a_c / n_c
-      float nrm = st_beta(beta_hat[c]);
+      float nrm = s_bet[c];
+#pragma unroll
       for (int j = 0; j < C0; ++j) {
         const float xj = s_a[j * 64 + v];
-        nrm = fmaf(st_gamma(gamma_hat[c * C0 + j]), xj * xj, nrm);
+        nrm = fmaf(s_gam[c * C0 + j], xj * xj, nrm);
       }
       nrm = sqrtf(nrm);
       s_n[tid] = nrm;
@@ -359,7 +363,8 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
     __syncthreads();
     {  // da0_i = dh_i n_i + a_i sum_c t_c gamma_ci  (i = this thread's channel)
       float mix = 0.f;
-      for (int cc = 0; cc < C0; ++cc) mix = fmaf(s_t[cc * 64 + v], st_gamma(gamma_hat[cc * C0 + c]), mix);
+#pragma unroll
+      for (int cc = 0; cc < C0; ++cc) mix = fmaf(s_t[cc * 64 + v], s_gam[cc * C0 + c], mix);
       const float d = s_dh[tid] * s_n[tid] + s_a[tid] * mix;
       da0[(size_t)b * NT + tid] = d;
       s_da[c * 343 + ((iz + 2) * 7 + iy + 2) * 7 + ix + 2] = d;
