@@ -357,6 +357,32 @@ __device__ __forceinline__ float latent_x_rounded(const float* __restrict__ e, c
   return rintf(hc / sqrtf(nrm));
 }
 
+// the same element from its c inputs already in registers and the parameters anywhere (LDS): the arithmetic of
+// latent_x_rounded / latent_fwd_body (fmaf over i ascending, then the GDN sum over j ascending)
+__device__ __forceinline__ float latent_x_rounded_from(const float (&ev)[8], const float* w, const float* bw,
+                                                       const float* beta_hat, const float* gamma_hat, int ch, int c) {
+  float h[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < c) acc = fmaf(ev[i], w[i * c + j], acc);
+      h[j] = acc + bw[j];
+    }
+  }
+  float nrm = gdn_beta(beta_hat[ch]), hc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < c) {
+      nrm = fmaf(gdn_gamma(gamma_hat[ch * c + j]), h[j] * h[j], nrm);
+      if (j == ch) hc = h[j];
+    }
+  }
+  return rintf(hc / sqrtf(nrm));
+}
+
 // ---- the latent tail ---------------------------------------------------------------------------------------------
 struct LatentTail {
   // rate of the latents (+ the decoder's gradient arriving at them): d lat

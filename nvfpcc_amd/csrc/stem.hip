@@ -27,6 +27,25 @@ __device__ __forceinline__ float st_gamma(float gh) {
   float m = fmaxf(gh, NVF_GAMMA_BOUND);
   return m * m - NVF_PEDESTAL;
 }
+// dst[e] = src[index(e)] for e < n with U loads of a thread in flight before the first store (a plain copy loop is a
+// chain of load -> wait -> store round trips: 16 of them for the wide stem's 64 KB of weights)
+template <int NT, int U, class Index>
+__device__ __forceinline__ void stem_copy(float* dst, const float* __restrict__ src, int n, int tid, Index index) {
+#pragma unroll 1
+  for (int e0 = tid; e0 < n; e0 += NT * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * NT;
+      v[u] = e < n ? src[index(e)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * NT;
+      if (e < n) dst[e] = v[u];
+    }
+  }
+}
 }  // namespace
 
 // conv0 for one output parity class (EZ,EY,EX): lane = cell, COG output channels in registers, taps unrolled so
@@ -106,17 +125,34 @@ __global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restri
   __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1
   __shared__ __attribute__((aligned(16))) float s_w1[NCG * C0 * 125 * COG];
   __shared__ float s_beta[C0], s_gamma[C0 * C0];
+  __shared__ float s_lat[2 * MAXCH * MAXCH + 2 * MAXCH];   // latent generator: w [ci][co], gamma_hat, bias, beta_hat
   const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  if (tid < ch * 8)
-    s_x[tid] = LATENT ? latent_x_rounded(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, b, tid >> 3, tid & 7, ch, 8)
-                      : x0[(size_t)b * ch * 8 + tid];
+  float ev[MAXCH];                                           // this thread's latent element: its ch inputs, fetched together
+  if (LATENT) {
+    // (parameters through LDS and the inputs up front: as loads inside the fmaf chains they were ch^2 dependent round trips)
+    if (tid < ch * ch) { s_lat[tid] = L.w[tid]; s_lat[MAXCH * MAXCH + tid] = L.gamma_hat[tid]; }
+    if (tid >= 64 && tid < 64 + ch) {
+      s_lat[2 * MAXCH * MAXCH + tid - 64] = L.bw[tid - 64];
+      s_lat[2 * MAXCH * MAXCH + MAXCH + tid - 64] = L.beta_hat[tid - 64];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) ev[i] = (tid < ch * 8 && i < ch) ? L.e[((size_t)b * ch + i) * 8 + (tid & 7)] : 0.f;
+  } else if (tid < ch * 8) {
+    s_x[tid] = x0[(size_t)b * ch * 8 + tid];
+  }
   if (tid >= 64 && tid < 64 + C0) s_beta[tid - 64] = st_beta(beta_hat[tid - 64]);
   if (tid >= 128 && tid < 128 + C0 * C0) s_gamma[tid - 128] = st_gamma(gamma_hat[tid - 128]);
   for (int e = tid; e < C0 * 216; e += NT) s_h[e] = 0.f;
-  for (int e = tid; e < ch * 125 * C0; e += NT) s_w0[e] = w0[e];
-  for (int e = tid; e < NCG * C0 * 125 * COG; e += NT) {
+  stem_copy<NT, 16>(s_w0, w0, ch * 125 * C0, tid, [](int e) { return e; });
+  stem_copy<NT, 16>(s_w1, w1, NCG * C0 * 125 * COG, tid, [&](int e) {
     const int cg = e / (C0 * 125 * COG), r = e - cg * (C0 * 125 * COG);
-    s_w1[e] = w1[(size_t)(r / COG) * C1 + (part * NCG + cg) * COG + r % COG];
+    return (r / COG) * C1 + (part * NCG + cg) * COG + r % COG;
+  });
+  if (LATENT) {
+    __syncthreads();
+    if (tid < ch * 8)
+      s_x[tid] = latent_x_rounded_from(ev, s_lat, s_lat + 2 * MAXCH * MAXCH, s_lat + 2 * MAXCH * MAXCH + MAXCH,
+                                       s_lat + MAXCH * MAXCH, tid >> 3, ch);
   }
   __syncthreads();
   const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(C0 * 32) void stem_bwd_dh_kernel(const float* __res
   const int b = blockIdx.x, cp = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int e = tid; e < 2 * 1331; e += NT) s_g[e] = 0.f;
-  for (int e = tid; e < 2 * 125 * C0; e += NT) s_w[e] = w1b[(size_t)cp * 2 * 125 * C0 + e];
+  stem_copy<NT, 8>(s_w, w1b + (size_t)cp * 2 * 125 * C0, 2 * 125 * C0, tid, [](int e) { return e; });
   __syncthreads();
   for (int e = tid; e < 2 * 512; e += NT) {
     const int cc = e >> 9, q = e & 511;
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
   const int c = tid >> 6, v = lane, iz = v >> 4, iy = (v >> 2) & 3, ix = v & 3;
   __shared__ float s_bet[C0], s_gam[C0 * C0];            // re-parametrised IGDN parameters (were scalar-load chains)
   for (int e = tid; e < C0 * 343; e += NT) s_da[e] = 0.f;
-  for (int e = tid; e < C0 * 125 * ch; e += NT) s_w0[e] = w0b[e];
+  stem_copy<NT, 16>(s_w0, w0b, C0 * 125 * ch, tid, [](int e) { return e; });
   for (int e = tid; e < C0 * C0; e += NT) s_gam[e] = st_gamma(gamma_hat[e]);
   if (tid < C0) s_bet[tid] = st_beta(beta_hat[tid]);
   float own_gdn = 0.f;                  // thread p < NCOL owns IGDN partial p
