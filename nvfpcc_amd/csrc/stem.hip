@@ -155,10 +155,12 @@ __global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restri
                                        s_lat + MAXCH * MAXCH, tid >> 3, ch);
   }
   __syncthreads();
-  const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
-  {  // up0: a0[co = c, o] = b0 + sum_ci sum_{k : o + 2 - k = 2 i} x0[ci, i] w0[ci][k][co]
+  {  // up0: a0[co, o] = b0 + sum_ci sum_{k : o + 2 - k = 2 i} x0[ci, i] w0[ci][k][co]
     // per axis the valid taps are k = o (input i = 1) and k = o + 2 (i = 0, if o <= 2): ascending k, the order of
-    // the per-layer kernel, without walking the 125 taps
+    // the per-layer kernel, without walking the 125 taps.  Lanes run over the output CHANNEL here (the weight row of a
+    // tap is C0 consecutive words): with lanes over positions every lane read another tap's row at a stride of C0
+    // words -- 2 (C0 = 16) or 4 banks for the whole wave, 11 us of this launch for the wide decoder.
+    const int co = tid % C0, vo = tid / C0, oz = vo >> 4, oy = (vo >> 2) & 3, ox = vo & 3;
     float acc = 0.f;
     for (int ci = 0; ci < ch; ++ci)
 #pragma unroll
@@ -174,14 +176,15 @@ __global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restri
             const int kx = ox + 2 * ax;
             if (kx > 4) continue;
             acc = fmaf(s_x[ci * 8 + (1 - az) * 4 + (1 - ay) * 2 + (1 - ax)],
-                       s_w0[(ci * 125 + (kz * 5 + ky) * 5 + kx) * C0 + c], acc);
+                       s_w0[(ci * 125 + (kz * 5 + ky) * 5 + kx) * C0 + co], acc);
           }
         }
       }
-    const float val = acc + b0[c];
-    s_a[tid] = val;
-    if (part == 0) a0[(size_t)b * C0 * 64 + tid] = val;
+    const float val = acc + b0[co];
+    s_a[co * 64 + vo] = val;
+    if (part == 0) a0[(size_t)b * C0 * 64 + co * 64 + vo] = val;
   }
+  const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
   __syncthreads();
   {  // IGDN: h0 = a0 * sqrt(beta_c + sum_j gamma_cj a0_j^2)
     float nrm = s_beta[c];
