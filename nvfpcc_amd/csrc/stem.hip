@@ -357,7 +357,9 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
                                                            float* __restrict__ dx0, float* __restrict__ slab_gdn,
                                                            float* __restrict__ slab_w, int batch, int ch, int want_w) {
   constexpr int NT = C0 * 64, NCOL = stem_ncol(C0), NOWN = (kStemWMax * C0 + NT - 1) / NT;
-  __shared__ float s_dh[NT], s_a[NT], s_n[NT], s_t[NT];
+  constexpr int LS = 65;                // row stride of the [channel][64] tiles: the parameter sums below read one column k of
+                                        // every row at once -- at a stride of 64 words that was ONE bank for the whole wave
+  __shared__ float s_dh[NT], s_a[C0 * LS], s_n[NT], s_t[C0 * LS];
   __shared__ float s_da[C0 * 343];      // da0 with a two-voxel halo: [co][7][7][7], index q + 2
   __shared__ float s_x[MAXCH * 8];
   __shared__ float s_w0[C0 * 125 * MAXCH];
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
   __syncthreads();
 
   for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-    s_a[tid] = a0[(size_t)b * NT + tid];
+    s_a[c * LS + v] = a0[(size_t)b * NT + tid];
     if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
     {
       // dh0 = the channel-pair partials of conv0's backward-data, added in ascending order
@@ -392,30 +394,30 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
       float nrm = s_bet[c];
 #pragma unroll
       for (int j = 0; j < C0; ++j) {
-        const float xj = s_a[j * 64 + v];
+        const float xj = s_a[j * LS + v];
         nrm = fmaf(s_gam[c * C0 + j], xj * xj, nrm);
       }
       nrm = sqrtf(nrm);
       s_n[tid] = nrm;
-      s_t[tid] = dh * s_a[tid] / nrm;
+      s_t[c * LS + v] = dh * s_a[c * LS + v] / nrm;
     }
     __syncthreads();
     {  // da0_i = dh_i n_i + a_i sum_c t_c gamma_ci  (i = this thread's channel)
       float mix = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < C0; ++cc) mix = fmaf(s_t[cc * 64 + v], s_gam[cc * C0 + c], mix);
-      const float d = s_dh[tid] * s_n[tid] + s_a[tid] * mix;
+      for (int cc = 0; cc < C0; ++cc) mix = fmaf(s_t[cc * LS + v], s_gam[cc * C0 + c], mix);
+      const float d = s_dh[tid] * s_n[tid] + s_a[c * LS + v] * mix;
       da0[(size_t)b * NT + tid] = d;
       s_da[c * 343 + ((iz + 2) * 7 + iy + 2) * 7 + ix + 2] = d;
       if (want_w && tid < NCOL) {   // parameter partials: p < C0: d beta_p ; else d gamma_{cc,j}
         float sum = 0.f;
         if (tid < C0) {
-          for (int k = 0; k < 64; ++k) sum += s_t[tid * 64 + k];
+          for (int k = 0; k < 64; ++k) sum += s_t[tid * LS + k];
         } else {
           const int cc = (tid - C0) / C0, j = (tid - C0) % C0;
           for (int k = 0; k < 64; ++k) {
-            const float xj = s_a[j * 64 + k];
-            sum = fmaf(s_t[cc * 64 + k], xj * xj, sum);
+            const float xj = s_a[j * LS + k];
+            sum = fmaf(s_t[cc * LS + k], xj * xj, sum);
           }
         }
         own_gdn += 0.5f * sum;
