@@ -356,7 +356,7 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma_hat, float* __restrict__ da0,
                                                            float* __restrict__ dx0, float* __restrict__ slab_gdn,
                                                            float* __restrict__ slab_w, int batch, int ch, int want_w) {
-  constexpr int NT = C0 * 64, NCOL = stem_ncol(C0), NOWN = (kStemWMax * C0 + NT - 1) / NT;
+  constexpr int NT = C0 * 64, NCOL = stem_ncol(C0), NPAIR = (C0 * 125 + NT - 1) / NT;   // (co, k) pairs per thread
   constexpr int LS = 65;                // row stride of the [channel][64] tiles: the parameter sums below read one column k of
                                         // every row at once -- at a stride of 64 words that was ONE bank for the whole wave
   __shared__ float s_dh[NT], s_a[C0 * LS], s_n[NT], s_t[C0 * LS];
@@ -371,9 +371,11 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
   for (int e = tid; e < C0 * C0; e += NT) s_gam[e] = st_gamma(gamma_hat[e]);
   if (tid < C0) s_bet[tid] = st_beta(beta_hat[tid]);
   float own_gdn = 0.f;                  // thread p < NCOL owns IGDN partial p
-  float own_w[NOWN];                    // up0 weight-gradient outputs j = tid + NT r
+  float own_w[NPAIR][MAXCH];            // up0 weight gradient: thread owns pairs p = tid + NT r = (co, k), all ch inputs
 #pragma unroll
-  for (int r = 0; r < NOWN; ++r) own_w[r] = 0.f;
+  for (int r = 0; r < NPAIR; ++r)
+#pragma unroll
+    for (int ci = 0; ci < MAXCH; ++ci) own_w[r][ci] = 0.f;
   const int jtotal = ch * C0 * 125;
   __syncthreads();
 
@@ -442,20 +444,28 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
       for (int m = 1; m < C0; m <<= 1) acc += __shfl_xor(acc, m, 64);
       if (co == 0) dx0[(size_t)b * ch * 8 + out] = acc;
     }
-    // ---- up0 weight gradient: dW0[ci][co][k] += sum_i x0[ci, i] da0[co, 2 i - 2 + k]
+    // ---- up0 weight gradient: dW0[ci][co][k] += sum_i x0[ci, i] da0[co, 2 i - 2 + k].  A thread owns (co, k) pairs and
+    // all ch input channels: the eight da0 values of a pair are read once for the ch sums (one thread per (ci, co, k)
+    // re-read them ch times and decoded its index 16 times: 11 of the wide launch's 26 us)
     if (want_w) {
 #pragma unroll
-      for (int r = 0; r < NOWN; ++r) {
-        const int j = tid + NT * r;
-        if (j < jtotal) {
-          const int k = j % 125, co = (j / 125) % C0, ci = j / (125 * C0);
-          const int kz = k / 25, ky = (k / 5) % 5, kx = k % 5;
+      for (int r = 0; r < NPAIR; ++r) {
+        const int p = tid + NT * r;
+        if (p < C0 * 125) {
+          const int kk = p % 125, co = p / 125;
+          const int kz = kk / 25, ky = (kk / 5) % 5, kx = kk % 5;
           const float* dp = s_da + co * 343 + (kz * 7 + ky) * 7 + kx;
-          float acc = own_w[r];
+          float dv[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            acc = fmaf(s_x[ci * 8 + i], dp[((2 * (i >> 2)) * 7 + 2 * ((i >> 1) & 1)) * 7 + 2 * (i & 1)], acc);
-          own_w[r] = acc;
+          for (int i = 0; i < 8; ++i) dv[i] = dp[((2 * (i >> 2)) * 7 + 2 * ((i >> 1) & 1)) * 7 + 2 * (i & 1)];
+#pragma unroll
+          for (int ci = 0; ci < MAXCH; ++ci)
+            if (ci < ch) {
+              float acc = own_w[r][ci];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc = fmaf(s_x[ci * 8 + i], dv[i], acc);
+              own_w[r][ci] = acc;
+            }
         }
       }
     }
@@ -464,9 +474,13 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
   if (want_w) {
     if (tid < NCOL) slab_gdn[(size_t)blockIdx.x * NCOL + tid] = own_gdn;
 #pragma unroll
-    for (int r = 0; r < NOWN; ++r) {
-      const int j = tid + NT * r;
-      if (j < jtotal) slab_w[(size_t)blockIdx.x * jtotal + j] = own_w[r];
+    for (int r = 0; r < NPAIR; ++r) {
+      const int p = tid + NT * r;
+      if (p < C0 * 125) {
+#pragma unroll
+        for (int ci = 0; ci < MAXCH; ++ci)
+          if (ci < ch) slab_w[(size_t)blockIdx.x * jtotal + (size_t)ci * C0 * 125 + p] = own_w[r][ci];
+      }
     }
   }
 }
