@@ -22,6 +22,7 @@
 // channel stride chosen so the 32 lanes of a ds_read group hit 32 distinct banks.
 // Per output the accumulation order is fixed (ci group, ty, tx, tz), independent of batch and tile.
 #include "nvf_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -351,24 +352,30 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
   int b, oz0, oy0, ox0;
   origin(t, b, oz0, oy0, ox0);
   st.issue(x + (size_t)b * CIN * vol, lds, lds0, 0, wave, lane, oz0 - d.pad, oy0 - d.pad, ox0 - d.pad, d);
-  // every A fragment of the layer, resident in registers for the whole launch
+  // every A fragment of the layer, resident in registers for the whole launch.  Only the first channel group's are
+  // fetched before the loop: the explicit vmcnt(0) that ends a staging step waits for EVERY outstanding load, so the
+  // other groups' fragments are requested right after the first barrier (the first tile's first step is peeled) and
+  // arrive under group 0's MFMAs -- all NA up front was 6.5 us of the 52 us launch (s_memrealtime stamps; it is bound
+  // by the L1's throughput: 8 waves x 40 KB).
+  constexpr int NA0 = C::NA / NG;
   float A[C::NA];
 #pragma unroll
-  for (int i = 0; i < C::NA; ++i) A[i] = wp[(size_t)i * 64 + lane];
+  for (int i = 0; i < NA0; ++i) A[i] = wp[(size_t)i * 64 + lane];
 
-#pragma unroll 1
-  for (;;) {
+  bool more = false;
+  int bn = 0, ozn = 0, oyn = 0, oxn = 0;
+  auto tile = [&](auto firstc) {
+    constexpr bool FIRST = decltype(firstc)::value;
     const int tn = t + wpx;                                  // this workgroup's next tile
-    const bool more = tn < t_hi;
-    int bn = 0, ozn = 0, oyn = 0, oxn = 0;
+    more = tn < t_hi;
     if (more) origin(tn, bn, ozn, oyn, oxn);
     f32x4 acc[NC][NT];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int q = 0; q < NT; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    auto step = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's share of step (t, g) has landed
       __syncthreads();                                              // ... everyone's; the other buffer is free
       if (d.dbg & 1) {
@@ -377,15 +384,23 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
                  oy0 - d.pad, ox0 - d.pad, d);
       else if (more)
         st.issue(x + (size_t)bn * CIN * vol, lds, lds0, 0, wave, lane, ozn - d.pad, oyn - d.pad, oxn - d.pad, d);
-      if (d.dbg & 2) continue;
-      if (g == 0) mfma_step<C, 0>(lds + (g & 1) * BUF, colbase, A, acc);
-      if (g == 1) mfma_step<C, (NG > 1 ? 1 : 0)>(lds + (g & 1) * BUF, colbase, A, acc);
-      if (g == 2) mfma_step<C, (NG > 2 ? 2 : 0)>(lds + (g & 1) * BUF, colbase, A, acc);
-      if (g == 3) mfma_step<C, (NG > 3 ? 3 : 0)>(lds + (g & 1) * BUF, colbase, A, acc);
+    };
+    step(std::integral_constant<int, 0>{});
+    if constexpr (FIRST) {                                   // the remaining fragments are requested here
+#pragma unroll
+      for (int i = NA0; i < C::NA; ++i) A[i] = wp[(size_t)i * 64 + lane];
     }
+    if (!(d.dbg & 2)) mfma_step<C, 0>(lds, colbase, A, acc);
+    if constexpr (NG > 1) { step(std::integral_constant<int, 1>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 1 ? 1 : 0)>(lds + BUF, colbase, A, acc); }
+    if constexpr (NG > 2) { step(std::integral_constant<int, 2>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 2 ? 2 : 0)>(lds, colbase, A, acc); }
+    if constexpr (NG > 3) { step(std::integral_constant<int, 3>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 3 ? 3 : 0)>(lds + BUF, colbase, A, acc); }
     mfma_store<C, EPI>(acc, bias, y, addend, mask, d, b, oz0 + ZS * wz * NT, oy0, ox0, j, wc, kq);
-    if (!more) break;
-    t = tn; b = bn; oz0 = ozn; oy0 = oyn; ox0 = oxn;
+  };
+  tile(std::true_type{});
+#pragma unroll 1
+  while (more) {
+    t += wpx; b = bn; oz0 = ozn; oy0 = oyn; ox0 = oxn;
+    tile(std::false_type{});
   }
 }
 
