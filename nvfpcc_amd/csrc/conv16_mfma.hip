@@ -200,16 +200,43 @@ __global__ __launch_bounds__(C::NT) void conv_g16_mfma(const float* __restrict__
 
   // epilogue: lane holds rows co = 4 kq + r4 of column j of each of its tiles
   const size_t ovol = (size_t)d.dout * d.hout * d.wout;
-  {
-    // (a tile row is CTX consecutive x: every (kq, r4, patch row) writes one CTX * 4-byte segment.  Sending patch-shaped
-    // tiles through LDS to store whole rows was measured SLOWER -- 347 vs 303 us on conv2's backward-data: the kernel
-    // is bound by its MFMAs, the padded border included, not by its stores)
-    const int co0 = cog * 16 + 4 * kq;
-    float bv4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
+  const int co0 = cog * 16 + 4 * kq;
+  float bv4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) bv4[r4] = co0 + r4 < d.cout ? bias[co0 + r4] : 0.f;
+    for (int r4 = 0; r4 < 4; ++r4) bv4[r4] = co0 + r4 < d.cout ? bias[co0 + r4] : 0.f;
+  }
+  constexpr int TILE = 16 * C::OZ * C::OY * C::OX;      // the workgroup's outputs as [channel][z][y][x]
+  if constexpr (C::CTX < 16 && TILE <= 2 * C::BUF) {
+    // Patch-shaped column tiles (4 x 4, 2 x 8): written directly, every store / mask read of a wave touches 16-byte
+    // pieces of 16 different lines (s_memrealtime stamps: 21-29 us of the 88 us a conv2 backward-data workgroup takes).
+    // The tile goes through the (now idle) staging buffers instead and leaves as whole rows, lanes along x.
+    __syncthreads();                                     // every wave is done with its B fragments
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int s = wave * R + r;
+      if (!C::EVEN && s >= C::NSEG) continue;
+      const int cx = s % C::NCX, cy = (s / C::NCX) % C::NCY, z = s / (C::NCX * C::NCY);
+      const int ty = cy * C::CTY + j / C::CTX, tx = cx * C::CTX + j % C::CTX;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        lds[(((4 * kq + r4) * C::OZ + z) * C::OY + ty) * C::OX + tx] = nvf_act(acc[r][r4] + bv4[r4], d.act);
     }
+    __syncthreads();
+    const size_t obase = (size_t)b * d.cout * ovol;
+#pragma unroll 4
+    for (int e = tid; e < TILE; e += NT) {
+      const int tx = e % C::OX, t1 = e / C::OX, ty = t1 % C::OY, t2 = t1 / C::OY, z = t2 % C::OZ, ch = t2 / C::OZ;
+      const int oz = oz0 + z, oy = oy0 + ty, ox = ox0 + tx, co = cog * 16 + ch;
+      if (oz >= d.dout || oy >= d.hout || ox >= d.wout || co >= d.cout) continue;
+      const size_t oo = obase + (size_t)co * ovol + ((size_t)oz * d.hout + oy) * d.wout + ox;
+      float v = lds[e];
+      if (addend) v += addend[oo];
+      if (mask) v = mask[oo] > 0.f ? v : 0.f;
+      y[oo] = v;
+    }
+  } else {
+    // (a tile row is CTX consecutive x: every (kq, r4, patch row) writes one CTX * 4-byte segment)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = wave * R + r;
