@@ -1005,10 +1005,11 @@ extern "C" int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t
   long wg = 0;
   const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
   if (rc != NVF_OK) return rc;
-  // 16 workgroups per layer and pack job; 64 for the wide decoder's kernels (up to 64 000 weights each: 31 -> us)
-  int wpl = 16;
+  // workgroups per layer and pack job: 64 (narrow: 10.0 us with 16, 8.0 with 32, 7.2 with 64); 128 for the wide decoder's
+  // kernels (up to 64 000 weights each: 30.6 us with 16, 13.7 with 64, 12.1 with 128)
+  int wpl = 64;
   for (int j = 0; j < npack; ++j)
-    if (pack_c0s && pack_c1s && pack_c0s[j] * pack_c1s[j] >= 256) wpl = 64;
+    if (pack_c0s && pack_c1s && pack_c0s[j] * pack_c1s[j] >= 256) wpl = 128;
   step_head_kernel<<<wpl * nlayers + wpl * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
       (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl);
   NVF_LAUNCH_CHECK();
