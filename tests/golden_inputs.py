@@ -123,6 +123,23 @@ def codec_cases():
     return cases
 
 
+def huffman_cases():
+    """Integer weight pools (float32 arrays of whole numbers, as `ws[k].numpy() * qp` gives them,
+    util_code_quantized_weights.py:37-51) for the Huffman codebook goldens."""
+    rng = np.random.default_rng(777)
+    cases = {}
+    # a 4-bit trained decoder looks like this: a narrow two-sided geometric around 0
+    cases["laplace"] = np.round(rng.laplace(0.0, 1.6, 52000)).clip(-9, 11).astype(np.float32)
+    # exact ties everywhere: every value 0..7 occurs 64 times, -1 occurs 128 and 9 occurs 32 times
+    t = np.concatenate([np.repeat(np.arange(8), 64), np.full(128, -1), np.full(32, 9)])
+    cases["ties"] = rng.permutation(t).astype(np.float32)
+    # two symbols, and a gap in the value range (zero-frequency bins are dropped)
+    cases["gap"] = np.array([-3] * 5 + [4] * 11 + [5] * 11 + [7], np.float32)
+    # one distinct value: the codebook is the empty word
+    cases["single"] = np.full(37, 2, np.float32)
+    return cases
+
+
 def synthetic_cloud(seed=99, n_dir=40000, radius=70.0, center=(500.0, 530.0, 470.0)):
     """A 10-bit voxelised ellipsoid shell (~30 k points, ~100 level-5 cubes) for the pre-processing tests."""
     rng = np.random.default_rng(seed)

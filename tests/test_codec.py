@@ -137,3 +137,27 @@ def test_single_valued_kernels_use_the_empty_codeword(tmp_path):
     assert pack['bit_stream'] == b'' and list(pack['inv_codebook']) == ['']
     dec = weight_codec.entropy_decode(pack['bit_stream'], pack['inv_codebook'], pack['element_length'], pack['shape_list'])
     assert all(not t.any() for t in dec)
+
+
+@pytest.mark.parametrize("name", ["laplace", "ties", "gap", "single"])
+def test_huffman_codebook_equals_the_reference_functions(name, golden_dir):
+    """tests/golden/huffman.npz holds what the reference's own get_pdf / get_huffman_codebook / est_rate
+    (util_code_quantized_weights.py:53-105) return for these pools (tools/gen_golden_codec.py imports them): the
+    same pdf, the same bit string for every symbol -- tie-breaking included -- the same expected length and the
+    same stream length in bytes.  What stays unpinned is only the order of bits INSIDE a byte, which belongs to
+    the PyPI `bitstream` package."""
+    from tests.golden_inputs import huffman_cases
+    g = np.load(os.path.join(golden_dir, "huffman.npz"))
+    eles = huffman_cases()[name]
+    pdf, bins = weight_codec.get_pdf(eles)
+    assert np.array_equal(bins, g[name + "/bins"]) and np.array_equal(pdf, g[name + "/pdf"])
+    codebook, inv = weight_codec.get_huffman_codebook(pdf, bins)
+    want = {str(w): int(s) for w, s in zip(g[name + "/words"], g[name + "/symbols"])}
+    assert {k: int(v) for k, v in inv.items()} == want
+    for word, sym in want.items():
+        assert "".join("1" if b else "0" for b in codebook[sym]) == word
+    assert weight_codec.est_rate(pdf, bins, codebook) == pytest.approx(float(g[name + "/rate"]), rel=1e-12, abs=0)
+    stream, shapes = weight_codec.entropy_encode([eles], codebook)
+    assert len(stream) == int(g[name + "/nbytes"])
+    back = weight_codec.entropy_decode(stream, inv, eles.size, shapes)
+    assert np.array_equal(back[0], eles)

@@ -29,7 +29,33 @@ def ref_decode(stream, mu, sigma):
     return np.frombuffer(out, np.int16)
 
 
+def gen_huffman():
+    """Huffman codebooks from the reference's OWN get_pdf / get_huffman_codebook / est_rate
+    (util_code_quantized_weights.py:53-105: pure numpy; the module's `import bitstream` is satisfied by an empty
+    stand-in because these three functions never touch it)."""
+    import types
+    sys.modules.setdefault("bitstream", types.ModuleType("bitstream"))
+    sys.path.insert(0, "/root/reference")
+    import util_code_quantized_weights as ref
+    from tests.golden_inputs import huffman_cases
+    g = {}
+    for name, eles in huffman_cases().items():
+        pdf, bins = ref.get_pdf(eles)
+        codebook, inv = ref.get_huffman_codebook(pdf, bins)
+        words = sorted(inv)                                     # bit strings ('' for the one-symbol pool)
+        g[name + "/words"] = np.array(words, dtype="U64")
+        g[name + "/symbols"] = np.array([int(inv[w]) for w in words], np.int64)
+        g[name + "/pdf"] = np.asarray(pdf, np.float64)
+        g[name + "/bins"] = np.asarray(bins, np.int64)
+        g[name + "/rate"] = np.float64(ref.est_rate(pdf, bins, codebook))
+        nbits = sum(len(codebook[int(v)]) for v in eles)
+        g[name + "/nbytes"] = np.int64((nbits + 7) // 8)        # :119-126: zero-padded to whole bytes
+        print("huffman", name, "symbols", len(words), "rate", g[name + "/rate"], "bytes", g[name + "/nbytes"])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "huffman.npz"), **g)
+
+
 def main():
+    gen_huffman()
     g = {}
     for name, (sym, mu, sigma) in codec_cases().items():
         stream = ref_encode(sym, mu, sigma)
