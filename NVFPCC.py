@@ -60,8 +60,9 @@ def _build_net(args, dev):
 
 
 def _psnr1(sse, denom):
-    mse1 = sse / max(denom, 1e-30)
-    return mse1, 20 * np.log10(1023 / np.sqrt(mse1 / 3)) if mse1 > 0 else float('inf')
+    with np.errstate(divide="ignore", invalid="ignore"):     # 0 / 0 prints nan, as in the reference (NVFPCC.py:259-260)
+        mse1 = np.float64(sse) / np.float64(denom)
+        return mse1, 20 * np.log10(1023 / np.sqrt(mse1 / 3))
 
 
 def train(args):
@@ -100,16 +101,8 @@ def train(args):
             eng.noise_step += 1
         nd.allgather_rows_(eng.emb, rank, world)
         # NaN guards of NVFPCC.py:199-212 are checked here, on the summed counters (raises ValueError)
-        m, sums = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None)
-        ls = sums[0:3] / nsteps
-        # b_net is replicated: every rank (idle ones included) added it once per step
-        bs = np.array([sums[3], sums[4] / world]) / nsteps
-        mse1, psnr1 = _psnr1(m[4], m[5])
-        total = ls.sum() + args.lmbda * (bs[0] * args.w1 + bs[1] * args.w2)
-        say('[Epoch %04d TRAIN %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f '
-            'S1 Loss: %.4f S2 Loss: %.4f bpp: %.4f b_latent: %.4f  b_net: %.4f MSE1: %.4f PSNR1: %.4f' % (
-                epoch, time.time() - t0, total, 0.0, 0.0, m[0] / max(m[1], 1), m[2] / max(m[3], 1), ls[1], ls[2],
-                bs[0] + bs[1], bs[0], bs[1], mse1, psnr1))
+        acc = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None, world=world)
+        say(TRAIN_LINE % ((epoch, time.time() - t0) + tuple(eng.train_log_fields(acc, nsteps))))
         if epoch % 10 == 0 and rank == 0:
             print('[INFO] Saving')
             os.makedirs(args.checkpoint_dir, exist_ok=True)
@@ -117,14 +110,46 @@ def train(args):
             torch.save(sd, './%s/%04d.ckpt' % (args.checkpoint_dir, epoch))
             torch.save(eng.emb.detach().clone(), './%s/%04d_emb.ckpt' % (args.checkpoint_dir, epoch))
             t1 = time.time()
-            a = eng.eval_forward(q=2)
-            mt = ops.metrics(a["p2"], eng.gt, eng.dist, 0.5, 0.6).cpu().numpy()
-            lat_bits = a["lbits"].item()
-            net_bits = net.get_network_bits()
-            mse1, psnr1 = _psnr1(mt[4], mt[5])
-            print('[Epoch %04d TEST %.1f seconds] Pacc: %.4f Nacc: %.4f b_latent: %.4f b_all: %.4f MSE1: %.4f '
-                  'PSNR1: %.4f' % (epoch, time.time() - t1, mt[0] / max(mt[1], 1), mt[2] / max(mt[3], 1),
-                                   lat_bits / data.N, (lat_bits + net_bits) / data.N, mse1, psnr1))
+            fields = tuple(test_log_fields(eng, net, data.N, args.lmbda))
+            print(TEST_LINE % ((epoch, time.time() - t1) + fields))
+
+
+def test_log_fields(eng, net, n_points, lmbda):
+    """The 17 numbers of the reference's TEST line (NVFPCC.py:308-392): full-batch net(emb, 'eval', 2), the same
+    losses / metrics as the TRAIN line on ALL blocks (one "mini-batch": cnt = 1), and b_all = (latent bits + network
+    bits incl. the side information of Net.get_network_bits) / N.  Quirk kept: its Loss adds lambda * (b_latent + b_net)
+    without the w1 / w2 weights (:347)."""
+    from nvfpcc_amd import ops
+    a = eng.eval_forward(q=2)
+    loss = torch.empty(4, device=eng.dev)
+    ops.focal_loss_multi([(a["p2"], eng.gt, eng.dist, 0.9, 1.0), (a["p0"], eng.gt8, None, 0.85, 0.0),
+                          (a["p1"], eng.gt16, None, 0.85, 0.0)], loss)
+    c = ops.metrics3([a["p2"], a["p0"], a["p1"]], [eng.gt, eng.gt8, eng.gt16], [eng.dist, None, None], 0.5, 0.6)
+    c = c.double().cpu().numpy()
+    ls = loss.double().cpu().numpy()
+    lat_bits = float(a["lbits"].item())
+    nbits = torch.empty(7, device=eng.dev)
+    lm = net.reconstructor.likelihood_model
+    ops.weight_rate_batch([eng.layers[n].mod.kernel for n in ("up0", "conv0", "up1", "conv1", "up2", "conv2",
+                                                               "conv2_cls")], None, lm.sigma, lm.mu, nbits)
+    n_pts = float(eng.counts.sum())
+    b_latent, b_net = lat_bits / n_pts, float(nbits.sum().item()) / float(n_points)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = [c[6 * t + k] / c[6 * t + k + 1] for t in range(3) for k in (0, 2)]
+        mse1 = c[4] / c[5]
+        psnr1 = 20 * np.log10(1023 / np.sqrt(mse1 / 3))
+    b_all = (lat_bits + net.get_network_bits()) / float(n_points)
+    return [ls[0] + ls[1] + ls[2] + lmbda * (b_latent + b_net), 0.0, 0.0, r[0], r[1], ls[1], ls[2], r[2], r[3], r[4],
+            r[5], b_latent + b_net, b_latent, b_net, b_all, mse1, psnr1]
+
+
+# the reference's format strings (NVFPCC.py:261, 371), character for character: anything that parses its log parses ours
+TRAIN_LINE = ('[Epoch %04d TRAIN %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f '
+              'S1 Loss: %.4f S2 Loss: %.4f S1Pacc: %.4f S1Nacc: %.4f S2Pacc: %.4f S2Nacc: %.4f bpp: %.4f '
+              'b_latent: %.4f  b_net: %.4f MSE1: %.4f PSNR1: %.4f')
+TEST_LINE = ('[Epoch %04d TEST %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f '
+             'S1 Loss: %.4f S2 Loss: %.4f S1Pacc: %.4f S1Nacc: %.4f S2Pacc: %.4f S2Nacc: %.4f bpp: %.4f '
+             'b_latent: %.4f b_net: %.4f b_all: %.4f MSE1: %.4f PSNR1: %.4f')
 
 
 def encode(args):

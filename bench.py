@@ -367,7 +367,7 @@ def run(args):
             else:
                 eng.noise_step += 1
             nd.allgather_rows_(eng.emb, rank, world)
-            m, sums = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None)   # the epoch's one sync
+            eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None, world=world)   # the epoch's one sync
             if ep % 10 == 0 and rank == 0:
                 a = eng.eval_forward(q=2)
                 ops.metrics(a["p2"], eng.gt, eng.dist, 0.5, 0.6).cpu()

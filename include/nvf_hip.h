@@ -394,6 +394,14 @@ int nvf_focal_loss_multi(const float* const* ps, const float* const* gts, const 
 int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
                 void* workspace, size_t workspace_bytes, int64_t n, int accumulate, NvfStepCtx* ctx, void* stream);
 
+/* the same six sums for up to three (prediction, ground truth[, dist]) pairs in one launch: out[6 t + k], overwritten
+ * (the main output and the two coarse heads of the TRAIN / TEST log lines, NVFPCC.py:174-179, 214-221); dists or any
+ * dists[t] may be NULL (sse = 0).  workspace: nvf_metrics_workspace() bytes (also enough for nvf_metrics). */
+size_t nvf_metrics_workspace(void);
+int nvf_metrics3(const float* const* ps, const float* const* gts, const float* const* dists, const int64_t* ns,
+                 int nterm, float thh_acc, float thh_sse, float* out, void* workspace, size_t workspace_bytes,
+                 NvfStepCtx* ctx, void* stream);
+
 /* dlogit = dp * p * (1 - p)   (sigmoid backward of network.py:4761,4764,4768) */
 int nvf_sigmoid_bwd(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
 
@@ -413,16 +421,46 @@ int nvf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float eps, int step, void* stream);
 
 /* The tail of a training step with every per-step scalar in device memory (so it can be a node of a replayed HIP
- * graph, behind the data-parallel all-reduce): nvf_adam_step with coef_dev[0] = lr / (1 - beta1^t) and
- * coef_dev[1] = sqrt(1 - beta2^t) (coef_dev NULL: the two host values coef0_host, coef1_host instead) --
- * nvf_adam_coefficients() gives exactly the two floats nvf_adam_step would use, so the updates are identical -- plus, when acc is non-NULL, the epoch's running sums (NVFPCC.py:190-221 without the
- * per-step .item() syncs): acc[0..2] += loss_terms[0..2]; acc[3] += lbits[0] * (g_lat_dev ? *g_lat_dev : 1) *
- * lbits_scale (b_latent, NVFPCC.py:161); acc[4] += sum(nbits[0..nnb)) * nbits_scale (b_net, :162); acc[5] += number
- * of non-finite terms among those; acc[6] += number of non-finite gradient entries (the checks of NVFPCC.py:199-212,
- * read by the host once per epoch); acc[7] += 1. */
-int nvf_step_tail(float* p, const float* g, float* m, float* v, int64_t n, const float* coef_dev, float coef0_host,
-                  float coef1_host, float beta1, float beta2, float eps, const float* loss_terms, const float* lbits, const float* nbits, int nnb,
-                  const float* g_lat_dev, float lbits_scale, float nbits_scale, float* acc, void* stream);
+ * graph, behind the data-parallel all-reduce).  One launch does
+ *   - nvf_adam_step over n floats with coef_dev[0] = lr / (1 - beta1^t), coef_dev[1] = sqrt(1 - beta2^t) (coef_dev
+ *     NULL: the host values coef0_host, coef1_host) -- nvf_adam_coefficients() gives exactly the two floats
+ *     nvf_adam_step would use, so the updates are identical.  An element whose gradient is NaN / +-inf keeps its
+ *     parameter and moments and is counted in acc[6] (the reference checks before opt.step(), NVFPCC.py:199-212);
+ *   - when acc is non-NULL, the epoch's running sums behind the TRAIN log line (NVFPCC.py:190-221, 256-281, without
+ *     the per-step .item() syncs): acc[0..2] += loss_terms[0..2]; acc[3] += lbits[0] * (inv_npts_dev ? *inv_npts_dev :
+ *     inv_npts_host) (b_latent, :161); acc[4] += sum(nbits[0..nnb)) * nbits_scale (b_net, :162); acc[5] += number of
+ *     non-finite terms among those; acc[7] += 1; and, when counts (the 18 floats of nvf_metrics3) is non-NULL, the
+ *     per-step ratios the reference averages: acc[8 + 2t] += tp_t / ap_t, acc[9 + 2t] += tn_t / an_t for t = main
+ *     output, head 0, head 1 (get_acc_dense, loss.py:74-84), acc[14] += sse, acc[15] += denom (get_sse1);
+ *   - when sched_rows is non-NULL, the hand-over to the next step: row sched_cursor[0] of the caller's schedule
+ *     (sched_words int64 words per row: whatever the step's kernels read from sched_buf -- block ids, noise step, rate
+ *     coefficient, Adam coefficients) is copied over sched_buf and the cursor advances, so a replayed graph needs no
+ *     host-to-device copy per step.
+ * done: one uint32 of device memory, zero before the first call (the last workgroup to arrive does the scalars and
+ * resets it); required when acc or sched_rows is given. */
+typedef struct NvfStepTail {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  const float* coef_dev;
+  float coef0_host, coef1_host, beta1, beta2, eps;
+  int32_t nnb;
+  const float* loss_terms;
+  const float* lbits;
+  const float* nbits;
+  const float* inv_npts_dev;
+  float inv_npts_host, nbits_scale;
+  const float* counts;
+  float* acc;
+  int64_t* sched_buf;
+  const int64_t* sched_rows;
+  uint64_t* sched_cursor;
+  uint32_t* done;
+  int32_t sched_words, reserved;
+} NvfStepTail;
+int nvf_step_tail(const NvfStepTail* args, void* stream);
 int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
 
 /* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose

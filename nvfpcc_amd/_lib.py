@@ -85,12 +85,14 @@ PROTOTYPES = {
     "nvf_focal_loss": (I, [P, P, P, F, F, P, P, P, F, P, Z, L, I, I, P]),
     "nvf_focal_loss_multi": (I, [P, P, P, P, P, P, P, I, P, I, P, Z, P, P]),
     "nvf_metrics": (I, [P, P, P, F, F, P, P, Z, L, I, P, P]),
+    "nvf_metrics_workspace": (Z, []),
+    "nvf_metrics3": (I, [P, P, P, P, I, F, F, P, P, Z, P, P]),
     "nvf_sigmoid_bwd": (I, [P, P, P, L, P]),
     "nvf_relu_bwd": (I, [P, P, P, L, P]),
     "nvf_squared_error_map": (I, [P, P, F, P, I, I, P]),
     "nvf_maxpool2": (I, [P, P, I, I, I, I, P]),
     "nvf_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
-    "nvf_step_tail": (I, [P, P, P, P, L, P, F, F, F, F, F, P, P, P, I, P, F, F, P, P]),
+    "nvf_step_tail": (I, [P, P]),
     "nvf_adam_coefficients": (I, [F, F, F, I, P]),
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
@@ -101,6 +103,18 @@ PROTOTYPES = {
     "nvf_threshold_count": (I, [P, F, P, I, I, P]),
     "nvf_threshold_compact": (I, [P, F, P, P, P, I, I, P]),
 }
+
+
+
+class NvfStepTail(C.Structure):
+    """include/nvf_hip.h: typedef struct NvfStepTail (field for field)."""
+    _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", L), ("coef_dev", P),
+                ("coef0_host", F), ("coef1_host", F), ("beta1", F), ("beta2", F), ("eps", F), ("nnb", C.c_int32),
+                ("loss_terms", P), ("lbits", P), ("nbits", P), ("inv_npts_dev", P),
+                ("inv_npts_host", F), ("nbits_scale", F), ("counts", P), ("acc", P),
+                ("sched_buf", P), ("sched_rows", P), ("sched_cursor", P), ("done", P),
+                ("sched_words", C.c_int32), ("reserved", C.c_int32)]
+
 
 _lib = None
 

@@ -138,6 +138,16 @@ __device__ __forceinline__ void stem_gdn_final_body(const StemGdnFinal& f, int p
   }
 }
 
+// metric partials of term t (rows of 6) -> out[6 t + k], k = tid % 6, in row order (the arithmetic of finalize_partials)
+__device__ __forceinline__ void metrics_final_body(const float* __restrict__ part, float* __restrict__ out,
+                                                   const int32_t* nwg, int nterm, int accumulate, int tid) {
+  if (tid >= 6 * nterm) return;
+  const int t = tid / 6, k = tid - 6 * t;
+  float s = 0.f;
+  for (int g = 0; g < nwg[t]; ++g) s += part[((size_t)t * kLossMaxWG + g) * 6 + k];
+  out[tid] = accumulate ? out[tid] + s : s;
+}
+
 // Everything one finals launch needs (at most one job of each kind)
 struct FinalsArgs {
   FocalMulti f;
@@ -154,9 +164,9 @@ struct FinalsArgs {
   const float* r_gdev;
   float r_ghost;
   StemGdnFinal g;
-  const float* m_part;   // metrics (nvf_metrics): m_nwg rows of 6 partial sums, added into m_out[0..5]
-  float* m_out;
-  int32_t m_nwg, m_accumulate;
+  const float* m_part;   // metrics (nvf_metrics / nvf_metrics3): per term t, m_nwg[t] rows of 6 partial sums at row
+  float* m_out;          // t * kLossMaxWG, summed in row order into m_out[6 t .. 6 t + 5]
+  int32_t m_nwg[3], m_nterm, m_accumulate;
   int32_t f_nterm, has_f, has_s, has_r, has_g, has_m;
 };
 
@@ -170,6 +180,6 @@ int nvf_finals_run_stem_gdn(NvfStepCtx* ctx, const StemGdnFinal& f, void* stream
 // queue the focal final pass or, when nothing is being deferred, launch it on `stream`
 int nvf_finals_run_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);
 bool nvf_finals_push_sums(NvfStepCtx* ctx, const MultiSumDesc& d, const float* part);
-bool nvf_finals_push_metrics(NvfStepCtx* ctx, const float* part, float* out, int nwg, int accumulate);
+bool nvf_finals_push_metrics(NvfStepCtx* ctx, const float* part, float* out, const int* nwg, int nterm, int accumulate);
 bool nvf_finals_push_rate(NvfStepCtx* ctx, const WeightRateBatch& b, const float* part, const float* sigma, float* bits,
                           float* dsigma, float* dmu, const float* g_dev, float g_host);

@@ -9,11 +9,7 @@ namespace {
 __global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a, int sum_blocks) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x == 2 + sum_blocks) {
-    if (a.has_m && tid < 6) {
-      float s = 0.f;
-      for (int g = 0; g < a.m_nwg; ++g) s += a.m_part[(size_t)g * 6 + tid];
-      a.m_out[tid] = a.m_accumulate ? a.m_out[tid] + s : s;
-    }
+    if (a.has_m) metrics_final_body(a.m_part, a.m_out, a.m_nwg, a.m_nterm, a.m_accumulate, tid);
   } else if (blockIdx.x == 0) {
     if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
   } else if (blockIdx.x == 1) {
@@ -41,10 +37,12 @@ bool nvf_finals_push_sums(NvfStepCtx* ctx, const MultiSumDesc& d, const float* p
   return true;
 }
 
-bool nvf_finals_push_metrics(NvfStepCtx* ctx, const float* part, float* out, int nwg, int accumulate) {
-  if (!nvf_ctx_ok(ctx) || !ctx->deferring || ctx->args.has_m) return false;
+bool nvf_finals_push_metrics(NvfStepCtx* ctx, const float* part, float* out, const int* nwg, int nterm,
+                              int accumulate) {
+  if (!nvf_ctx_ok(ctx) || !ctx->deferring || ctx->args.has_m || nterm < 1 || nterm > 3) return false;
   FinalsArgs& q = ctx->args;
-  q.m_part = part; q.m_out = out; q.m_nwg = nwg; q.m_accumulate = accumulate; q.has_m = 1;
+  q.m_part = part; q.m_out = out; q.m_nterm = nterm; q.m_accumulate = accumulate; q.has_m = 1;
+  for (int t = 0; t < nterm; ++t) q.m_nwg[t] = nwg[t];
   return true;
 }
 

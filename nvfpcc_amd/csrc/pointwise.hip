@@ -627,13 +627,28 @@ extern "C" int nvf_focal_loss_multi(const float* const* ps, const float* const* 
   return NVF_OK;
 }
 
-// metrics (utils/loss.py:74-84, 113-121): tp, ap, tn, an at thh_acc; sse, denom at thh_sse
-__global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ p, const float* __restrict__ gt,
-                                                      const float* __restrict__ dist, float thh_acc, float thh_sse,
-                                                      float* __restrict__ part, long n) {
+// metrics (utils/loss.py:74-84, 113-121): tp, ap, tn, an at thh_acc; sse, denom at thh_sse -- of up to three
+// (prediction, ground truth) pairs in one launch (blockIdx.y = term): the main output and the two coarse heads, whose
+// accuracies the reference's log line prints beside it (NVFPCC.py:174-179, 261-281).  dist may be NULL (sse = 0).
+struct MetricsMulti {
+  const float* p[3];
+  const float* gt[3];
+  const float* dist[3];
+  long n[3];
+  int nwg[3];
+};
+
+__global__ __launch_bounds__(256) void metrics_kernel(MetricsMulti m, float thh_acc, float thh_sse,
+                                                      float* __restrict__ part) {
   __shared__ float red[16];
+  const int t = blockIdx.y;
+  if ((int)blockIdx.x >= m.nwg[t]) return;
+  const float* __restrict__ p = m.p[t];
+  const float* __restrict__ gt = m.gt[t];
+  const float* __restrict__ dist = m.dist[t];
+  const long n = m.n[t];
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)m.nwg[t] * blockDim.x) {
     float pv = p[i];
     bool occ = gt[i] != 0.f;
     v[0] += (pv > thh_acc && occ) ? 1.f : 0.f;
@@ -648,24 +663,54 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    float t = nvf_block_sum(v[k], red);
-    if (threadIdx.x == 0) part[blockIdx.x * 6 + k] = t;
+    float tot = nvf_block_sum(v[k], red);
+    if (threadIdx.x == 0) part[((size_t)t * kLossMaxWG + blockIdx.x) * 6 + k] = tot;
   }
+}
+
+__global__ void metrics_final_kernel(const float* __restrict__ part, float* __restrict__ out, int n0, int n1, int n2,
+                                     int nterm, int accumulate) {
+  const int32_t nwg[3] = {n0, n1, n2};
+  metrics_final_body(part, out, nwg, nterm, accumulate, threadIdx.x);
+}
+
+extern "C" size_t nvf_metrics_workspace(void) { return (size_t)3 * kLossMaxWG * 6 * sizeof(float); }
+
+static int metrics_launch(const float* const* ps, const float* const* gts, const float* const* dists,
+                          const int64_t* ns, int nterm, float thh_acc, float thh_sse, float* out, void* workspace,
+                          size_t workspace_bytes, int accumulate, NvfStepCtx* ctx, void* stream) {
+  if (!ps || !gts || !ns || !out || !workspace || nterm < 1 || nterm > 3) return NVF_EINVAL;
+  if (workspace_bytes < nvf_metrics_workspace()) return NVF_EWORKSPACE;
+  MetricsMulti m{};
+  int most = 0;
+  for (int t = 0; t < nterm; ++t) {
+    if (!ps[t] || !gts[t] || ns[t] <= 0) return NVF_EINVAL;
+    m.p[t] = ps[t]; m.gt[t] = gts[t]; m.dist[t] = dists ? dists[t] : nullptr; m.n[t] = (long)ns[t];
+    int nwg = (int)((ns[t] + 256 * 8 - 1) / (256 * 8));
+    m.nwg[t] = nwg > kLossMaxWG ? kLossMaxWG : nwg;
+    if (m.nwg[t] > most) most = m.nwg[t];
+  }
+  hipStream_t s = nvf_stream(stream);
+  metrics_kernel<<<dim3(most, nterm), 256, 0, s>>>(m, thh_acc, thh_sse, (float*)workspace);
+  if (!nvf_finals_push_metrics(ctx, (const float*)workspace, out, m.nwg, nterm, accumulate))
+    metrics_final_kernel<<<1, 64, 0, s>>>((const float*)workspace, out, m.nwg[0], m.nwg[1], m.nwg[2], nterm,
+                                          accumulate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 extern "C" int nvf_metrics(const float* p, const float* gt, const float* dist, float thh_acc, float thh_sse, float* out,
                            void* workspace, size_t workspace_bytes, int64_t n, int accumulate, NvfStepCtx* ctx,
                            void* stream) {
-  if (!p || !gt || !out || !workspace || n <= 0) return NVF_EINVAL;
-  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
-  int nwg = (int)((n + 256 * 8 - 1) / (256 * 8));
-  if (nwg > kLossMaxWG) nwg = kLossMaxWG;
-  hipStream_t s = nvf_stream(stream);
-  metrics_kernel<<<nwg, 256, 0, s>>>(p, gt, dist, thh_acc, thh_sse, (float*)workspace, (long)n);
-  if (!nvf_finals_push_metrics(ctx, (const float*)workspace, out, nwg, accumulate))
-    finalize_partials<<<1, 64, 0, s>>>((const float*)workspace, out, nwg, 6, accumulate);
-  NVF_LAUNCH_CHECK();
-  return NVF_OK;
+  return metrics_launch(&p, &gt, &dist, &n, 1, thh_acc, thh_sse, out, workspace, workspace_bytes, accumulate, ctx,
+                        stream);
+}
+
+// out[6 t + k]: the six sums of term t (t < nterm <= 3), overwritten
+extern "C" int nvf_metrics3(const float* const* ps, const float* const* gts, const float* const* dists,
+                            const int64_t* ns, int nterm, float thh_acc, float thh_sse, float* out, void* workspace,
+                            size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
+  return metrics_launch(ps, gts, dists, ns, nterm, thh_acc, thh_sse, out, workspace, workspace_bytes, 0, ctx, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -776,67 +821,85 @@ extern "C" int nvf_adam_step(float* p, const float* g, float* m, float* v, int64
 
 // The tail of a training step with every per-step scalar in DEVICE memory, so that it can sit inside a replayed HIP graph
 // (and behind the data-parallel all-reduce): Adam with coef[0] = lr / (1 - b1^t), coef[1] = sqrt(1 - b2^t) staged by the
-// host (the floats nvf_adam_step computes: identical updates), a count of non-finite gradient entries
-// (NVFPCC.py:199-212's checks, read once per epoch instead of synchronising every step), and the epoch's running sums of
-// the objective's terms.  Workgroup 0's first thread does the sums after the element-wise part.
-struct StepStats {
-  const float* loss_terms;   // [3] focal terms (main, head 0, head 1)
-  const float* lbits;        // [1] latent bits of the mini-batch
-  const float* nbits;        // [nnb] weight bits per quantised kernel
-  const float* g_lat_dev;    // [1] optional factor: lambda * w1 / n_pts when lbits_scale = 1 / (lambda * w1)
-  float* acc;                // [8]: loss terms 0..2, b_latent, b_net, non-finite objective terms, non-finite gradient
-                             //      entries, steps
-  float lbits_scale, nbits_scale;
-  int32_t nnb;
-};
-
-__global__ void step_tail_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                 float* __restrict__ v, long n, const float* __restrict__ coef, float c0, float c1,
-                                 float b1, float b2, float eps, StepStats st) {
+// host (the floats nvf_adam_step computes: identical updates); the epoch's running sums behind NVFPCC.py's log line
+// (:190-221, 256-281) and the counters behind its NaN checks (:199-212), read once per epoch instead of synchronising
+// every step; and the hand-over to the NEXT step: the last workgroup to finish copies the next row of the caller's
+// step schedule (block ids, noise step, rate coefficients, Adam coefficients) over the buffer the step's kernels read,
+// so a replayed graph needs no host-to-device copy per step.  An element whose gradient is not finite keeps its
+// parameter and moments (it is counted): the parameters at the raise are finite.
+__global__ void step_tail_kernel(NvfStepTail a) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int bad = 0;
-  if (i < n) {
-    const float step_size = coef ? coef[0] : c0, bc2_sqrt = coef ? coef[1] : c1;
-    float gi = g[i];
+  if (i < a.n) {
+    const float step_size = a.coef_dev ? a.coef_dev[0] : a.coef0_host, bc2_sqrt = a.coef_dev ? a.coef_dev[1] : a.coef1_host;
+    const float gi = a.g[i];
     bad = !(fabsf(gi) <= 3.402823466e38f);          // NaN or +-inf
-    float mi = m[i] * b1 + gi * (1.f - b1);
-    float vi = v[i] * b2 + (gi * gi) * (1.f - b2);
-    m[i] = mi;
-    v[i] = vi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    if (!bad) {
+      const float mi = a.m[i] * a.beta1 + gi * (1.f - a.beta1);
+      const float vi = a.v[i] * a.beta2 + (gi * gi) * (1.f - a.beta2);
+      a.m[i] = mi;
+      a.v[i] = vi;
+      const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+      a.p[i] = a.p[i] - step_size * (mi / denom);
+    }
   }
-  if (!st.acc) return;
-  const unsigned long long any = __ballot(bad);
-  if (any && (threadIdx.x & 63) == 0) atomicAdd(st.acc + 6, (float)__popcll(any));   // integer-valued: order-free
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (a.acc) {
+    const unsigned long long any = __ballot(bad);
+    if (any && (threadIdx.x & 63) == 0) atomicAdd(a.acc + 6, (float)__popcll(any));   // integer-valued: order-free
+  }
+  if (!a.acc && !a.sched_rows) return;
+  // the last workgroup to arrive does the per-step scalars: every other workgroup has read its coefficients by then
+  __shared__ int last;
+  bool is_last = gridDim.x == 1;
+  if (gridDim.x > 1) {
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(a.done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    is_last = last != 0;
+  }
+  if (!is_last) return;
+  if (a.acc && threadIdx.x == 0) {
     int bad_terms = 0;
     for (int t = 0; t < 3; ++t) {
-      const float x = st.loss_terms[t];
-      st.acc[t] += x;
+      const float x = a.loss_terms[t];
+      a.acc[t] += x;
       bad_terms += !(fabsf(x) <= 3.402823466e38f);
     }
-    const float bl = st.lbits[0] * (st.g_lat_dev ? st.g_lat_dev[0] : 1.f) * st.lbits_scale;
+    const float bl = a.lbits[0] * (a.inv_npts_dev ? a.inv_npts_dev[0] : a.inv_npts_host);
     float nb = 0.f;
-    for (int l = 0; l < st.nnb; ++l) nb += st.nbits[l];
-    nb *= st.nbits_scale;
-    st.acc[3] += bl;
-    st.acc[4] += nb;
+    for (int l = 0; l < a.nnb; ++l) nb += a.nbits[l];
+    nb *= a.nbits_scale;
+    a.acc[3] += bl;
+    a.acc[4] += nb;
     bad_terms += !(fabsf(bl) <= 3.402823466e38f) + !(fabsf(nb) <= 3.402823466e38f);
-    st.acc[5] += (float)bad_terms;
-    st.acc[7] += 1.f;
+    a.acc[5] += (float)bad_terms;
+    a.acc[7] += 1.f;
+    if (a.counts) {      // per-step ratios, as get_acc_dense returns them (0/0 = NaN included), summed over the epoch
+      for (int t = 0; t < 3; ++t) {
+        a.acc[8 + 2 * t] += a.counts[6 * t] / a.counts[6 * t + 1];
+        a.acc[9 + 2 * t] += a.counts[6 * t + 2] / a.counts[6 * t + 3];
+      }
+      a.acc[14] += a.counts[4];
+      a.acc[15] += a.counts[5];
+    }
   }
+  if (a.sched_rows) {
+    const unsigned long long c = a.sched_cursor[0];
+    const int64_t* row = a.sched_rows + c * (unsigned long long)a.sched_words;
+    for (int w = threadIdx.x; w < a.sched_words; w += blockDim.x) a.sched_buf[w] = row[w];
+    if (threadIdx.x == 0) a.sched_cursor[0] = c + 1;
+  }
+  if (threadIdx.x == 0 && gridDim.x > 1) a.done[0] = 0u;
 }
 
-extern "C" int nvf_step_tail(float* p, const float* g, float* m, float* v, int64_t n, const float* coef_dev,
-                             float coef0_host, float coef1_host, float beta1, float beta2, float eps, const float* loss_terms, const float* lbits,
-                             const float* nbits, int nnb, const float* g_lat_dev, float lbits_scale, float nbits_scale,
-                             float* acc, void* stream) {
-  if (!p || !g || !m || !v || n <= 0) return NVF_EINVAL;
-  if (acc && (!loss_terms || !lbits || !nbits || nnb <= 0 || nnb > 16)) return NVF_EINVAL;
-  StepStats st{loss_terms, lbits, nbits, g_lat_dev, acc, lbits_scale, nbits_scale, nnb};
-  step_tail_kernel<<<NVF_GRID(n, 256), 256, 0, nvf_stream(stream)>>>(p, g, m, v, (long)n, coef_dev, coef0_host,
-                                                                    coef1_host, beta1, beta2, eps, st);
+extern "C" int nvf_step_tail(const NvfStepTail* args, void* stream) {
+  if (!args) return NVF_EINVAL;
+  const NvfStepTail a = *args;
+  if (!a.p || !a.g || !a.m || !a.v || a.n <= 0) return NVF_EINVAL;
+  if (a.acc && (!a.loss_terms || !a.lbits || !a.nbits || a.nnb <= 0 || a.nnb > 16)) return NVF_EINVAL;
+  if (a.sched_rows && (!a.sched_buf || !a.sched_cursor || a.sched_words <= 0)) return NVF_EINVAL;
+  if ((a.acc || a.sched_rows) && !a.done) return NVF_EINVAL;
+  step_tail_kernel<<<NVF_GRID(a.n, 256), 256, 0, nvf_stream(stream)>>>(a);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -108,8 +108,8 @@ class TrainEngine:
         self._g_lat_dev = None    # lambda * w1 / n_pts
         self._wg = None
         self.ctx = ops.StepCtx()  # deferred final passes + queued latent tail of the step in flight (caller-owned)
-        self.metrics_acc = None   # float[6] epoch accumulator of tp, ap, tn, an, sse, denom (NVFPCC.py train logging)
-        self.epoch_acc = None     # float[8] epoch sums written by nvf_step_tail (enable_epoch_stats)
+        self.epoch_acc = None     # float[16] epoch sums written by nvf_step_tail (enable_epoch_stats)
+        self._tail_done = torch.zeros(2, dtype=torch.int32, device=self.dev)   # nvf_step_tail's arrival counter
         self.collective_mode = None   # "graph" / "host": where GraphedTrainStep puts the all-reduce (dist.attach)
         # the three classifier heads go through the one-launch kernels (instantiated for the two decoders of BASELINE.json);
         # the one-launch trunk weight gradients exist for the narrow decoder only
@@ -121,7 +121,12 @@ class TrainEngine:
         named = list(self.net.named_parameters())
         total = sum(p.numel() for _, p in named)
         self.flat_p = torch.empty(total, device=self.dev)
-        self.flat_g = torch.zeros(total, device=self.dev)
+        # gradients + 32 floats behind them: [0, 18) = the step's metric counts (ops.metrics3: main output, head 0,
+        # head 1).  They ride in the data-parallel all-reduce of the gradients, so the per-step accuracy RATIOS the
+        # reference logs (NVFPCC.py:214-221) are those of the whole mini-batch whatever the number of ranks
+        self.flat_gx = torch.zeros(total + 32, device=self.dev)
+        self.flat_g = self.flat_gx[:total]
+        self.step_counts = self.flat_gx[total:total + 18]
         self.flat_m = torch.zeros(total, device=self.dev)
         self.flat_v = torch.zeros(total, device=self.dev)
         self.slices = {}
@@ -392,10 +397,12 @@ class TrainEngine:
         if not fused_loss:
             dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
                                                   (a["p1"], gt16, None, 0.85, 0.0)], loss, ctx=ctx)
-        if self.metrics_acc is not None and want_w:
-            # logging sums of NVFPCC.py:190-221 (Pacc / Nacc / sse / denom over the epoch): one partial-sum launch, the
-            # final pass rides in the finals launch and adds into the epoch accumulator
-            ops.metrics(a["p2"], gt, dist, 0.5, 0.6, out=self.metrics_acc, accumulate=True, ctx=ctx)
+        if self.epoch_acc is not None and want_w:
+            # logging counts of NVFPCC.py:174-179, 190-221 (tp / ap / tn / an of the main output and of both heads at 0.5,
+            # sse / denom at 0.6): one partial-sum launch, the final pass rides in the finals launch; nvf_step_tail turns
+            # them into the per-step ratios behind the all-reduce
+            ops.metrics3([a["p2"], a["p0"], a["p1"]], [gt, gt8, gt16], [dist, None, None], 0.5, 0.6,
+                         out=self.step_counts, ctx=ctx)
         ev_t1 = ev_t0 = None
         if self.heads3:
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
@@ -545,48 +552,66 @@ class TrainEngine:
 
     def enable_epoch_stats(self):
         """Device accumulators behind NVFPCC.py train's per-epoch log line (the reference syncs ~14 .item()s per step,
-        NVFPCC.py:190-221): metrics_acc[6] = tp, ap, tn, an, sse, denom; epoch_acc[8] = the three focal terms,
-        b_latent, b_net, non-finite objective terms, non-finite gradient entries, steps (nvf_step_tail)."""
+        NVFPCC.py:190-221): epoch_acc[16] = the three focal terms, b_latent, b_net, non-finite objective terms,
+        non-finite gradient entries, steps, then the per-step ratios Pacc, Nacc, S1Pacc, S1Nacc, S2Pacc, S2Nacc summed
+        over the steps, sse, denom (nvf_step_tail)."""
         if self.epoch_acc is None:
-            self.metrics_acc = torch.zeros(6, device=self.dev)
-            self.epoch_acc = torch.zeros(8, device=self.dev)
+            self.epoch_acc = torch.zeros(16, device=self.dev)
 
-    def read_epoch_stats(self, reset=True, reduce=None):
-        """(metrics[6], sums[8]) as float64 numpy arrays: ONE host sync per epoch (``reduce``: the data-parallel
-        all-reduce applied to the 14 floats first).  Raises on the reference's NaN checks (NVFPCC.py:199-212:
-        'Problem in loss' / 'Problem with grad') instead of opening an IPython shell."""
-        both = torch.cat([self.metrics_acc, self.epoch_acc])
+    def read_epoch_stats(self, reset=True, reduce=None, world=1):
+        """epoch_acc as a float64 numpy array [16]: ONE host sync per epoch.  ``reduce``: the data-parallel SUM
+        all-reduce, applied to the 16 floats first; entries that every rank holds identically (b_net, the step count and
+        the ratios / sse / denom, which nvf_step_tail derives from all-reduced counts) are divided by ``world`` after it.
+        Raises on the reference's NaN checks (NVFPCC.py:199-212: 'Problem in loss' / 'Problem with grad') instead of
+        opening an IPython shell; a non-finite gradient entry never reaches its parameter (nvf_step_tail skips it)."""
+        acc = self.epoch_acc.clone()
         if reduce is not None:
-            reduce(both)
-        both = both.double().cpu().numpy()
+            reduce(acc)
+        acc = acc.double().cpu().numpy()
+        if reduce is not None and world > 1:
+            acc[4] /= world
+            acc[7:16] /= world
         if reset:
-            self.metrics_acc.zero_()
             self.epoch_acc.zero_()
-        if both[6 + 5] > 0:
-            raise ValueError("Problem in loss: %d non-finite objective terms this epoch" % int(both[6 + 5]))
-        if both[6 + 6] > 0:
-            raise ValueError("Problem with grad: %d non-finite gradient entries this epoch" % int(both[6 + 6]))
-        return both[:6], both[6:]
+        if acc[5] > 0:
+            raise ValueError("Problem in loss: %d non-finite objective terms this epoch" % int(acc[5]))
+        if acc[6] > 0:
+            raise ValueError("Problem with grad: %d non-finite gradient entries this epoch" % int(acc[6]))
+        return acc
+
+    def train_log_fields(self, acc, nsteps):
+        """The 16 numbers of the reference's TRAIN line after 'seconds]' (NVFPCC.py:261-281), from read_epoch_stats:
+        Loss, PosiPenal, PosiGain, Pacc, Nacc, S1 Loss, S2 Loss, S1Pacc, S1Nacc, S2Pacc, S2Nacc, bpp, b_latent, b_net,
+        MSE1, PSNR1 -- means over the epoch's mini-batches, MSE1 = sum sse / sum denom (0 / 0 = nan, as there)."""
+        cnt = float(nsteps)
+        ls, bl, bn = acc[0:3] / cnt, acc[3] / cnt, acc[4] / cnt
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mse1 = np.float64(acc[14]) / np.float64(acc[15])
+            psnr1 = 20 * np.log10(1023 / np.sqrt(mse1 / 3))
+        loss = ls.sum() + self.lmbda * (bl * self.w1 + bn * self.w2)
+        return [loss, 0.0, 0.0, acc[8] / cnt, acc[9] / cnt, ls[1], ls[2], acc[10] / cnt, acc[11] / cnt,
+                acc[12] / cnt, acc[13] / cnt, bl + bn, bl, bn, mse1, psnr1]
 
     def _tail(self, n_pts):
         """All-reduce hook (data parallelism), then Adam (+ the epoch sums): nvf_step_tail with host coefficients."""
         if self.grad_hook is not None:
-            self.grad_hook(self.flat_g)
+            self.grad_hook(self.flat_gx)
         self.opt_step += 1
         t = self.last
         stats = self.epoch_acc is not None
         ops.step_tail(self.flat_p, self.flat_g, self.flat_m, self.flat_v, None,
                       ops.adam_coefficients(self.lr, self.opt_step),
                       loss_terms=t["loss_terms"] if stats else None, lbits=t["latent_bits"] if stats else None,
-                      nbits=t["net_bits"] if stats else None, lbits_scale=1.0 / n_pts,
-                      nbits_scale=1.0 / self.n_points_total, acc=self.epoch_acc)
+                      nbits=t["net_bits"] if stats else None, inv_npts_host=1.0 / n_pts,
+                      nbits_scale=1.0 / self.n_points_total, counts=self.step_counts if stats else None,
+                      acc=self.epoch_acc, done=self._tail_done)
 
     def _idle_backward(self):
         """A rank whose share of a short last mini-batch is empty (NVFPCC.py:149 with 917 mod 16 = 5 blocks on 8
         GPUs): no block terms, but its 1/W share of the replicated weight-rate gradient (and of d/d sigma, d/d mu of
         the likelihood model) still goes into the all-reduce, so the summed gradient is the single-GPU one."""
         net, Ls = self.net, self.layers
-        self.flat_g.zero_()
+        self.flat_gx.zero_()
         lm = net.reconstructor.likelihood_model
         nbits = torch.empty(7, device=self.dev)
         g_net = self.lmbda * self.w2 / self.n_points_total
@@ -617,7 +642,7 @@ class TrainEngine:
         if update:
             self._tail(n_pts)
         elif self.grad_hook is not None:
-            self.grad_hook(self.flat_g)
+            self.grad_hook(self.flat_gx)
         return a
 
     def latent_step(self, q, lo=0, hi=None, update=True):
@@ -655,64 +680,74 @@ class TrainEngine:
 class GraphedTrainStep:
     """The whole mini-batch step -- step head, forward, losses, backward, [all-reduce], Adam + epoch sums -- captured
     once into a HIP graph and replayed: removes ~90 host-side launches per step (the reference pays ~1 500 aten
-    dispatches).  Everything that changes from step to step comes from device memory, refreshed by ONE pinned-memory
-    copy: block ids, the noise-step counter, the rate coefficient lambda*w1/n_pts and Adam's two step-dependent
-    coefficients (lr / (1 - b1^t), sqrt(1 - b2^t): nvf_step_tail).
+    dispatches).  Everything that changes from step to step comes from device memory: block ids, the noise-step
+    counter, the rate coefficient lambda*w1/n_pts (and 1/n_pts for the log line) and Adam's two step-dependent
+    coefficients (lr / (1 - b1^t), sqrt(1 - b2^t)) are one ROW of a schedule the host uploads once per epoch
+    (``load_schedule``); the last kernel of step s (nvf_step_tail) copies row s + 1 over the buffer the kernels read, so
+    a replay costs the host one graph launch and the GPU no host-to-device copy.
 
-    Data parallelism: ``collective`` = "host" (default) ends the graph after the backward pass and launches the
-    all-reduce hook and the optimiser node from the host; "graph" (NVF_GRAPH_COLLECTIVE=graph) captures the all-reduce
-    of flat_g inside the graph, so that the hand-over between the compute stream and RCCL's stream becomes a graph
-    edge instead of two event waits per step -- validated on one GPU with a one-rank RCCL group
-    (bench.py --force-collective); left opt-in until it has run on a multi-GPU node."""
+    Data parallelism: ``collective`` = "graph" captures the all-reduce of the gradient buffer as a node of the graph
+    (the hand-over between the compute stream and RCCL's stream is then a graph edge instead of two event waits per
+    step); "host" ends the graph after the backward pass and launches the all-reduce hook and the optimiser node from
+    the host.  dist.attach picks "graph" for RCCL and falls back to "host" in-process if the capture fails."""
 
-    def __init__(self, eng, batch, q, ring=8, collective=None):
+    CAP = 4096       # rows of the device-resident schedule (longer schedules are loaded in pieces)
+
+    def __init__(self, eng, batch, q, ring=2, collective=None):
         self.eng, self.batch, self.q = eng, batch, q
         dev = eng.dev
         if collective is None:
             collective = getattr(eng, "collective_mode", None) or os.environ.get("NVF_GRAPH_COLLECTIVE", "host")
         self.collective = collective if eng.grad_hook is not None else "none"
-        # one device buffer [idx (B x i64) | noise step (u64) | lambda*w1/n_pts (f32 in the low half) | Adam coef (2 x f32)]
-        # refreshed by a single pinned-memory copy per step.  The host may run several steps ahead of the GPU, so the
-        # staging side is a ring of pinned buffers: a slot is rewritten only after the copy that read it has executed.
-        nw = batch + 3
+        # the buffer the step's kernels read: [idx (B x i64) | noise step (u64) | lambda*w1/n_pts, 1/n_pts (2 x f32) |
+        # Adam coefficients (2 x f32)]; sched = [cursor | unused | CAP + 1 rows of the same layout]
+        nw = self.nw = batch + 3
         self.buf = torch.zeros(nw, dtype=torch.int64, device=dev)
-        self.pins = [torch.zeros(nw, dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
+        self.sched = torch.zeros(2 + (self.CAP + 1) * nw, dtype=torch.int64, device=dev)
+        self.cursor, self.rows = self.sched[0:1], self.sched[2:]
+        # staging ring: the host may load the next schedule while the copy of the previous one has not executed yet
+        self.pins = [torch.zeros(self.sched.numel(), dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
         self.pin_events = [None] * len(self.pins)
-        self.calls = 0
+        self.loads = 0
+        self.pending = []            # (n_pts) of the loaded steps not replayed yet
         self.idx = self.buf[:batch]
         self.step = self.buf[batch:batch + 1]
-        self.g_lat = self.buf[batch + 1:batch + 2].view(torch.float32)[0:1]
+        rate = self.buf[batch + 1:batch + 2].view(torch.float32)
+        self.g_lat, self.inv_npts = rate[0:1], rate[1:2]
         self.coef = self.buf[batch + 2:batch + 3].view(torch.float32)
         eng._step_dev, eng._g_lat_dev = self.step, self.g_lat
-        self.pins[0][:batch] = torch.arange(batch) % eng.N_leaf
-        self.pins[0][batch + 1:batch + 2].view(torch.float32)[0] = 1.0
-        self.buf.copy_(self.pins[0])
+        first = torch.zeros(nw, dtype=torch.int64)
+        first[:batch] = torch.arange(batch) % eng.N_leaf
+        first[batch + 1:batch + 2].view(torch.float32)[:] = 1.0
+        self.buf.copy_(first)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        macc = eng.metrics_acc
+        acc = eng.epoch_acc
         try:
             with torch.cuda.stream(side):      # warm-up: allocates the grow-only workspaces outside the graph; the
-                if macc is not None:           # tail (no workspace) is left out, so no state is touched
-                    eng.metrics_acc = torch.zeros_like(macc)
-                for _ in range(2):
+                for _ in range(2):             # tail (no workspace) is left out, so no state is touched
                     self._body(tail=False)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            eng.metrics_acc = macc
             if self.collective == "graph":
-                # RCCL builds its communicator (allocations, IPC handles) on the first collective: that must happen
-                # eagerly -- inside a capture it invalidates the capture, and an invalidated capture cannot be retried
-                # in the same process (measured on MI355X / RCCL 2.26: "operation not permitted when stream is
-                # capturing"), which is why "host" is the default and "graph" an explicit choice
-                with torch.cuda.stream(side):
-                    eng.grad_hook(torch.zeros_like(eng.flat_g))
-                torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._body(tail=self.collective != "host")
+                try:
+                    self._capture(True)
+                except Exception as e:       # noqa: BLE001 -- a failed capture of the collective: host launch instead
+                    import warnings
+                    warnings.warn(f"all-reduce could not be captured into the step graph ({e}); launching it from "
+                                  f"the host behind the graph instead")
+                    torch.cuda.synchronize()
+                    self.collective = eng.collective_mode = "host"
+                    self._capture(False)
+            else:
+                self._capture(self.collective != "host")
         finally:
-            eng.metrics_acc = macc
             eng._step_dev, eng._g_lat_dev = None, None
+
+    def _capture(self, tail):
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body(tail=tail)
 
     def _body(self, tail):
         eng = self.eng
@@ -727,42 +762,65 @@ class GraphedTrainStep:
     def _tail(self):
         eng = self.eng
         if eng.grad_hook is not None:
-            eng.grad_hook(eng.flat_g)
+            eng.grad_hook(eng.flat_gx)
         t = self.last
         stats = eng.epoch_acc is not None
         ops.step_tail(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, self.coef,
                       loss_terms=t["loss_terms"] if stats else None, lbits=t["latent_bits"] if stats else None,
-                      nbits=t["net_bits"] if stats else None, g_lat_dev=self.g_lat,
-                      lbits_scale=1.0 / (eng.lmbda * eng.w1), nbits_scale=1.0 / eng.n_points_total, acc=eng.epoch_acc)
+                      nbits=t["net_bits"] if stats else None, inv_npts_dev=self.inv_npts,
+                      nbits_scale=1.0 / eng.n_points_total, counts=eng.step_counts if stats else None,
+                      acc=eng.epoch_acc, done=eng._tail_done, sched=(self.buf, self.rows, self.cursor, self.nw))
 
-    def __call__(self, idx_host, n_pts=None):
-        eng = self.eng
-        idx_host = np.asarray(idx_host, np.int64)
-        assert idx_host.shape[0] == self.batch
-        eng.noise_step += 1
-        eng.opt_step += 1
-        if n_pts is None:
-            n_pts = float(eng.counts[idx_host].sum())
-        slot = self.calls % len(self.pins)
-        self.calls += 1
+    def load_schedule(self, steps):
+        """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
+        CAP).  One host-to-device copy for all of them; Adam / noise counters continue from the engine's."""
+        eng, B, nw = self.eng, self.batch, self.nw
+        n = len(steps)
+        assert 0 < n <= self.CAP and not self.pending
+        slot = self.loads % len(self.pins)
+        self.loads += 1
         if self.pin_events[slot] is not None:
-            self.pin_events[slot].synchronize()      # blocks only when the host is a whole ring ahead of the GPU
+            self.pin_events[slot].synchronize()
         pin = self.pins[slot]
-        pin[:self.batch] = torch.from_numpy(idx_host)
-        pin[self.batch] = eng.noise_step
-        pin[self.batch + 1:self.batch + 2].view(torch.float32)[0] = eng.lmbda * eng.w1 / n_pts
-        c = pin[self.batch + 2:self.batch + 3].view(torch.float32)
-        c[0], c[1] = ops.adam_coefficients(eng.lr, eng.opt_step)
-        self.buf.copy_(pin, non_blocking=True)
+        rows = pin[2:2 + (n + 1) * nw].view(n + 1, nw)
+        f32 = rows.view(torch.float32)            # [n + 1, 2 nw]
+        for k, (ids, n_pts) in enumerate(steps):
+            ids = np.asarray(ids, np.int64)
+            assert ids.shape[0] == B
+            if n_pts is None:
+                n_pts = float(eng.counts[ids].sum())
+            rows[k, :B] = torch.from_numpy(ids)
+            rows[k, B] = eng.noise_step + 1 + k
+            f32[k, 2 * (B + 1)] = eng.lmbda * eng.w1 / n_pts
+            f32[k, 2 * (B + 1) + 1] = 1.0 / n_pts
+            f32[k, 2 * (B + 2)], f32[k, 2 * (B + 2) + 1] = ops.adam_coefficients(eng.lr, eng.opt_step + 1 + k)
+            self.pending.append(float(n_pts))
+        rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
+        pin[0], pin[1] = 1, 0                     # cursor: the tail of the first step fetches row 1
+        m = 2 + (n + 1) * nw
+        self.sched[:m].copy_(pin[:m], non_blocking=True)
+        self.buf.copy_(pin[2:2 + nw], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pin_events[slot] = ev
+
+    def replay(self):
+        """Run the next loaded step."""
+        eng = self.eng
+        n_pts = self.pending.pop(0)
+        eng.noise_step += 1
+        eng.opt_step += 1
         self.graph.replay()
         eng.last = dict(self.last)
         eng.last["n_pts"] = n_pts
         if self.collective == "host":
             self._tail()
         return self.out
+
+    def __call__(self, idx_host, n_pts=None):
+        """One step with its own one-row schedule (tests; the training loop loads an epoch at a time)."""
+        self.load_schedule([(idx_host, n_pts)])
+        return self.replay()
 
 
 class EpochDriver:
@@ -782,15 +840,27 @@ class EpochDriver:
         eng, B = self.eng, self.batch
         n = len(order)
         nsteps = (n + B - 1) // B
+        plan = []
         for s in range(nsteps):
             ids, whole = self.nd.shard_minibatch(order, s, B, self.rank, self.world)
             n_pts = float(eng.counts[whole].sum())
-            if self.use_graph and len(whole) == B and len(ids) > 0:
-                key = (len(ids), q)
-                g = self.graphs.get(key)
-                if g is None:
-                    g = self.graphs[key] = GraphedTrainStep(eng, len(ids), q)
-                g(ids, n_pts=n_pts)
-            else:
+            plan.append((ids, n_pts, self.use_graph and len(whole) == B and len(ids) > 0))
+        s = 0
+        while s < nsteps:
+            ids, n_pts, graphed = plan[s]
+            if not graphed:
                 eng.train_step(ids, q, n_pts=n_pts)
+                s += 1
+                continue
+            key = (len(ids), q)
+            g = self.graphs.get(key)
+            if g is None:
+                g = self.graphs[key] = GraphedTrainStep(eng, len(ids), q)
+            e = s                                       # the run of graph-replayed steps starting here: one upload
+            while e < nsteps and plan[e][2] and len(plan[e][0]) == len(ids) and e - s < g.CAP:
+                e += 1
+            g.load_schedule([(plan[k][0], plan[k][1]) for k in range(s, e)])
+            for _ in range(s, e):
+                g.replay()
+            s = e
         return nsteps

@@ -62,6 +62,7 @@ class StepCtx:
         addr = ctypes.addressof(self._mem)
         self.ptr = (addr + 15) // 16 * 16
         self._ws = {}      # workspaces of the passes deferred in this context: their partial sums wait for flush()
+        self._retired = []  # outgrown workspaces (see workspace())
         check(lib().nvf_step_ctx_init(self.ptr), "nvf_step_ctx_init")
 
     def begin(self):
@@ -86,6 +87,7 @@ def _ctx(ctx):
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def workspace(nbytes, device, tag="ws", ctx=None):
@@ -95,6 +97,10 @@ def workspace(nbytes, device, tag="ws", ctx=None):
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
     buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # an outgrown buffer stays alive: a captured HIP graph (engine.GraphedTrainStep) or a kernel in flight on
+            # another stream may still hold its address
+            (_ws_retired if ctx is None else ctx._retired).append(buf)
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
         cache[key] = buf
     return buf
@@ -787,9 +793,25 @@ def metrics(p, gt, dist, thh_acc, thh_sse, out=None, accumulate=False, ctx=None)
     (an open StepCtx.begin) the final pass joins the deferred ones: ``out`` exists after ctx.flush()."""
     _f32(p, gt, dist, out)
     o = out if out is not None else torch.empty(6, device=p.device)
-    ws = workspace(lib().nvf_reduce_workspace(), p.device, "metrics", ctx)   # its own buffer: partials may wait for a flush
+    ws = workspace(lib().nvf_metrics_workspace(), p.device, "metrics", ctx)   # its own buffer: partials may wait for a flush
     check(lib().nvf_metrics(_ptr(p), _ptr(gt), _ptr(dist), float(thh_acc), float(thh_sse), _ptr(o), _ptr(ws),
                             ws.numel(), p.numel(), int(accumulate), _ctx(ctx), _stream()), "nvf_metrics")
+    return o
+
+
+def metrics3(ps, gts, dists, thh_acc, thh_sse, out=None, ctx=None):
+    """The six sums of ``metrics`` for up to three (p, gt[, dist]) pairs in ONE launch: out[6 t + k] (overwritten) --
+    the main output and the two coarse heads of NVFPCC.py's log lines (:174-179, 214-221)."""
+    import ctypes
+    n = len(ps)
+    dists = list(dists) if dists is not None else [None] * n
+    _f32(*ps, *gts, *[d for d in dists if d is not None], out)
+    o = out if out is not None else torch.empty(6 * n, device=ps[0].device)
+    ws = workspace(lib().nvf_metrics_workspace(), ps[0].device, "metrics", ctx)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    check(lib().nvf_metrics3(arr(ps), arr(gts), arr(dists), (ctypes.c_int64 * n)(*[p.numel() for p in ps]), n,
+                             float(thh_acc), float(thh_sse), _ptr(o), _ptr(ws), ws.numel(), _ctx(ctx), _stream()),
+          "nvf_metrics3")
     return o
 
 
@@ -840,15 +862,31 @@ def adam_coefficients(lr, step, beta1=0.9, beta2=0.999):
     return float(c[0]), float(c[1])
 
 
-def step_tail(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, lbits=None, nbits=None, g_lat_dev=None, lbits_scale=1.0,
-              nbits_scale=1.0, acc=None, beta1=0.9, beta2=0.999, eps=1e-8):
-    """Adam with its two step-dependent scalars in device memory (graph-capturable) + the epoch's running sums and
-    non-finite counters in ``acc`` [8] (see nvf_step_tail in include/nvf_hip.h)."""
-    _f32(p, g, m, v, coef_dev, loss_terms, lbits, nbits, g_lat_dev, acc)
-    check(lib().nvf_step_tail(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(coef_dev), float(coef_host[0]),
-                              float(coef_host[1]), float(beta1), float(beta2), float(eps), _ptr(loss_terms), _ptr(lbits), _ptr(nbits),
-                              0 if nbits is None else nbits.numel(), _ptr(g_lat_dev), float(lbits_scale),
-                              float(nbits_scale), _ptr(acc), _stream()), "nvf_step_tail")
+def step_tail(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, lbits=None, nbits=None,
+              inv_npts_dev=None, inv_npts_host=1.0, nbits_scale=1.0, counts=None, acc=None, done=None, sched=None,
+              beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam with its two step-dependent scalars in device memory (graph-capturable), the epoch's running sums and
+    non-finite counters in ``acc`` [16], and the hand-over to the next step of a device-resident schedule
+    (``sched`` = (buf, rows, cursor, words); see NvfStepTail in include/nvf_hip.h)."""
+    import ctypes
+    from ._lib import NvfStepTail
+    _f32(p, g, m, v, coef_dev, loss_terms, lbits, nbits, inv_npts_dev, counts, acc)
+    a = NvfStepTail()
+    a.p, a.g, a.m, a.v, a.n = _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel()
+    a.coef_dev, a.coef0_host, a.coef1_host = _ptr(coef_dev), float(coef_host[0]), float(coef_host[1])
+    a.beta1, a.beta2, a.eps = float(beta1), float(beta2), float(eps)
+    a.nnb = 0 if nbits is None else nbits.numel()
+    a.loss_terms, a.lbits, a.nbits = _ptr(loss_terms), _ptr(lbits), _ptr(nbits)
+    a.inv_npts_dev, a.inv_npts_host, a.nbits_scale = _ptr(inv_npts_dev), float(inv_npts_host), float(nbits_scale)
+    a.counts, a.acc = _ptr(counts), _ptr(acc)
+    if done is not None:
+        _chk(done)
+        a.done = done.data_ptr()
+    if sched is not None:
+        buf, rows, cursor, words = sched
+        _chk(buf, rows, cursor)
+        a.sched_buf, a.sched_rows, a.sched_cursor, a.sched_words = buf.data_ptr(), rows.data_ptr(), cursor.data_ptr(), int(words)
+    check(lib().nvf_step_tail(ctypes.byref(a), _stream()), "nvf_step_tail")
 
 
 def gather_rows(src, idx):

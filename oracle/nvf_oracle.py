@@ -379,30 +379,50 @@ def lr_at_epoch(base_lr, epoch):
 
 
 class OracleTrainer:
-    """CPU restatement of one mini-batch step and one latent step (NVFPCC.py:149-250)."""
+    """CPU restatement of train()'s optimisation loop (NVFPCC.py:105-254): one mini-batch step (:149-223), one latent
+    step per epoch (:225-251), the learning-rate schedule (:117,126,253-254).  Pinned by tests/golden/trajectory.npz
+    (tests/test_oracle_golden.py).  ``noise_fn(step, ids, q) -> (u_latent, u_w)`` replaces torch.rand_like (``step``
+    counts train-mode forwards from 1); None draws from torch's global RNG as the reference does."""
 
     def __init__(self, ch, channels, seed, n_leaf, n_points, lr=1e-3, wemb=5.0,
-                 lmbda=200.0, w1=10.0, w2=57.0):
+                 lmbda=200.0, w1=10.0, w2=57.0, noise_fn=None):
         self.P, _ = build_state(ch, channels, seed)
         self.keys = trainable_keys(self.P)
         for k in self.keys:
             self.P[k].requires_grad_(True)
         self.emb = torch.ones(n_leaf, ch, 2, 2, 2, requires_grad=True)   # NVFPCC.py:120-123
+        self.base_lr = lr
         self.opt = torch.optim.Adam([self.P[k] for k in self.keys], lr=lr)
         self.opt_emb = torch.optim.Adam([self.emb], lr=lr * wemb)
         self.n_points = n_points
         self.h = dict(lmbda=lmbda, w1=w1, w2=w2)
+        self.noise_fn = noise_fn
+        self.forwards = 0
+
+    def set_epoch(self, epoch):
+        """What sch.step() + sch_emb.step() have done to the decoder LR by the start of ``epoch``."""
+        for grp in self.opt.param_groups:
+            grp["lr"] = lr_at_epoch(self.base_lr, epoch)
+
+    def _noise(self, ids, q):
+        self.forwards += 1
+        if self.noise_fn is None:
+            return {}
+        u_latent, u_w = self.noise_fn(self.forwards, ids, q)
+        return dict(u_latent=u_latent, u_w=u_w)
 
     def train_step(self, idx, gt, dist, q=1):
         self.opt.zero_grad()
-        loss, *_ = rd_loss(self.P, self.emb[idx], gt, dist, self.n_points, mode="train", q=q, **self.h)
+        loss, *_ = rd_loss(self.P, self.emb[idx], gt, dist, self.n_points, mode="train", q=q, **self.h,
+                           **self._noise(idx, q))
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     def latent_step(self, gt, dist, q=1):
         self.opt_emb.zero_grad()
-        loss, *_ = rd_loss(self.P, self.emb, gt, dist, self.n_points, mode="train", q=q, **self.h)
+        loss, *_ = rd_loss(self.P, self.emb, gt, dist, self.n_points, mode="train", q=q, **self.h,
+                           **self._noise(range(self.emb.shape[0]), q))
         loss.backward()
         self.opt_emb.step()
-        return float(loss)
+        return float(loss.detach())

@@ -50,10 +50,7 @@ def main():
         else:
             eng.noise_step += 1
         nd.allgather_rows_(eng.emb, rank, world)
-        m, sums = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None)
-        sums[4] /= world
-        sums[7] /= world
-        stats.append(np.concatenate([m, sums]))
+        stats.append(eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None, world=world))
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({"flat_p": eng.flat_p.cpu(), "emb": eng.emb.cpu(), "stats": np.stack(stats), "grads": grads,

@@ -14,6 +14,16 @@ CONFIGS = {
 HYPER = dict(lmbda=200.0, w1=10.0, w2=57.0, lr=1e-3, wemb=5.0, n_points=917 * 936.0)
 
 
+# Training trajectory (tools/gen_golden.py:gen_trajectory): NVFPCC.py:105-254 run for 3 epochs on 14 blocks at
+# batch 4 (three full mini-batches + a short one per epoch), q = 1 in epoch 0, q = 2 from --phase_change = 1
+TRAJ = dict(tag="S", n_blocks=14, batch=4, epochs=3, phase_change=1, noise_seed=5, order_seed=909)
+
+
+def traj_order(epoch):
+    """Block ids in the order epoch `epoch` visits them (what the DataLoader + dataset permutation would yield)."""
+    return np.random.default_rng(TRAJ["order_seed"] + epoch).permutation(TRAJ["n_blocks"]).astype(np.int64)
+
+
 def perturb_state_(sd, seed):
     """Move every trainable tensor off its trivial initial value, in state-dict order."""
     g = torch.Generator().manual_seed(seed)

@@ -67,10 +67,12 @@ def test_two_ranks_through_a_real_collective_equal_one_rank(tmp_path):
     de = (one["emb"] - two["emb"]).abs()
     assert (dp > 1e-6).float().mean().item() < 1e-3 and dp.max().item() < 6 * 2e-3, (dp.max().item(), (dp > 1e-6).sum())
     assert de.max().item() < 1e-5, de.max().item()
-    np.testing.assert_array_equal(one["stats"][:, [1, 3]], two["stats"][:, [1, 3]])  # occupied / empty voxel counts
-    assert np.abs(one["stats"][:, [0, 2]] - two["stats"][:, [0, 2]]).max() <= 5       # tp, tn: p within 1e-6 of 0.5
-    np.testing.assert_allclose(one["stats"][:, 4:11], two["stats"][:, 4:11], rtol=2e-4)
-    assert (two["stats"][:, 13] == 3).all() and (two["stats"][:, 11:13] == 0).all()
+    # the epoch's log sums (engine.read_epoch_stats): focal terms, b_latent, b_net; the per-step accuracy RATIOS are
+    # those of the whole mini-batch on both worlds, because the counts ride in the all-reduce of the gradients
+    np.testing.assert_allclose(one["stats"][:, 0:5], two["stats"][:, 0:5], rtol=2e-4)
+    np.testing.assert_allclose(one["stats"][:, 8:14], two["stats"][:, 8:14], atol=2e-3)   # a few voxels at p = 0.5
+    np.testing.assert_allclose(one["stats"][:, 14:16], two["stats"][:, 14:16], rtol=2e-3, atol=2.0)
+    assert (two["stats"][:, 7] == 3).all() and (two["stats"][:, 5:7] == 0).all()
 
 
 @pytest.mark.timeout(600)

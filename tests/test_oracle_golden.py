@@ -247,3 +247,64 @@ def test_adam_restatement_matches_torch():
         opt.step()
         O.adam_update(p, grad, m, v, step, 1e-3)
     close(p, p_ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+# ---- the training trajectory: pins OracleTrainer (the object bench.py's cpu_baseline times) ---------------------------
+def traj_noise_fn(ch):
+    from tests import philox_np
+    from tests.golden_inputs import TRAJ
+
+    def fn(step, ids, q):
+        u_lat = torch.from_numpy(philox_np.latent_noise(TRAJ["noise_seed"], step, list(ids), ch))
+        u_w = {}
+        if q == 1:
+            shapes = {n: s for (n, _, s, _) in [(t[0].split(".")[-1], t[1], t[2], t[3])
+                                                for t in O.layer_table(ch, CONFIGS[TRAJ["tag"]]["channels"])]}
+            u_w = {n: torch.from_numpy(philox_np.weight_noise(TRAJ["noise_seed"], step, i + 1, shapes[n]))
+                   for i, n in enumerate(TRUNK_ORDER)}
+        return u_lat, u_w
+    return fn
+
+
+def traj_compare_params(G, prefix, get, rtol_abs):
+    """get(key) -> CPU tensor; golden holds small tensors whole, large ones as summary(256).  Returns the worst
+    |difference| / max|golden| over all tensors."""
+    worst = 0.0
+    for name in [k[len(prefix):] for k in G.files if k.startswith(prefix)]:
+        want = G[prefix + name]
+        t = get(name)
+        got = t.detach().double().reshape(-1).numpy() if t.numel() <= 1024 else summary(t, 256)
+        want = np.asarray(want, np.float64).reshape(-1)
+        scale = max(np.abs(want).max(), 1e-3)
+        err = np.abs(got - want).max() / scale
+        assert err <= rtol_abs, (name, err)
+        worst = max(worst, err)
+    return worst
+
+
+def test_oracle_trainer_reproduces_the_reference_trajectory(golden_dir):
+    """NVFPCC.py:105-254 for three epochs (q = 1, then q = 2 twice) on 14 blocks at batch 4: Adam moment accumulation
+    across steps, the zero_grad / backward / step order of both optimisers, the latent phase on the post-mini-batch
+    decoder, all with the reference's own loop as the generator (tools/gen_golden.py:gen_trajectory)."""
+    from tests.golden_inputs import TRAJ, traj_order
+    G = np.load(os.path.join(golden_dir, "trajectory.npz"))
+    cfg = CONFIGS[TRAJ["tag"]]
+    n, B = TRAJ["n_blocks"], TRAJ["batch"]
+    gts, dists = make_blocks(n)
+    gt, dist = torch.from_numpy(gts).float(), torch.from_numpy(dists).float()
+    assert float(gts.sum()) == float(G["n_points"])
+    torch.set_num_threads(8)
+    tr = O.OracleTrainer(cfg["ch"], cfg["channels"], synthetic_seed(), n_leaf=n, n_points=float(gts.sum()),
+                         lr=HYPER["lr"], wemb=HYPER["wemb"], lmbda=HYPER["lmbda"], w1=HYPER["w1"], w2=HYPER["w2"],
+                         noise_fn=traj_noise_fn(cfg["ch"]))
+    for epoch in range(TRAJ["epochs"]):
+        q = 1 if epoch < TRAJ["phase_change"] else 2
+        tr.set_epoch(epoch)
+        order = traj_order(epoch)
+        assert np.array_equal(order, G[f"epoch{epoch}/order"])
+        losses = [tr.train_step(torch.from_numpy(order[s:s + B]), gt[order[s:s + B]], dist[order[s:s + B]], q)
+                  for s in range(0, n, B)]
+        close(np.array(losses), G[f"epoch{epoch}/step_loss"], rtol=2e-6)
+        close(tr.latent_step(gt, dist, q), G[f"epoch{epoch}/latent_loss"], rtol=2e-6)
+        close(tr.emb, G[f"epoch{epoch}/emb"], rtol=1e-5, atol=2e-6)
+        traj_compare_params(G, f"epoch{epoch}/param/", lambda k: tr.P[k], 2e-5)

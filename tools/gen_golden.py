@@ -26,7 +26,9 @@ sys.path.insert(0, ROOT)
 
 from nvfpcc_amd.seeds import synthetic_seed          # noqa: E402
 from nvfpcc_amd.synth import make_blocks             # noqa: E402
-from tests.golden_inputs import (CONFIGS, HYPER, perturb_state_, make_emb, noise_stream,   # noqa: E402
+from tests import philox_np                           # noqa: E402
+from tests.golden_inputs import (TRAJ, traj_order,    # noqa: E402
+                                 CONFIGS, HYPER, perturb_state_, make_emb, noise_stream,   # noqa: E402
                                  sample_index, loss_case_inputs, gdn_case_inputs)
 
 
@@ -177,6 +179,108 @@ def gen_net_cases(net_mod, loss_mod, tag):
     print(tag, "seed_used", net.seed_used, "loss", g["grad_q2/loss"], g["train_q1/loss"])
 
 
+def gen_trajectory(net_mod, loss_mod):
+    """The reference's train() loop itself (NVFPCC.py:105-254), statement for statement where it touches the
+    optimisers, on 14 synthetic blocks: fresh Net, emb = ones, Adam + both MultiStepLR objects wired as :116-126,
+    zero_grad / backward / step order of :150-222 and :226-250, the latent phase on the post-mini-batch decoder, the
+    per-epoch log sums of :256-281.  torch.rand_like is replaced by the counter RNG of the HIP engine (tests/philox_np),
+    keyed exactly as the engine keys it (one noise step per train-mode forward), so that the engine -- which cannot be
+    fed foreign noise -- can be held to this trajectory directly."""
+    cfg = CONFIGS[TRAJ["tag"]]
+    ch, channels = cfg["ch"], cfg["channels"]
+    n, B = TRAJ["n_blocks"], TRAJ["batch"]
+    net = RefNet(net_mod, ch, channels)
+    gts, dists = make_blocks(n)
+    gt_all, dist_all = torch.from_numpy(gts).float(), torch.from_numpy(dists).float()
+    N = float(gts.sum())                                   # train_data.N (dataloader.py:160)
+    lmbda, w1, w2, lr, wemb = (HYPER[k] for k in ("lmbda", "w1", "w2", "lr", "wemb"))
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, [300, 400, 450], 0.1)
+    emb = torch.ones((n, ch, 2, 2, 2), dtype=torch.float32).requires_grad_(True)
+    opt_emb = torch.optim.Adam([emb], lr=lr * wemb)
+    sch_emb = torch.optim.lr_scheduler.MultiStepLR(opt, [300, 400, 450], 0.1)
+    pool = torch.nn.MaxPool3d(2, 2)
+    ms = lambda x: [pool(pool(x)), pool(x), x]
+    noise = {"step": 0, "ids": None, "call": 0}
+
+    def rand_like(t, *a, **k):
+        c = noise["call"]
+        noise["call"] += 1
+        if c == 0:       # QuantGaussianLikelihood.forward (network.py:4516)
+            return torch.from_numpy(philox_np.latent_noise(TRAJ["noise_seed"], noise["step"], noise["ids"], ch))
+        return torch.from_numpy(philox_np.weight_noise(TRAJ["noise_seed"], noise["step"], c, tuple(t.shape)))
+
+    def forward(ids, q):
+        noise["step"] += 1
+        noise["ids"], noise["call"] = list(ids), 0
+        out = net(emb[torch.as_tensor(ids)], "train", q)
+        assert noise["call"] == (8 if q == 1 else 1), noise["call"]
+        return out
+
+    g = {"n_points": np.float64(N)}
+    real_rand_like = torch.rand_like
+    torch.rand_like = rand_like
+    try:
+        for epoch in range(TRAJ["epochs"]):
+            q = 1 if epoch < TRAJ["phase_change"] else 2
+            order = traj_order(epoch)
+            rows, sse_l, den_l, losses = [], [], [], []
+            for s in range(0, n, B):
+                ids = order[s:s + B]
+                opt.zero_grad()
+                x, dist = gt_all[ids], dist_all[ids]
+                n_pts = x.sum()
+                gl = ms(x)
+                out, cls, nbits, lbits, _, _ = forward(ids, q)
+                b_latent = lbits.sum() / n_pts
+                b_net = nbits.sum() / N
+                f = [loss_mod.get_focal_dense(cls[0], gl[0], alpha=0.85), loss_mod.get_focal_dense(cls[1], gl[1], alpha=0.85)]
+                acc = [loss_mod.get_acc_dense(cls[0], gl[0], thh=0.5), loss_mod.get_acc_dense(cls[1], gl[1], thh=0.5)]
+                bce = loss_mod.get_surf_focal_dense(out, x, dist, beta=1, alpha=0.9)
+                sse, den = loss_mod.get_sse1(out, x, dist, 0.6)
+                loss = bce + f[0] + f[1] + lmbda * (b_latent * w1 + b_net * w2)
+                loss.backward()
+                pacc, nacc = loss_mod.get_acc_dense(out, x)
+                rows.append([loss.item(), pacc.item(), nacc.item(), f[0].item(), f[1].item(), acc[0][0].item(),
+                             acc[0][1].item(), acc[1][0].item(), acc[1][1].item(), (b_latent + b_net).item(),
+                             b_latent.item(), b_net.item()])
+                sse_l.append(sse.item())
+                den_l.append(den.item())
+                opt.step()
+            # latent update (NVFPCC.py:225-251)
+            opt_emb.zero_grad()
+            gl = ms(gt_all)
+            out, cls, nbits, lbits, _, _ = forward(np.arange(n), q)
+            b_latent = lbits.sum() / gt_all.sum()
+            b_net = nbits.sum() / N
+            loss = (loss_mod.get_surf_focal_dense(out, gt_all, dist_all, beta=1, alpha=0.9)
+                    + loss_mod.get_focal_dense(cls[0], gl[0], alpha=0.85) + loss_mod.get_focal_dense(cls[1], gl[1], alpha=0.85)
+                    + lmbda * (b_latent * w1 + b_net * w2))
+            loss.backward()
+            opt_emb.step()
+            sch_emb.step()
+            sch.step()
+            r = np.array(rows)
+            mse1 = np.sum(sse_l) / np.sum(den_l)
+            p = f"epoch{epoch}/"
+            g[p + "order"] = order
+            g[p + "step_loss"] = r[:, 0]
+            g[p + "latent_loss"] = np.float64(loss.item())
+            # the numbers of the TRAIN log line in its order (NVFPCC.py:261-281) after "seconds]": Loss, PosiPenal,
+            # PosiGain, Pacc, Nacc, S1 Loss, S2 Loss, S1Pacc, S1Nacc, S2Pacc, S2Nacc, bpp, b_latent, b_net, MSE1, PSNR1
+            cnt = len(rows)
+            g[p + "log"] = np.concatenate([[r[:, 0].sum() / cnt, 0.0, 0.0], r[:, 1:].sum(0) / cnt,
+                                           [mse1, 20 * np.log10(1023 / np.sqrt(mse1 / 3))]])
+            g[p + "emb"] = emb.detach().numpy().copy()
+            for k, p_ in net.named_parameters():
+                g[p + "param/" + k] = p_.detach().numpy().copy() if p_.numel() <= 1024 else summary(p_, 256)
+            print("trajectory epoch", epoch, "q", q, "losses", r[:, 0], "latent", loss.item())
+    finally:
+        torch.rand_like = real_rand_like
+    g["lr_after"] = np.float64(opt.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(OUT, "trajectory.npz"), **g)
+
+
 def gen_loss_cases(loss_mod):
     g = {}
     for name, (p, gt, dist) in loss_case_inputs().items():
@@ -241,6 +345,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     net_mod, loss_mod, gdn_mod = import_reference()
+    if "--trajectory" in sys.argv:
+        return gen_trajectory(net_mod, loss_mod)
+    gen_trajectory(net_mod, loss_mod)
     for tag in CONFIGS:
         gen_net_cases(net_mod, loss_mod, tag)
     gen_loss_cases(loss_mod)
