@@ -61,7 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each (value = the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic")
-    ap.add_argument("--sweep", action="store_true", help="also time batch 256 and the full-batch latent step")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip the `sweep` object (batch 256 per GPU, full-batch latent step, 4096-block latent step + eval)")
+    ap.add_argument("--sweep-blocks", type=int, default=4096, help="blocks of the sweep's big latent step / eval (all ranks together)")
+    ap.add_argument("--pmc-mark", default="", help=argparse.SUPPRESS)
     ap.add_argument("--naive", action="store_true", help="debug: one-thread-per-output kernels")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying a captured HIP graph")
     ap.add_argument("--force-collective", action="store_true",
@@ -115,10 +118,16 @@ class KernelProbe:
 
     def wrap(self, ops, fn_name, label, match):
         import torch
+        from nvfpcc_amd import ops as ops_mod
         orig = getattr(ops, fn_name)
         probe = self
 
         def wrapped(*a, **k):
+            if probe.mark == label and match(*a, **k):
+                # PMC child pass: a marker dispatch (uniform_kernel over MARK_N floats) right in front of the probed
+                # launch, so the parent finds it in the counter CSV by position, whatever the kernel is called
+                ops_mod.uniform((probe.MARK_N,), a[0].device, 0, 0)      # tensors and WgradBatch both have .device
+                return orig(*a, **k)
             if probe.enabled and match(*a, **k):
                 wb = a[0] if hasattr(a[0], "jobs") and hasattr(a[0], "offset") else None   # WgradBatch method
                 state = (wb.offset, len(wb.jobs)) if wb is not None else None
@@ -137,6 +146,8 @@ class KernelProbe:
         setattr(ops, fn_name, wrapped)
 
     enabled = False
+    mark = None
+    MARK_N = 7717          # grid of the marker dispatch: ceil(7717 / 256) workgroups of 256
 
     def summary(self):
         import numpy as np
@@ -144,8 +155,10 @@ class KernelProbe:
                 for k, v in self.events.items()}  # us per launch
 
 
-def cpu_baseline(args, seconds=15.0):
-    """The oracle (CPU restatement of the reference's step) on this box's host cores: bounded sample."""
+def cpu_baseline(args, seconds=18.0, samples=3):
+    """The oracle (CPU restatement of the reference's step; tests/golden/trajectory.npz pins OracleTrainer to the
+    reference's own loop) on this box's host cores: a bounded sample, reported as the median of `samples` timed runs
+    with their spread."""
     import torch
     from oracle import nvf_oracle as O
     from nvfpcc_amd.seeds import synthetic_seed
@@ -162,29 +175,35 @@ def cpu_baseline(args, seconds=15.0):
     tr = O.OracleTrainer(args.ch, channels, synthetic_seed(), n_leaf=B, n_points=float(gt.sum()), lr=1e-3, wemb=5.0)
     idx = torch.arange(B)
     # the step is ~1 500 small aten ops: more threads is not faster, so calibrate the thread count first
-    # (2 steps each) and then time the best setting -- the baseline is the CPU at its best, not at its widest
+    # (3 steps each) and then time the best setting -- the baseline is the CPU at its best, not at its widest
     best, best_t = None, 1e30
     for threads in sorted({t for t in (8, 16, 32, 64, cores // 2, cores) if 1 <= t <= cores}):
         torch.set_num_threads(threads)
         tr.train_step(idx, gt, dist, q=1)   # warm-up (oneDNN primitive creation)
         t0 = time.time()
-        for _ in range(2):
+        for _ in range(3):
             tr.train_step(idx, gt, dist, q=1)
-        t = (time.time() - t0) / 2
+        t = (time.time() - t0) / 3
         if t < best_t:
             best, best_t = threads, t
     torch.set_num_threads(best)
     tr.train_step(idx, gt, dist, q=1)
-    t0 = time.time()
-    n = 0
-    while time.time() - t0 < seconds or n < 3:
-        tr.train_step(idx, gt, dist, q=1)
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(n * B / dt, 2), "unit": "blocks/s", "cores": best, "kind": "port",
-            "sample": f"{n} train steps of batch {B} (oracle/nvf_oracle.py OracleTrainer = the reference's aten CPU ops, "
-                      f"torch {torch.__version__}, best of 8/16/32/64/{cores // 2}/{cores} threads = {best}, {dt:.1f} s; "
-                      f"host has {cores} logical CPUs)"}
+    rates, total_n, total_t = [], 0, 0.0
+    for _ in range(samples):
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < seconds / samples or n < 3:
+            tr.train_step(idx, gt, dist, q=1)
+            n += 1
+        dt = time.time() - t0
+        rates.append(n * B / dt)
+        total_n, total_t = total_n + n, total_t + dt
+    return {"value": round(statistics.median(rates), 2), "unit": "blocks/s", "cores": best, "kind": "port",
+            "min": round(min(rates), 2), "max": round(max(rates), 2), "samples": [round(r, 2) for r in rates],
+            "sample": f"median of {samples} runs, {total_n} train steps of batch {B} in all (oracle/nvf_oracle.py "
+                      f"OracleTrainer = the reference's aten CPU ops, pinned to the reference's own loop by "
+                      f"tests/golden/trajectory.npz; torch {torch.__version__}, best of 8/16/32/64/{cores // 2}/{cores} "
+                      f"threads = {best}, {total_t:.1f} s; host has {cores} logical CPUs)"}
 
 
 def kernel_source_hash():
@@ -195,46 +214,54 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def measure_traffic(args, kernel_substr):
-    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (host-launched steps,
-    so every dispatch carries its kernel name) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two
-    do not fit one pass), medians per dispatch, FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B:
-    MI355X_MICROARCH.md, HBM section).  Returns (bytes or None, note)."""
+def measure_traffic(args, label):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (host-launched steps)
+    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two do not fit one pass), medians per dispatch,
+    FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM section).  The child puts a
+    marker dispatch (KernelProbe.mark) in front of every launch behind `label`; the launch is the row after the marker
+    in dispatch order, so nothing here depends on how the kernel or its template arguments are spelled.
+    Returns (bytes or None, note, kernel name or None)."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.isfile(rocprof):
-        return None, "rocprofv3 not found"
-    vals = {}
+        return None, "rocprofv3 not found", None
+    vals, name = {}, None
     base = tempfile.mkdtemp(prefix="nvf_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    mark_grid = (KernelProbe.MARK_N + 255) // 256 * 256
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(base, counter)
         cmd = [rocprof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-               "python3", os.path.abspath(__file__), "--pmc-child", "--no-cpu-baseline", "--no-pmc", "--no-graph",
-               "--steps", "6", "--warmup", "3", "--repeats", "1", "--batch", str(args.batch), "--blocks", str(args.blocks),
-               "--distinct", str(args.distinct), "--ch", str(args.ch), "--chanstr", args.chanstr, "--q", str(args.q)]
+               "python3", os.path.abspath(__file__), "--pmc-child", "--pmc-mark", label, "--no-cpu-baseline", "--no-pmc",
+               "--no-graph", "--no-sweep", "--no-epoch", "--steps", "6", "--warmup", "3", "--repeats", "1", "--batch",
+               str(args.batch), "--blocks", str(args.blocks), "--distinct", str(args.distinct), "--ch", str(args.ch),
+               "--chanstr", args.chanstr, "--q", str(args.q)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                timeout=240)
         except subprocess.TimeoutExpired:
             shutil.rmtree(base, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {counter} child timed out"
+            return None, f"rocprofv3 --pmc {counter} child timed out", None
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
             shutil.rmtree(base, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {counter} child failed (rc {r.returncode}): {r.stdout[-300:]}"
+            return None, f"rocprofv3 --pmc {counter} child failed (rc {r.returncode}): {r.stdout[-300:]}", None
+        rows = [row for row in csv.DictReader(open(files[0])) if row["Counter_Name"] == counter]
+        rows.sort(key=lambda row: int(row["Dispatch_Id"]))
         per = []
-        for row in csv.DictReader(open(files[0])):
-            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+        for prev, row in zip(rows, rows[1:]):
+            if "uniform_kernel" in prev["Kernel_Name"] and int(prev["Grid_Size"]) in (mark_grid, mark_grid // 256):
                 per.append(float(row["Counter_Value"]))
+                name = row["Kernel_Name"]
         if not per:
             shutil.rmtree(base, ignore_errors=True)
-            return None, f"no dispatch of {kernel_substr} in the {counter} pass"
+            return None, f"no marked dispatch of {label} in the {counter} pass", None
         vals[counter] = statistics.median(per)
     shutil.rmtree(base, ignore_errors=True)
     # rocprofv3 reports both in KB
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (
         f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (host-launched steps), median per "
-        f"dispatch, 2 x FETCH_SIZE + WRITE_SIZE; kernel sources {kernel_source_hash()}")
+        f"dispatch of the launch behind a marker dispatch, 2 x FETCH_SIZE + WRITE_SIZE; kernel sources "
+        f"{kernel_source_hash()}"), name
 
 
 def run(args):
@@ -272,12 +299,32 @@ def run(args):
     if not args.no_graph and args.mode == "step":
         graphed = GraphedTrainStep(eng, B, args.q)
 
-    def step(i, use_graph=True):
+    def shares(i):
         ids, whole = nd.shard_minibatch(order, i, B * world, rank, world)
+        return ids, float(counts[whole].sum())
+
+    def step(i, use_graph=True):
+        ids, n_pts = shares(i)
         if graphed is not None and use_graph:
-            graphed(ids, n_pts=float(counts[whole].sum()))
+            graphed(ids, n_pts=n_pts)
         else:
-            eng.train_step(ids, args.q, n_pts=float(counts[whole].sum()))
+            eng.train_step(ids, args.q, n_pts=n_pts)
+
+    def run_steps(lo, hi):
+        """Steps [lo, hi): with the graph, ONE upload of their schedule (block ids, noise steps, rate and Adam
+        coefficients: (hi - lo) x (B + 3) words), then one graph replay per step -- the upload is inside the timed
+        region; without the graph, host-launched steps."""
+        if graphed is None:
+            for i in range(lo, hi):
+                step(i)
+            return
+        i = lo
+        while i < hi:
+            e = min(hi, i + graphed.CAP)
+            graphed.load_schedule([shares(k) for k in range(i, e)])
+            for _ in range(i, e):
+                graphed.replay()
+            i = e
 
     probe = KernelProbe()
     c3 = int(args.chanstr.split(",")[3])
@@ -302,13 +349,6 @@ def run(args):
     probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
     # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
     probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs: True)
-    # rocprofv3 names of the kernels behind those labels (for the PMC child passes)
-    wide = c3 == 16
-    kernel_names = {"wgrad_trunk5": "wgrad_mfma3_kernel", "wgrad_conv2_up2_conv1": "wgrad_mfma3_kernel",
-                    "conv2_fwd": "G16<16, 4, 1, 8, 4, 2, 1, 16, 8>" if wide else "MCv<8, 0, 1, 16, 8, 1, 4, 2, 2>",
-                    "conv2_bwd_data": "G16<16, 4, 1, 7, 1, 9, 4, 4, 7>" if wide else "MCvFlat<8, 18, 7, 4, 2, 2>",
-                    "conv2_bwd_weight": "W16<4, 1, 32, 4>" if wide else "wgrad_k4_mfma"}
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -326,14 +366,12 @@ def run(args):
     region_ms = []
     dt = None
     if args.mode == "step":
-        for i in range(args.warmup):
-            step(i)
+        run_steps(0, args.warmup)
         nxt = args.warmup
         for r in range(nreg):                     # region 0 is the contract's measurement; the others show its spread
             barrier()
             t0 = time.perf_counter()
-            for i in range(nxt, nxt + args.steps):
-                step(i)
+            run_steps(nxt, nxt + args.steps)
             barrier()
             d = timed_max(time.perf_counter() - t0)
             nxt += args.steps
@@ -343,6 +381,7 @@ def run(args):
         # kernels inside a replayed graph cannot be bracketed by events: time the dominant kernels on the same stream
         # in the same process right after the timed region, same shapes and operands, launched from the host
         probe.enabled = not args.pmc_child
+        probe.mark = args.pmc_mark or None
         for i in range(nxt, nxt + min(args.steps, 10)):
             step(i, use_graph=False)
         torch.cuda.synchronize()
@@ -401,26 +440,69 @@ def run(args):
 
     blocks_per_s = (args.steps * B * world / dt) if args.mode == "step" else args.blocks * args.epochs / dt
 
+    # ---- sweep (B in {16, 256, 4096}; 8(e): report both the latency-bound B = 16 line and the lines
+    # that keep every GPU busy): batch 256 PER GPU train step, the full-batch latent step over this rank's shard of
+    # the resident blocks, and a `--sweep-blocks`-block latent step + eval forward sharded over the ranks.  Weak scaling
+    # for the first, strong for the other two; every figure is a max over ranks and carries its step-level fraction.
+    launch_desc = "host" if (graphed is None and args.mode == "step") else (
+        "hip-graph replay (step head .. backward), then all-reduce + Adam from the host"
+        if (graphed is not None and graphed.collective == "host") else
+        "hip-graph replay (step head .. Adam in one graph; per-step scalars from a device-resident schedule)")
+    collective_desc = None if eng.grad_hook is None else (
+        "all-reduce captured in the step graph" if (graphed is not None and graphed.collective == "graph")
+        else "all-reduce launched from the host")
     extra = {}
-    if args.sweep and rank == 0 and world == 1:
-        order2 = np.concatenate([rng.permutation(args.blocks) for _ in range(13 * 256 // args.blocks + 2)])
-        for b2 in (256,):
-            for i in range(3):
-                eng.train_step(order2[i * b2:(i + 1) * b2], args.q)
-            torch.cuda.synchronize()
+    if not args.no_sweep and args.mode == "step":
+        fwd_macs = FWD_MACS.get(args.chanstr, 0)
+        frac = lambda bps, flop_per_block: round(bps / world * flop_per_block / 1e12 / PEAK_FP32_TFLOPS, 4)
+
+        def timed(fn, n):
+            fn()
+            barrier()
             t1 = time.perf_counter()
-            n2 = 10
-            for i in range(n2):
-                eng.train_step(order2[i * b2:(i + 1) * b2], args.q)
-            torch.cuda.synchronize()
-            extra[f"train_step_B{b2}_blocks_per_s"] = round(n2 * b2 / (time.perf_counter() - t1), 1)
-        eng.latent_step(args.q)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(3):
-            eng.latent_step(args.q)
-        torch.cuda.synchronize()
-        extra[f"latent_step_N{args.blocks}_blocks_per_s"] = round(3 * args.blocks / (time.perf_counter() - t1), 1)
+            for _ in range(n):
+                fn()
+            barrier()
+            return timed_max(time.perf_counter() - t1) / n
+
+        b2 = 256
+        order2 = np.concatenate([rng.permutation(args.blocks) for _ in range(14 * b2 * world // args.blocks + 2)])
+        it = [0]
+
+        def big_step():
+            ids, whole = nd.shard_minibatch(order2, it[0], b2 * world, rank, world)
+            it[0] += 1
+            eng.train_step(ids, args.q, n_pts=float(counts[whole].sum()))
+        for _ in range(2):
+            big_step()
+        dt2 = timed(big_step, 8)
+        bps = b2 * world / dt2
+        extra[f"train_step_B{b2}_per_gpu"] = {"blocks_per_s": round(bps, 1), "ms_per_step": round(dt2 * 1e3, 3),
+                                              "global_batch": b2 * world, "scaling": "weak",
+                                              "frac_of_fp32_peak": frac(bps, 6.0 * fwd_macs)}
+        lo, hi = nd.shard_range(args.blocks, rank, world)
+        dt3 = timed(lambda: eng.latent_step(args.q, lo, hi) if hi > lo else None, 3)
+        bps = args.blocks / dt3
+        extra[f"latent_step_N{args.blocks}"] = {"blocks_per_s": round(bps, 1), "ms_per_step": round(dt3 * 1e3, 3),
+                                                 "scaling": "strong (blocks sharded over the ranks, no collective)",
+                                                 "frac_of_fp32_peak": frac(bps, 4.0 * fwd_macs)}
+        nbig = args.sweep_blocks
+        if nbig > 0:
+            del eng, graphed
+            torch.cuda.empty_cache()
+            lo, hi = nd.shard_range(nbig, rank, world)
+            big = argparse.Namespace(**dict(vars(args), blocks=max(hi - lo, 1), force_collective=False))
+            eng2 = build_engine(big, device, 1)
+            dt4 = timed(lambda: eng2.latent_step(args.q), 3)
+            dt5 = timed(lambda: eng2.eval_forward(), 3)
+            extra[f"latent_step_N{nbig}"] = {"blocks_per_s": round(nbig / dt4, 1), "ms_per_step": round(dt4 * 1e3, 2),
+                                             "blocks_per_gpu": hi - lo, "scaling": "strong",
+                                             "frac_of_fp32_peak": frac(nbig / dt4, 4.0 * fwd_macs)}
+            extra[f"eval_forward_N{nbig}"] = {"blocks_per_s": round(nbig / dt5, 1), "ms": round(dt5 * 1e3, 2),
+                                              "blocks_per_gpu": hi - lo, "scaling": "strong",
+                                              "frac_of_fp32_peak": frac(nbig / dt5, 2.0 * fwd_macs),
+                                              "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+            del eng2
 
     if rank == 0:
         kern_us = probe.summary()
@@ -437,13 +519,14 @@ def run(args):
                           "wgrad_trunk5": macs + UP2_MACS[cs] + CONV1_MACS[cs] + UP1_MACS[cs] + CONV0_MACS[cs]}
             flops = 2.0 * layer_macs.get(label, macs) * B
             achieved = flops / (us * 1e-6) / 1e12
-            traffic, tnote = None, "not measured (--no-pmc or N > 1)"
+            traffic, tnote, kname = None, "not measured (--no-pmc or N > 1)", None
             if world == 1 and not args.no_pmc:
                 torch.cuda.synchronize()
-                traffic, tnote = measure_traffic(args, kernel_names[label])
+                traffic, tnote, kname = measure_traffic(args, label)
             roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                         "traffic": None if traffic is None else round(traffic), "traffic_source": tnote,
+                        "kernel_name": kname,
                         "avg_launch_us": round(us, 2), "flops_per_launch": flops,
                         "all_kernels_avg_us": {k: round(v, 2) for k, v in kern_us.items()}}
         fwd = FWD_MACS.get(args.chanstr)
@@ -458,13 +541,7 @@ def run(args):
             "higher_is_better": True,
             "scaling": "weak" if args.mode == "step" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "launch": "host" if (graphed is None and args.mode == "step") else (
-                           "hip-graph replay (step head .. backward), then all-reduce + Adam from the host"
-                           if (graphed is not None and graphed.collective == "host") else
-                           "hip-graph replay (step head .. Adam in one graph)"),
-                       "collective": None if eng.grad_hook is None else
-                                     ("all-reduce captured in the step graph" if (graphed is not None and graphed.collective == "graph")
-                                      else "all-reduce launched from the host"),
+                       "launch": launch_desc, "collective": collective_desc,
                        "batch_per_gpu": B, "global_batch": B * world, "blocks_resident": args.blocks,
                        "ch": args.ch, "chanstr": args.chanstr, "parallelism": f"dp{world}",
                        "data_detail": f"{min(args.blocks, args.distinct)} distinct synthetic 32^3 quadric-sheet blocks "

@@ -21,6 +21,46 @@ def run(cmd, cwd):
     return r.stdout
 
 
+# the reference's own format strings (/root/reference/NVFPCC.py:261 and :371), turned into parsers: whatever reads the
+# reference's training log reads ours
+REF_TRAIN = ('[Epoch %04d TRAIN %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f S1 Loss: %.4f '
+             'S2 Loss: %.4f S1Pacc: %.4f S1Nacc: %.4f S2Pacc: %.4f S2Nacc: %.4f bpp: %.4f b_latent: %.4f  b_net: %.4f '
+             'MSE1: %.4f PSNR1: %.4f')
+REF_TEST = ('[Epoch %04d TEST %.1f seconds] Loss: %.4e PosiPenal: %.4f PosiGain: %.4f Pacc: %.4f Nacc: %.4f S1 Loss: %.4f '
+            'S2 Loss: %.4f S1Pacc: %.4f S1Nacc: %.4f S2Pacc: %.4f S2Nacc: %.4f bpp: %.4f b_latent: %.4f b_net: %.4f '
+            'b_all: %.4f MSE1: %.4f PSNR1: %.4f')
+
+
+def line_parser(fmt):
+    import re
+    num = r"([-+]?(?:\d+\.\d+(?:e[-+]\d+)?|nan|inf))"
+    pat = re.escape(fmt)
+    for spec in ("%04d", "%.1f", "%.4e", "%.4f"):
+        pat = pat.replace(re.escape(spec), r"(\d{4})" if spec == "%04d" else num)
+    return re.compile("^" + pat + "$")
+
+
+def check_log_lines(out):
+    """Every TRAIN / TEST line matches the reference's format exactly (field names, order, spacing, precision), and
+    the accuracies are per-mini-batch means of ratios in [0, 1]."""
+    tr, te = line_parser(REF_TRAIN), line_parser(REF_TEST)
+    trains = [ln for ln in out.splitlines() if " TRAIN " in ln]
+    tests = [ln for ln in out.splitlines() if " TEST " in ln]
+    assert trains and tests
+    for ln in trains:
+        m = tr.match(ln)
+        assert m, ln
+        v = [float(x) for x in m.groups()]
+        assert len(v) == 18 and all(0.0 <= x <= 1.0 for x in v[5:7] + v[9:13]), ln      # Pacc Nacc S1P S1N S2P S2N
+        assert abs(v[13] - (v[14] + v[15])) < 2e-4                                      # bpp = b_latent + b_net
+    for ln in tests:
+        m = te.match(ln)
+        assert m, ln
+        v = [float(x) for x in m.groups()]
+        assert len(v) == 19 and all(0.0 <= x <= 1.0 for x in v[5:7] + v[9:13]), ln
+        assert v[16] >= v[13] - 1e-4                                                    # b_all includes the side information
+
+
 CASES = {
     # BASELINE.json configs[1] / configs[4]: narrow and wide decoder, the reference's own command lines (README.md:50-63)
     "S": ["--chanstr", "8,16,8,8", "--ch", "3"],
@@ -48,6 +88,7 @@ def test_train_encode_decode_roundtrip(tmp_path, tag):
                "1e-3", "--w1", "10", "--w2", "57", "--wemb", wemb, "--shuffle", "True", "--epochs", "11",
                "--phase_change", "5"] + common, cwd)
     assert "[Epoch 0010 TRAIN" in out and "[Epoch 0010 TEST" in out
+    check_log_lines(out)
     sd = torch.load(os.path.join(cwd, "ckpts", "0010.ckpt"), map_location="cpu")
     assert len(sd) == 50 and sd["reconstructor.conv2.kernel"].shape == (c[3], c[3], 4, 4, 4)
     assert sd["reconstructor.up1.kernel"].shape == (c[1], c[2], 5, 5, 5) and sd["entropy_coder.sigma"].shape == (1, ch, 1, 1, 1)

@@ -88,7 +88,8 @@ def test_bench_gpus_2_launches_two_ranks_and_reports_the_live_world_size(tmp_pat
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
-                        "--epochs", "1", "--blocks", "61", "--distinct", "61", "--no-pmc", "--no-cpu-baseline"],
+                        "--epochs", "1", "--blocks", "61", "--distinct", "61", "--no-pmc", "--no-cpu-baseline",
+                        "--sweep-blocks", "300"],
                        env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -99,3 +100,10 @@ def test_bench_gpus_2_launches_two_ranks_and_reports_the_live_world_size(tmp_pat
     assert d["config"]["collective"] == "all-reduce launched from the host"
     # 61 blocks at a global mini-batch of 32: one full mini-batch and a short one of 29 (15 + 14 blocks)
     assert d["epoch"]["minibatches_per_epoch"] == 2 and d["epoch"]["blocks_per_s"] > 0
+    # SURVEY 8(e) "report both": beside the latency-bound B = 16 / GPU line, the lines that keep every GPU busy --
+    # batch 256 per GPU (weak), the full-batch latent step and a big latent step + eval sharded over the ranks (strong)
+    sw = d["sweep"]
+    assert sw["train_step_B256_per_gpu"]["global_batch"] == 512 and sw["train_step_B256_per_gpu"]["blocks_per_s"] > 0
+    assert sw["latent_step_N61"]["blocks_per_s"] > 0
+    assert sw["latent_step_N300"]["blocks_per_gpu"] == 150 and sw["eval_forward_N300"]["blocks_per_s"] > 0
+    assert all(0 < v["frac_of_fp32_peak"] < 1 for v in sw.values())

@@ -17,8 +17,9 @@ from tests.golden_inputs import CONFIGS, HYPER, perturb_state_, make_emb, noise_
 
 pytestmark = pytest.mark.gpu
 TRUNK_ORDER = ["up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls"]
-# element-wise relative tolerance on gradient entries above 1e-3 of their tensor's maximum
-REL_TOL = 2e-2
+# element-wise relative tolerance on gradient entries above 1e-3 of their tensor's maximum (measured worst case on
+# MI355X: 1.1e-4 narrow decoder, all entries; 3.2e-3 wide decoder, 256 sampled entries per tensor)
+REL_TOL = 1e-2
 REL_SEEN = []
 
 
