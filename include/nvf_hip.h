@@ -54,6 +54,20 @@ typedef struct NvfStepCtx NvfStepCtx;
 size_t nvf_step_ctx_bytes(void);
 int nvf_step_ctx_init(NvfStepCtx* ctx);
 
+/* Adam fused into the launch that produces a gradient: an element g_base[i] written by that launch is followed by the
+ * nvf_step_tail update of p_base[i], m_base[i], v_base[i] (same coefficients, same arithmetic, same non-finite rule;
+ * bad_count, if non-NULL, is nvf_step_tail's acc + 6).  Applies to outputs inside [g_base, g_base + n) only. */
+typedef struct NvfAdamFuse {
+  const float* g_base;
+  float* p_base;
+  float* m_base;
+  float* v_base;
+  int64_t n;
+  const float* coef_dev;
+  float coef0_host, coef1_host, beta1, beta2, eps, reserved;
+  float* bad_count;
+} NvfAdamFuse;
+
 /* ---- weight packing -------------------------------------------------------
  * Re-lays an effective kernel into the two layouts the direct-conv kernels read
  * from scalar registers: w_fwd[ci][k][co] and w_bwd[co][k'][ci].
@@ -293,6 +307,14 @@ int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float* const* dws
                                     const int* jtotals, int n, const float* const* xs, float* const* outs,
                                     const int* channels, const int* spatials, int ntensors, int batch,
                                     void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream);
+/* ... with per-gradient addends (addends[i], or addends itself, may be NULL: dws[i][j] = sum of slabs + addends[i][j] --
+ * the weight-rate gradient of nvf_step_head's rate job) and, optionally, the optimiser applied to every element it
+ * writes (adam NULL: none). */
+int nvf_wgrad_reduce_multi_and_sums_fused(const float* const* slabs, float* const* dws, const int* nslabs,
+                                          const int* jtotals, int n, const float* const* addends,
+                                          const NvfAdamFuse* adam, const float* const* xs, float* const* outs,
+                                          const int* channels, const int* spatials, int ntensors, int batch,
+                                          void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream);
 
 /* The latent tail of a training step (backward of NVFPCC.py:186-196's latent generator on [batch, c <= 8, spatial]
  * tensors): gradient of the latent rate (+ dx_addend) -> GDN backward -> 1x1x1 weight and bias gradients, i.e.
@@ -356,6 +378,25 @@ int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const 
                           const float* sigma, const float* mu, float* bits, float* dsigma, float* dmu,
                           const float* g_dev, float g_host, void* workspace, size_t workspace_bytes, NvfStepCtx* ctx,
                           void* stream);
+
+/* The same rate term split so that its partial pass can ride in the step head (it depends on the parameters only, not
+ * on the mini-batch): nvf_step_head given a job computes the per-workgroup partial sums into job->part
+ * (nvf_weight_rate_batch_workspace() bytes) and WRITES g * dbits/dk to job->dk[l] (not accumulated: the caller hands
+ * those buffers to nvf_wgrad_reduce_multi_and_sums as addends); nvf_weight_rate_batch_final then adds the partials in
+ * the usual fixed order (queued in ctx between nvf_finals_begin / nvf_finals_flush, like nvf_weight_rate_batch's). */
+typedef struct NvfRateJob {
+  const float* kernel[8];
+  float* dk[8];            /* entries may be NULL */
+  int32_t n[8];
+  int32_t nlayers, reserved;
+  const float* sigma;
+  const float* mu;
+  float* part;
+  float g, reserved2;
+} NvfRateJob;
+int nvf_weight_rate_batch_final(const NvfRateJob* job, float* bits, float* dsigma, float* dmu, NvfStepCtx* ctx,
+                                void* stream);
+
 
 /* ---- deferred final passes ------------------------------------------------------
  * nvf_focal_loss_multi, nvf_multi_channel_sum / nvf_wgrad_reduce_multi_and_sums and nvf_weight_rate_batch end with a
@@ -461,6 +502,16 @@ typedef struct NvfStepTail {
   int32_t sched_words, reserved;
 } NvfStepTail;
 int nvf_step_tail(const NvfStepTail* args, void* stream);
+
+/* nvf_finals_flush and the tail of the training step in the same launch (single-GPU steps: nothing sits between the
+ * gradients and the optimiser): every gradient element a queued final pass writes inside [tail->g, tail->g + tail->n)
+ * -- bias sums, d/dsigma and d/dmu of the weight rate, the stem's GDN parameter gradients -- gets tail's Adam update on
+ * the spot; the elements of the nranges half-open index ranges ranges[2 r], ranges[2 r + 1] (gradients that earlier
+ * launches wrote directly, e.g. the latent tail's) get it from a workgroup of their own; the workgroup that ran the
+ * loss / rate / metrics passes adds the epoch statistics; the last workgroup to arrive hands the step buffer over to
+ * the next schedule row.  Together with nvf_wgrad_reduce_multi_and_sums_fused (the weight gradients) this covers what
+ * nvf_step_tail does; the caller makes the ranges the exact complement. */
+int nvf_finals_flush_tail(NvfStepCtx* ctx, const NvfStepTail* tail, const int64_t* ranges, int nranges, void* stream);
 int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
 
 /* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose
@@ -479,7 +530,8 @@ int nvf_gather_rows_multi(const float* const* srcs, float* const* dsts, const in
 int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step, const uint64_t* step_dev,
                   float* const* pack_dsts, const int* pack_kinds, const int* pack_c0s, const int* pack_c1s,
                   const int* pack_layers, const int* pack_bwd, int npack, const float* const* srcs,
-                  float* const* dsts, const int* widths, int n, const int64_t* idx, int rows, void* stream);
+                  float* const* dsts, const int* widths, int n, const int64_t* idx, int rows,
+                  const NvfRateJob* rate /* may be NULL: see nvf_weight_rate_batch_final */, void* stream);
 
 /* U[0,1) floats, Philox4x32-10 keyed by (seed, stream_id), counter = element index */
 int nvf_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);

@@ -97,7 +97,10 @@ PROTOTYPES = {
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
     "nvf_gather_rows_multi": (I, [P, P, P, I, P, I, P]),
-    "nvf_step_head": (I, [P, I, I, U, U, P, P, P, P, P, P, P, I, P, P, P, I, P, I, P]),
+    "nvf_step_head": (I, [P, I, I, U, U, P, P, P, P, P, P, P, I, P, P, P, I, P, I, P, P]),
+    "nvf_weight_rate_batch_final": (I, [P, P, P, P, P, P]),
+    "nvf_wgrad_reduce_multi_and_sums_fused": (I, [P, P, P, P, I, P, P, P, P, P, P, I, I, P, Z, P, P]),
+    "nvf_finals_flush_tail": (I, [P, P, P, I, P]),
     "nvf_uniform": (I, [P, L, U, U, P]),
     "nvf_nearest_dist2": (I, [P, P, P, P, P, P, I, P]),
     "nvf_threshold_count": (I, [P, F, P, I, I, P]),
@@ -114,6 +117,19 @@ class NvfStepTail(C.Structure):
                 ("inv_npts_host", F), ("nbits_scale", F), ("counts", P), ("acc", P),
                 ("sched_buf", P), ("sched_rows", P), ("sched_cursor", P), ("done", P),
                 ("sched_words", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NvfRateJob(C.Structure):
+    """include/nvf_hip.h: typedef struct NvfRateJob."""
+    _fields_ = [("kernel", P * 8), ("dk", P * 8), ("n", C.c_int32 * 8), ("nlayers", C.c_int32), ("reserved", C.c_int32),
+                ("sigma", P), ("mu", P), ("part", P), ("g", F), ("reserved2", F)]
+
+
+class NvfAdamFuse(C.Structure):
+    """include/nvf_hip.h: typedef struct NvfAdamFuse."""
+    _fields_ = [("g_base", P), ("p_base", P), ("m_base", P), ("v_base", P), ("n", L), ("coef_dev", P),
+                ("coef0_host", F), ("coef1_host", F), ("beta1", F), ("beta2", F), ("eps", F), ("reserved", F),
+                ("bad_count", P)]
 
 
 _lib = None

@@ -204,16 +204,19 @@ struct MStage {
     for (int c = 0; c < 4; ++c) {
       const float* xc = x0 + c * (long)d.din * plane;
       const int cbase = buf + c * C::CS;
+      // scalar base (the tile's first element of this channel; wave-uniform) + the lane's constant byte offset: a DMA
+      // instruction costs no vector address arithmetic (a per-lane 64-bit pointer was two VALU adds + waits per piece)
+      const float* xcs = nvf_uniform_ptr(xc);
       if (interior) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
-          if (pk[i] >= 0) nvf_glds_lane(xc + rel[i], lds0 + (unsigned)(cbase + (i * C::NW + wave) * 64) * 4u);
+          if (pk[i] >= 0) nvf_glds_row(xcs, (unsigned)rel[i] * 4u, lds0 + (unsigned)(cbase + (i * C::NW + wave) * 64) * 4u);
       } else {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
           const int gx = gx0 + (pk[i] & 255), gy = gy0 + ((pk[i] >> 8) & 255), gz = gz0 + (pk[i] >> 16);
           const bool ok = pk[i] >= 0 && gx >= 0 && gx < d.win && gy >= 0 && gy < d.hin && gz >= 0 && gz < d.din;
-          if (ok) nvf_glds_lane(xc + rel[i], lds0 + (unsigned)(cbase + (i * C::NW + wave) * 64) * 4u);
+          if (ok) nvf_glds_row(xcs, (unsigned)rel[i] * 4u, lds0 + (unsigned)(cbase + (i * C::NW + wave) * 64) * 4u);
           else if (pk[i] >= 0) lds[cbase + (i * C::NW + wave) * 64 + lane] = 0.f;
         }
       }

@@ -12,6 +12,30 @@ static const int kLossMaxWG = 1024;
 #define NVF_BETA_BOUND 1.0000072759311445e-03f /* sqrt(1e-6 + 2^-36) */
 #define NVF_GAMMA_BOUND 3.814697265625e-06f   /* 2^-18 */
 
+// ---- Adam fused into the launch that writes a gradient element (NvfAdamFuse, include/nvf_hip.h): nvf_step_tail's
+// arithmetic for ONE element -- an element whose gradient is not finite keeps its parameter and moments.  Returns 1 for
+// such an element (the caller counts them), 0 otherwise; gp outside [g_base, g_base + n): nothing happens.
+__device__ __forceinline__ int adam_fused_elem(const NvfAdamFuse& a, const float* gp, float gi) {
+  const long i = gp - a.g_base;
+  if (i < 0 || i >= a.n) return 0;
+  if (!(fabsf(gi) <= 3.402823466e38f)) return 1;
+  const float step_size = a.coef_dev ? a.coef_dev[0] : a.coef0_host, bc2_sqrt = a.coef_dev ? a.coef_dev[1] : a.coef1_host;
+  const float mi = a.m_base[i] * a.beta1 + gi * (1.f - a.beta1);
+  const float vi = a.v_base[i] * a.beta2 + (gi * gi) * (1.f - a.beta2);
+  a.m_base[i] = mi;
+  a.v_base[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+  a.p_base[i] = a.p_base[i] - step_size * (mi / denom);
+  return 0;
+}
+__device__ __forceinline__ NvfAdamFuse adam_fuse_of(const NvfStepTail& t) {
+  NvfAdamFuse a{};
+  a.g_base = t.g; a.p_base = t.p; a.m_base = t.m; a.v_base = t.v; a.n = t.n; a.coef_dev = t.coef_dev;
+  a.coef0_host = t.coef0_host; a.coef1_host = t.coef1_host; a.beta1 = t.beta1; a.beta2 = t.beta2; a.eps = t.eps;
+  a.bad_count = t.acc ? t.acc + 6 : nullptr;
+  return a;
+}
+
 // the three focal terms of the objective (main output + two heads, NVFPCC.py:166-184)
 struct FocalMulti {
   const float* p[3];
@@ -73,21 +97,24 @@ __device__ __forceinline__ void focal_multi_final_body(const FocalMulti& m, cons
   if (lane == 0) loss[t] = s;
 }
 
-__device__ __forceinline__ void multi_channel_sum_final_body(const MultiSumDesc& d, const float* __restrict__ part,
-                                                             int gch) {
-  if (gch >= d.total_channels) return;
+__device__ __forceinline__ int multi_channel_sum_final_body(const MultiSumDesc& d, const float* __restrict__ part,
+                                                            int gch, const NvfAdamFuse* adam = nullptr) {
+  if (gch >= d.total_channels) return 0;
   int t = 0;
   while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
   float s = 0.f;
   for (int g = 0; g < d.nchunk; ++g) s += part[(size_t)g * d.total_channels + gch];
-  d.out[t][gch - d.chan_base[t]] = s;
+  float* o = d.out[t] + (gch - d.chan_base[t]);
+  *o = s;
+  return adam ? adam_fused_elem(*adam, o, s) : 0;
 }
 
 // one wave: lanes take the chunk partials 64 apart (ascending), then a fixed-order wave sum
-__device__ __forceinline__ void weight_rate_batch_final_body(const WeightRateBatch& b, const float* __restrict__ part,
-                                                             const float* __restrict__ sigma, float* __restrict__ bits,
-                                                             float* __restrict__ dsigma, float* __restrict__ dmu,
-                                                             const float* __restrict__ g_dev, float g_host, int lane) {
+__device__ __forceinline__ int weight_rate_batch_final_body(const WeightRateBatch& b, const float* __restrict__ part,
+                                                            const float* __restrict__ sigma, float* __restrict__ bits,
+                                                            float* __restrict__ dsigma, float* __restrict__ dmu,
+                                                            const float* __restrict__ g_dev, float g_host, int lane,
+                                                            const NvfAdamFuse* adam = nullptr) {
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
   float acc_s = 0.f, acc_m = 0.f;
   for (int l = 0; l < b.nlayers; ++l) {
@@ -102,11 +129,19 @@ __device__ __forceinline__ void weight_rate_batch_final_body(const WeightRateBat
   }
   acc_s = nvf_wave_sum(acc_s);
   acc_m = nvf_wave_sum(acc_m);
-  if (lane != 0) return;
+  if (lane != 0) return 0;
   const float sraw = sigma[0];
   const float sgn = sraw > 0.f ? 1.f : (sraw < 0.f ? -1.f : 0.f);
-  if (dsigma) dsigma[0] = g * acc_s * sgn;
-  if (dmu) dmu[0] = g * acc_m;
+  int bad = 0;
+  if (dsigma) {
+    dsigma[0] = g * acc_s * sgn;
+    if (adam) bad += adam_fused_elem(*adam, dsigma, g * acc_s * sgn);
+  }
+  if (dmu) {
+    dmu[0] = g * acc_m;
+    if (adam) bad += adam_fused_elem(*adam, dmu, g * acc_m);
+  }
+  return bad;
 }
 
 // IGDN parameter gradients of the fused stem from its slabs (column p: p < c0 is d beta_p, the rest d gamma): fixed-order
@@ -121,21 +156,30 @@ struct StemGdnFinal {
 };
 
 // thread p0 of `stride` takes the columns p0, p0 + stride, ... (c0 + c0^2 columns: 72 narrow, 272 wide)
-__device__ __forceinline__ void stem_gdn_final_body(const StemGdnFinal& f, int p0, int stride) {
+__device__ __forceinline__ int stem_gdn_final_body(const StemGdnFinal& f, int p0, int stride,
+                                                   const NvfAdamFuse* adam = nullptr) {
   const int ncol = f.c0 + f.c0 * f.c0;
+  int bad = 0;
   for (int p = p0; p < ncol; p += stride) {
     float s = 0.f;
     for (int g = 0; g < f.nslab; ++g) s += f.slab_gdn[(size_t)g * ncol + p];
+    float* o;
+    float v;
     if (p < f.c0) {
       const float h = f.beta_hat[p];
       const float g = s * 2.f * fmaxf(h, NVF_BETA_BOUND);
-      f.dbeta_hat[p] = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
+      o = f.dbeta_hat + p;
+      v = (h >= NVF_BETA_BOUND || g < 0.f) ? g : 0.f;
     } else {
       const float h = f.gamma_hat[p - f.c0];
       const float g = s * 2.f * fmaxf(h, NVF_GAMMA_BOUND);
-      f.dgamma_hat[p - f.c0] = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
+      o = f.dgamma_hat + (p - f.c0);
+      v = (h >= NVF_GAMMA_BOUND || g < 0.f) ? g : 0.f;
     }
+    *o = v;
+    if (adam) bad += adam_fused_elem(*adam, o, v);
   }
+  return bad;
 }
 
 // metric partials of term t (rows of 6) -> out[6 t + k], k = tid % 6, in row order (the arithmetic of finalize_partials)

@@ -21,6 +21,76 @@ __global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a, int sum_block
   }
 }
 
+// finals + the tail of a single-GPU training step (nvf_finals_flush_tail).  Workgroup 0 runs the passes the epoch
+// statistics read -- the focal terms (waves 0-2), the weight-rate term (wave 3), then the metric counts -- and adds the
+// statistics itself, so no sum crosses a workgroup; workgroup 1 the stem's IGDN parameter gradients; workgroups
+// 2 .. 2 + sum_blocks - 1 the bias sums; the last one the index ranges whose gradients earlier launches wrote.  Every
+// gradient element gets its Adam update from the thread that produced (or owns) it.  The last workgroup to arrive --
+// all of them have read the step buffer's coefficients by then -- copies the next schedule row over the step buffer.
+struct TailRanges { long lo[16], hi[16]; int n; };
+
+__global__ __launch_bounds__(256) void finals_tail_kernel(FinalsArgs a, int sum_blocks, NvfStepTail t, TailRanges rg) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const NvfAdamFuse ad = adam_fuse_of(t);
+  int bad = 0;
+  if (blockIdx.x == 0) {
+    if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
+    if (a.has_r && wave == 3)
+      bad += weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost,
+                                          lane, &ad);
+    if (a.has_m) metrics_final_body(a.m_part, a.m_out, a.m_nwg, a.m_nterm, a.m_accumulate, tid);
+  } else if (blockIdx.x == 1) {
+    if (a.has_g) bad += stem_gdn_final_body(a.g, tid, 256, &ad);
+  } else if ((int)blockIdx.x < 2 + sum_blocks) {
+    if (a.has_s && tid < 64) bad += multi_channel_sum_final_body(a.s, a.s_part, ((int)blockIdx.x - 2) * 64 + tid, &ad);
+  } else {
+    for (int r = 0; r < rg.n; ++r)
+      for (long i = rg.lo[r] + tid; i < rg.hi[r]; i += blockDim.x) bad += adam_fused_elem(ad, t.g + i, t.g[i]);
+  }
+  if (t.acc) {
+    const unsigned long long any = __ballot(bad != 0);
+    // a lane's count is 0 .. a few: add the lanes' counts (integer-valued floats: order-free)
+    float c = (float)bad;
+    c = nvf_wave_sum(c);
+    if (any && lane == 0) atomicAdd(t.acc + 6, c);
+  }
+  __syncthreads();                                            // workgroup 0: the sums it wrote are visible to its thread 0
+  if (blockIdx.x == 0 && tid == 0 && t.acc) {
+    int bad_terms = 0;
+    for (int k = 0; k < 3; ++k) {
+      const float x = t.loss_terms[k];
+      t.acc[k] += x;
+      bad_terms += !(fabsf(x) <= 3.402823466e38f);
+    }
+    const float bl = t.lbits[0] * (t.inv_npts_dev ? t.inv_npts_dev[0] : t.inv_npts_host);
+    float nb = 0.f;
+    for (int l = 0; l < t.nnb; ++l) nb += t.nbits[l];
+    nb *= t.nbits_scale;
+    t.acc[3] += bl;
+    t.acc[4] += nb;
+    bad_terms += !(fabsf(bl) <= 3.402823466e38f) + !(fabsf(nb) <= 3.402823466e38f);
+    t.acc[5] += (float)bad_terms;
+    t.acc[7] += 1.f;
+    if (t.counts) {
+      for (int k = 0; k < 3; ++k) {
+        t.acc[8 + 2 * k] += t.counts[6 * k] / t.counts[6 * k + 1];
+        t.acc[9 + 2 * k] += t.counts[6 * k + 2] / t.counts[6 * k + 3];
+      }
+      t.acc[14] += t.counts[4];
+      t.acc[15] += t.counts[5];
+    }
+  }
+  if (!t.sched_rows) return;
+  __shared__ int last;
+  if (tid == 0) last = atomicAdd(t.done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  const unsigned long long c = t.sched_cursor[0];
+  const int64_t* row = t.sched_rows + c * (unsigned long long)t.sched_words;
+  for (int w = tid; w < t.sched_words; w += blockDim.x) t.sched_buf[w] = row[w];
+  if (tid == 0) { t.sched_cursor[0] = c + 1; t.done[0] = 0u; }
+}
+
 }  // namespace
 
 bool nvf_finals_push_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm) {
@@ -106,6 +176,29 @@ extern "C" void nvf_finals_cancel(NvfStepCtx* ctx) {
 
 // Run the queued final passes in one launch on `stream` (the stream their partial passes ran on) and stop queueing.
 // Nothing queued: no launch.
+extern "C" int nvf_finals_flush_tail(NvfStepCtx* ctx, const NvfStepTail* tail, const int64_t* ranges, int nranges,
+                                     void* stream) {
+  if (!nvf_ctx_ok(ctx) || !tail || nranges < 0 || nranges > 16 || (nranges > 0 && !ranges)) return NVF_EINVAL;
+  const NvfStepTail t = *tail;
+  if (!t.p || !t.g || !t.m || !t.v || t.n <= 0) return NVF_EINVAL;
+  if (t.acc && (!t.loss_terms || !t.lbits || !t.nbits || t.nnb <= 0 || t.nnb > 16)) return NVF_EINVAL;
+  if (t.sched_rows && (!t.sched_buf || !t.sched_cursor || t.sched_words <= 0 || !t.done)) return NVF_EINVAL;
+  TailRanges rg{};
+  for (int r = 0; r < nranges; ++r) {
+    if (ranges[2 * r] < 0 || ranges[2 * r + 1] > t.n || ranges[2 * r] > ranges[2 * r + 1]) return NVF_EINVAL;
+    rg.lo[r] = (long)ranges[2 * r]; rg.hi[r] = (long)ranges[2 * r + 1];
+  }
+  rg.n = nranges;
+  const FinalsArgs a = ctx->args;
+  ctx->args = FinalsArgs{};
+  ctx->deferring = 0;
+  if (a.has_f && a.f_nterm > 3) return NVF_EINVAL;
+  const int sum_blocks = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
+  finals_tail_kernel<<<2 + sum_blocks + 1, 256, 0, nvf_stream(stream)>>>(a, sum_blocks, t, rg);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 extern "C" int nvf_finals_flush(NvfStepCtx* ctx, void* stream) {
   if (!nvf_ctx_ok(ctx)) return NVF_EINVAL;
   const FinalsArgs a = ctx->args;

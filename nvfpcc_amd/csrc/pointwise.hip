@@ -446,17 +446,16 @@ extern "C" int nvf_weight_rate(const float* kernel, int n, const float* sigma, c
 // write (bits, dsigma, dmu) partials; one workgroup then adds the partials in chunk order (reproducible).
 // dk is ADDED to the weight gradients already in place.
 
-__global__ __launch_bounds__(256) void weight_rate_batch_kernel(WeightRateBatch b, const float* __restrict__ sigma,
-                                                                const float* __restrict__ mu,
-                                                                float* __restrict__ part,
-                                                                const float* __restrict__ g_dev, float g_host) {
-  __shared__ float red[16];
-  const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+// partial sums of workgroup `wg` (its fixed chunk of one layer): part[3 wg ..] = bits, d/dsigma, d/dmu; dk (if given)
+// is ADDED to (accumulate) or overwritten with g * dbits/dk
+__device__ __forceinline__ void weight_rate_partial_body(const WeightRateBatch& b, const float* __restrict__ sigma,
+                                                         const float* __restrict__ mu, float* __restrict__ part, float g,
+                                                         int wg, int accumulate, float* red) {
   const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
   const float sabs = fabsf(sigma[0]), m = mu[0];
   int l = 0;
-  while (l + 1 < b.nlayers && (int)blockIdx.x >= b.first_wg[l + 1]) ++l;
-  const int lo = ((int)blockIdx.x - b.first_wg[l]) * b.chunk;
+  while (l + 1 < b.nlayers && wg >= b.first_wg[l + 1]) ++l;
+  const int lo = (wg - b.first_wg[l]) * b.chunk;
   const int hi = min(lo + b.chunk, b.n[l]);
   const float* k = b.kernel[l];
   float* dk = b.dk[l];
@@ -467,16 +466,49 @@ __global__ __launch_bounds__(256) void weight_rate_batch_kernel(WeightRateBatch 
     sb += r.bits;
     ss += r.dsig;
     sm_ += r.dmu;
-    if (dk) dk[i] += g * r.dv;
+    if (dk) dk[i] = accumulate ? dk[i] + g * r.dv : g * r.dv;
   }
   float tb = nvf_block_sum(sb, red);
   float tsg = nvf_block_sum(ss, red);
   float tm = nvf_block_sum(sm_, red);
   if (threadIdx.x == 0) {
-    part[3 * blockIdx.x] = tb;
-    part[3 * blockIdx.x + 1] = tsg;
-    part[3 * blockIdx.x + 2] = tm;
+    part[3 * wg] = tb;
+    part[3 * wg + 1] = tsg;
+    part[3 * wg + 2] = tm;
   }
+}
+
+__global__ __launch_bounds__(256) void weight_rate_batch_kernel(WeightRateBatch b, const float* __restrict__ sigma,
+                                                                const float* __restrict__ mu,
+                                                                float* __restrict__ part,
+                                                                const float* __restrict__ g_dev, float g_host) {
+  __shared__ float red[16];
+  weight_rate_partial_body(b, sigma, mu, part, g_host * (g_dev ? g_dev[0] : 1.f), blockIdx.x, 1, red);
+}
+
+// workgroup layout of the batch: fixed chunks, <= ~256 + nlayers workgroups (the final pass walks them in this order)
+static int weight_rate_batch_desc(const float* const* kernels, float* const* dks, const int* ns, int nlayers,
+                                  WeightRateBatch& b) {
+  if (!kernels || !ns || nlayers <= 0 || nlayers > 8) return NVF_EINVAL;
+  long total = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    if (!kernels[i] || ns[i] <= 0) return NVF_EINVAL;
+    b.kernel[i] = kernels[i];
+    b.dk[i] = dks ? dks[i] : nullptr;
+    b.n[i] = ns[i];
+    total += ns[i];
+  }
+  b.nlayers = nlayers;
+  long chunk = (total + 255) / 256;
+  if (chunk < 256) chunk = 256;              // at least one element per thread
+  b.chunk = (int)chunk;
+  int wg = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    b.first_wg[i] = wg;
+    wg += (int)((ns[i] + chunk - 1) / chunk);
+  }
+  b.first_wg[nlayers] = wg;
+  return wg > 512 ? NVF_EINVAL : NVF_OK;
 }
 
 __global__ void weight_rate_batch_final(WeightRateBatch b, const float* __restrict__ part,
@@ -495,25 +527,9 @@ extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* 
   if (!kernels || !ns || nlayers <= 0 || nlayers > 8 || !sigma || !mu || !bits || !workspace) return NVF_EINVAL;
   if (workspace_bytes < nvf_weight_rate_batch_workspace()) return NVF_EWORKSPACE;
   WeightRateBatch b{};
-  long total = 0;
-  for (int i = 0; i < nlayers; ++i) {
-    if (!kernels[i] || ns[i] <= 0) return NVF_EINVAL;
-    b.kernel[i] = kernels[i];
-    b.dk[i] = dks ? dks[i] : nullptr;
-    b.n[i] = ns[i];
-    total += ns[i];
-  }
-  b.nlayers = nlayers;
-  long chunk = (total + 255) / 256;          // <= ~256 + nlayers workgroups
-  if (chunk < 256) chunk = 256;              // at least one element per thread
-  b.chunk = (int)chunk;
-  int wg = 0;
-  for (int i = 0; i < nlayers; ++i) {
-    b.first_wg[i] = wg;
-    wg += (int)((ns[i] + chunk - 1) / chunk);
-  }
-  b.first_wg[nlayers] = wg;
-  if (wg > 512) return NVF_EINVAL;
+  const int rc = weight_rate_batch_desc(kernels, dks, ns, nlayers, b);
+  if (rc != NVF_OK) return rc;
+  const int wg = b.first_wg[nlayers];
   hipStream_t s = nvf_stream(stream);
   weight_rate_batch_kernel<<<wg, 256, 0, s>>>(b, sigma, mu, (float*)workspace, g_dev, g_host);
   if (!nvf_finals_push_rate(ctx, b, (const float*)workspace, sigma, bits, dsigma, dmu, g_dev, g_host))
@@ -1025,10 +1041,25 @@ __device__ __forceinline__ int layout_to_kernel_index(const NvfLayerDesc& d, int
   return (i0 * d.dim1 + i1) * d.k3 + t;
 }
 
+struct RateInHead {
+  WeightRateBatch b;
+  const float* sigma;
+  const float* mu;
+  float* part;
+  float g;
+  int32_t nwg;
+};
+
 __global__ void step_head_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q, uint64_t seed,
                                  uint64_t step, const uint64_t* __restrict__ step_dev, PackJobs pk, GatherMulti g,
-                                 const int64_t* __restrict__ idx, int rows, int gwg, int wpl) {
+                                 const int64_t* __restrict__ idx, int rows, int gwg, int wpl, RateInHead rate) {
   int bid = blockIdx.x;        // wpl workgroups per layer / pack job
+  if (bid < rate.nwg) {        // the weight-rate term's partial sums: parameters only, nothing of the mini-batch
+    __shared__ float red[16];
+    weight_rate_partial_body(rate.b, rate.sigma, rate.mu, rate.part, rate.g, bid, 0, red);
+    return;
+  }
+  bid -= rate.nwg;
   if (bid < wpl * nlayers) { prepare_weights_body(table, q, seed, step, step_dev, bid / wpl, bid % wpl, wpl); return; }
   bid -= wpl * nlayers;
   if (bid < wpl * pk.n) {
@@ -1052,7 +1083,7 @@ extern "C" int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t
                              const uint64_t* step_dev, float* const* pack_dsts, const int* pack_kinds,
                              const int* pack_c0s, const int* pack_c1s, const int* pack_layers, const int* pack_bwd,
                              int npack, const float* const* srcs, float* const* dsts, const int* widths, int n,
-                             const int64_t* idx, int rows, void* stream) {
+                             const int64_t* idx, int rows, const NvfRateJob* rate_job, void* stream) {
   if (!table_dev || nlayers <= 0 || !idx || npack < 0) return NVF_EINVAL;
   PackJobs pk{};
   if (npack > 0) {
@@ -1073,8 +1104,16 @@ extern "C" int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t
   int wpl = 64;
   for (int j = 0; j < npack; ++j)
     if (pack_c0s && pack_c1s && pack_c0s[j] * pack_c1s[j] >= 256) wpl = 128;
-  step_head_kernel<<<wpl * nlayers + wpl * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
-      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl);
+  RateInHead rate{};
+  if (rate_job) {
+    if (!rate_job->sigma || !rate_job->mu || !rate_job->part) return NVF_EINVAL;
+    const int rrc = weight_rate_batch_desc(rate_job->kernel, rate_job->dk, rate_job->n, rate_job->nlayers, rate.b);
+    if (rrc != NVF_OK) return rrc;
+    rate.sigma = rate_job->sigma; rate.mu = rate_job->mu; rate.part = rate_job->part; rate.g = rate_job->g;
+    rate.nwg = rate.b.first_wg[rate.b.nlayers];
+  }
+  step_head_kernel<<<rate.nwg + wpl * nlayers + wpl * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
+      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl, rate);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -205,6 +205,27 @@ __global__ __launch_bounds__(C0::NT) void wgrad_tiled2_kernel(WgTiled2 m) {
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Tile staging through buffer loads: the descriptor (base of the batch element, its size) and the per-segment offset
+// are wave-uniform and live in scalar registers, the per-thread part is ONE constant voffset -- a load is an s_add and
+// a buffer_load, no vector address arithmetic (flat loads cost ~4 VALU instructions + waits per element: 64-bit
+// per-lane adds, 13 % of the conv2 gradient's time).  A lane that has nothing to fetch carries a voffset beyond the
+// descriptor's range: the range check returns 0 for it.
+#ifndef NVF_WG_BUF
+#define NVF_WG_BUF 1
+#endif
+constexpr int kWgOob = 0x7ffffff0;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float wg_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wg_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const wg_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 #ifndef NVF_WG_EPI_REGIONS
 #define NVF_WG_EPI_REGIONS 1
 #endif
@@ -266,6 +287,31 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
     const int e = tid + part * 256;
     xlo[part] = (e / (W + 3)) * XRS + e % (W + 3);
   }
+#if NVF_WG_BUF
+  // dY: thread t owns float4 (xq, yy, zz, c0) of the tile, c = c0 + u * CSTEP; X: word e = tid (+ 256 part) of a segment
+  constexpr int PER = (W / 4) * TY * TZ, CSTEP = 256 / PER;
+  static_assert(256 % PER == 0 && NG4 % 256 == 0, "a thread's dY float4s differ by whole channels");
+  const int gxq = tid % (W / 4), gr = tid / (W / 4), gyy = gr % TY, gt2 = gr / TY, gzz = gt2 % TZ, gc0 = gt2 / TZ;
+  const int gvoff = (((gc0 * W + gzz) * W + gyy) * W + 4 * gxq) * 4;
+  int xvoff[PPS];
+#pragma unroll
+  for (int part = 0; part < PPS; ++part) xvoff[part] = tid + part * 256 < SEG ? (tid + part * 256) * 4 : kWgOob;
+  auto load = [&](int item) {
+    const int n = item / tiles, t = item % tiles;
+    const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
+    const __amdgpu_buffer_rsrc_t rg = wg_rsrc(g + (size_t)n * 8 * W * W * W, 8 * W * W * W * 4);
+    const int gs = ((z0 * W + y0) * W) * 4;
+#pragma unroll
+    for (int u = 0; u < UG; ++u) gv[u] = wg_ld4(rg, gvoff, gs + u * CSTEP * W * W * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = wg_rsrc(x + (size_t)n * 8 * WQ * WQ * WQ, 8 * WQ * WQ * WQ * 4);
+    const int xs = ((z0 * WQ + y0) * WQ) * 4;
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int seg = u / PPS, part = u % PPS, c = seg / (TZ + 3), zz = seg % (TZ + 3);
+      xv[u] = wg_ld(rx, xvoff[part], xs + (c * WQ + zz) * WQ * WQ * 4);
+    }
+  };
+#else
   auto load = [&](int item) {
     const int n = item / tiles, t = item % tiles;
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
@@ -285,6 +331,7 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
       xv[u] = e < SEG ? xt[(c * WQ + zz) * WQ * WQ + e] : 0.f;
     }
   };
+#endif
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
@@ -472,6 +519,31 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
     const int e = tid + part * 256;
     glo[part] = (e / WG) * GRS + e % WG;
   }
+#if NVF_WG_BUF
+  // g: word e = tid (+ 256 part) of a segment; x: thread t owns element (xx, yy, zz, c0), c = c0 + u * CSTEP
+  constexpr int PERX = W * TY * TZ, CSTEP = 256 / PERX;
+  static_assert(256 % PERX == 0 && C::NXE % 256 == 0, "a thread's x elements differ by whole channels");
+  const int xxx = tid % W, xr = tid / W, xyy = xr % TY, xt2 = xr / TY, xzz = xt2 % TZ, xc0 = xt2 / TZ;
+  const int xvoff = (((xc0 * W + xzz) * W + xyy) * W + xxx) * 4;
+  int gvoff[C::PPS];
+#pragma unroll
+  for (int part = 0; part < C::PPS; ++part) gvoff[part] = tid + part * 256 < C::SEG ? (tid + part * 256) * 4 : kWgOob;
+  auto load = [&](int item) {
+    const int n = item / tiles, t = item % tiles;
+    const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
+    const __amdgpu_buffer_rsrc_t rg = wg_rsrc(g + (size_t)n * 8 * WG * WG * WG, 8 * WG * WG * WG * 4);
+    const int gs = ((2 * z0 * WG + 2 * y0) * WG) * 4;
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int seg = u / C::PPS, part = u % C::PPS, c = seg / GZ, zz = seg % GZ;
+      gv[u] = wg_ld(rg, gvoff[part], gs + (c * WG + zz) * WG * WG * 4);
+    }
+    const __amdgpu_buffer_rsrc_t rx = wg_rsrc(x + (size_t)n * 8 * W * W * W, 8 * W * W * W * 4);
+    const int xs = ((z0 * W + y0) * W) * 4;
+#pragma unroll
+    for (int u = 0; u < UX; ++u) xv[u] = wg_ld(rx, xvoff, xs + u * CSTEP * W * W * W * 4);
+  };
+#else
   auto load = [&](int item) {
     const int n = item / tiles, t = item % tiles;
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
@@ -490,6 +562,7 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
       xv[u] = e < C::NXE ? xn[(((size_t)c * W + z0 + zz) * W + y0 + yy) * W + xx] : 0.f;
     }
   };
+#endif
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
@@ -892,8 +965,10 @@ extern "C" int nvf_wgrad_partial(const float* p, const float* q, float* dw, void
 struct WgReduceMulti {
   const float* slabs[16];
   float* dw[16];
+  const float* add[16];        // optional addend per gradient (the weight-rate term's gradient), or null
   int32_t nslab[16], jtotal[16], blk_base[17];
-  int32_t n;
+  int32_t n, fuse;             // fuse: apply `adam` to every element written
+  NvfAdamFuse adam;
 };
 
 // same arithmetic as wgrad_reduce (16 interleaved slices in ascending slab order, then slices 0..15)
@@ -920,11 +995,20 @@ __device__ __forceinline__ void wgrad_reduce_multi_body(const WgReduceMulti& d, 
   const float s = (s0 + s1) + (s2 + s3);
   part[sl][jl] = s;
   __syncthreads();
-  if (sl == 0 && j < jtotal) {
-    float v = part[0][jl];
+  if (sl == 0) {
+    int bad = 0;
+    if (j < jtotal) {
+      float v = part[0][jl];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v += part[k][jl];
-    d.dw[t][j] = v;
+      for (int k = 1; k < 16; ++k) v += part[k][jl];
+      if (d.add[t]) v += d.add[t][j];
+      d.dw[t][j] = v;
+      if (d.fuse) bad = adam_fused_elem(d.adam, d.dw[t] + j, v);
+    }
+    if (d.fuse && d.adam.bad_count) {          // wave 0 of the workgroup: integer-valued, order-free
+      const unsigned long long any = __ballot(bad);
+      if (any && jl == 0) atomicAdd(d.adam.bad_count, (float)__popcll(any));
+    }
   }
 }
 
@@ -1147,6 +1231,16 @@ extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float*
                                                const int* jtotals, int n, const float* const* xs, float* const* outs,
                                                const int* channels, const int* spatials, int ntensors, int batch,
                                                void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
+  return nvf_wgrad_reduce_multi_and_sums_fused(slabs, dws, nslabs, jtotals, n, nullptr, nullptr, xs, outs, channels,
+                                               spatials, ntensors, batch, workspace, workspace_bytes, ctx, stream);
+}
+
+extern "C" int nvf_wgrad_reduce_multi_and_sums_fused(const float* const* slabs, float* const* dws, const int* nslabs,
+                                                     const int* jtotals, int n, const float* const* addends,
+                                                     const NvfAdamFuse* adam, const float* const* xs,
+                                                     float* const* outs, const int* channels, const int* spatials,
+                                                     int ntensors, int batch, void* workspace, size_t workspace_bytes,
+                                                     NvfStepCtx* ctx, void* stream) {
   if (!slabs || !dws || !nslabs || !jtotals || n <= 0 || n > 16) return NVF_EINVAL;
   if (!xs || !outs || !channels || !spatials || ntensors <= 0 || ntensors > 12 || batch <= 0 || !workspace)
     return NVF_EINVAL;
@@ -1156,12 +1250,18 @@ extern "C" int nvf_wgrad_reduce_multi_and_sums(const float* const* slabs, float*
     if (nslabs[i] == 0) continue;
     if (!slabs[i] || !dws[i] || nslabs[i] < 0 || jtotals[i] <= 0) return NVF_EINVAL;
     r.slabs[m] = slabs[i]; r.dw[m] = dws[i]; r.nslab[m] = nslabs[i]; r.jtotal[m] = jtotals[i];
+    r.add[m] = addends ? addends[i] : nullptr;
     r.blk_base[m] = base;
     base += (jtotals[i] + 63) / 64;
     ++m;
   }
   r.blk_base[m] = base;
   r.n = m;
+  if (adam) {
+    if (!adam->g_base || !adam->p_base || !adam->m_base || !adam->v_base || adam->n <= 0) return NVF_EINVAL;
+    r.fuse = 1;
+    r.adam = *adam;
+  }
   MultiSumDesc d{};
   int cb = 0;
   for (int i = 0; i < ntensors; ++i) {

@@ -110,6 +110,11 @@ class TrainEngine:
         self.ctx = ops.StepCtx()  # deferred final passes + queued latent tail of the step in flight (caller-owned)
         self.epoch_acc = None     # float[16] epoch sums written by nvf_step_tail (enable_epoch_stats)
         self._tail_done = torch.zeros(2, dtype=torch.int32, device=self.dev)   # nvf_step_tail's arrival counter
+        self._rate = None         # (NvfRateJob, {gk data_ptr: its weight-rate gradient}, rate_grad_scale) of the step head
+        self._rate_ready = False  # the step head of the step in flight carried the weight-rate partial pass
+        self.tail_done = False    # the last backward pass applied the optimiser itself (fused tail)
+        self._stem_gdn_in_finals = False
+        self._tail_ranges = {}    # gradient index ranges no fused launch covers, per set of covered intervals
         self.collective_mode = None   # "graph" / "host": where GraphedTrainStep puts the all-reduce (dist.attach)
         # the three classifier heads go through the one-launch kernels (instantiated for the two decoders of BASELINE.json);
         # the one-launch trunk weight gradients exist for the narrow decoder only
@@ -224,8 +229,28 @@ class TrainEngine:
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.dev)
         self.nlayers = len(mods)
 
-    def batch_and_prepare(self, idx_dev, q):
-        """_batch(idx_dev) and prepare_weights(q) -- row gather, effective weights, MFMA packings -- as ONE launch."""
+    def _rate_job(self):
+        """The weight-rate term's partial pass as a job of the step head: it reads parameters only.  g is a host
+        constant (lambda w2 / N, times 1 / world under data parallelism)."""
+        key = (self.rate_grad_scale, self.lmbda, self.w2, self.n_points_total)
+        if self._rate is None or self._rate[2] != key:
+            lm = self.net.reconstructor.likelihood_model
+            ks = [self.layers[n].mod.kernel for n in TRUNK]
+            dk = torch.zeros(sum(k.numel() for k in ks), device=self.dev)
+            dks, off = [], 0
+            for k in ks:
+                dks.append(dk[off:off + k.numel()])
+                off += k.numel()
+            part = torch.zeros(3 * 512, device=self.dev)
+            g = self.lmbda * self.w2 / self.n_points_total * self.rate_grad_scale
+            job = ops.rate_job(ks, dks, lm.sigma, lm.mu, part, g)
+            add = {self.layers[n].gk.data_ptr(): d for n, d in zip(TRUNK, dks)}
+            self._rate = (job, add, key, dk, part)
+        return self._rate
+
+    def batch_and_prepare(self, idx_dev, q, with_rate=False):
+        """_batch(idx_dev) and prepare_weights(q) -- row gather, effective weights, MFMA packings -- as ONE launch
+        (``with_rate``: + the weight-rate term's partial sums, consumed by the backward pass of the same step)."""
         import ctypes
         srcs = [self.gt, self.dist, self.gt16, self.gt8, self.emb]
         n, rows = len(srcs), idx_dev.numel()
@@ -241,7 +266,9 @@ class TrainEngine:
             iarr([j[3] for j in jobs]), iarr([j[4] for j in jobs]), iarr([m[0] for m in meta]),
             iarr([m[1] for m in meta]), npk, (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
             (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_int * n)(*[s[0].numel() for s in srcs]), n,
-            idx_dev.data_ptr(), rows, torch.cuda.current_stream().cuda_stream), "nvf_step_head")
+            idx_dev.data_ptr(), rows, ctypes.byref(self._rate_job()[0]) if with_rate else None,
+            torch.cuda.current_stream().cuda_stream), "nvf_step_head")
+        self._rate_ready = bool(with_rate)
         return dsts
 
     def prepare_weights(self, q):
@@ -374,7 +401,7 @@ class TrainEngine:
             self.ctx.cancel()              # never leave final passes or a latent tail queued in the context
             raise
 
-    def _backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb):
+    def _backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb, tail=None):
         """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g.
 
         Main stream: the backward-data chain.  Side stream: head backward-data (t0, t1), every weight gradient,
@@ -471,6 +498,7 @@ class TrainEngine:
         ig = net.reconstructor.activation
         gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
         gamma_view = None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape)
+        self._stem_gdn_in_finals = bool(self.fused_stem and defer and want_w)
         if self.fused_stem and defer:        # its final launch is shared with the slab reduction / the final passes
             da0, dx0 = ops.stem_bwd_partial(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta,
                                             ig.gamma, gview("reconstructor.activation.beta"), gamma_view,
@@ -530,20 +558,82 @@ class TrainEngine:
         g_net = self.lmbda * self.w2 / self.n_points_total
         gs, gm = self._g("reconstructor.likelihood_model.sigma"), self._g("reconstructor.likelihood_model.mu")
         kernels = [Ls[n].mod.kernel for n in TRUNK]
+        rate_head, self._rate_ready = self._rate_ready and want_w and defer, False
+        fused = None
         self._fork()
         with self._on_side():
             if want_w:     # slab reduction of every weight gradient + all bias sums
-                self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
-                ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
-                                      g_host=g_net * self.rate_grad_scale, ctx=ctx)
+                addends = None
+                if rate_head:
+                    # the weight-rate gradient was computed by the step head: the reduction adds it while it writes the
+                    # gradients (every trunk kernel must come out of that launch; otherwise the stand-alone pass)
+                    job, addends = self._rate_job()[:2]
+                    live = {j[1] for j in self._wg.jobs if j[2] > 0}
+                    if not all(Ls[n].gk.data_ptr() in live for n in TRUNK) or len(self._wg.jobs) > 16:
+                        rate_head, addends = False, None
+                if tail is not None and rate_head:
+                    fused = self._fused_tail(tail, loss, a["lbits"], nbits, gs, gm)
+                self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs],
+                                          addends=addends, adam=None if fused is None else fused[1])
+                if rate_head:
+                    ops.weight_rate_final(job, nbits, gs, gm, ctx=ctx)
+                else:
+                    ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
+                                          g_host=g_net * self.rate_grad_scale, ctx=ctx)
             else:
                 ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
             if defer:
-                self.ctx.flush()
+                if fused is not None:
+                    self.ctx.flush_tail(fused[0], fused[2])
+                else:
+                    self.ctx.flush()
+        self.tail_done = fused is not None
         if self.overlap:
             main.wait_stream(self.side)      # join: nothing below (Adam, frees) may pass the side work
         self.last = {"loss_terms": loss, "latent_bits": a["lbits"], "net_bits": nbits, "n_pts": n_pts}
         return de
+
+    def _fused_tail(self, tail, loss, lbits, nbits, gs, gm):
+        """(NvfStepTail, NvfAdamFuse, uncovered ranges) for a step whose optimiser rides in the slab reduction (weight
+        gradients) and in the finals launch (everything those final passes write + the ranges): single-GPU steps only.
+        ``tail``: dict(coef_dev= / coef_host=, inv_npts_dev= / inv_npts_host=, sched=)."""
+        stats = self.epoch_acc is not None
+        t = ops.step_tail_args(self.flat_p, self.flat_g, self.flat_m, self.flat_v, tail.get("coef_dev"),
+                               tail.get("coef_host", (0.0, 0.0)), loss_terms=loss if stats else None,
+                               lbits=lbits if stats else None, nbits=nbits if stats else None,
+                               inv_npts_dev=tail.get("inv_npts_dev"), inv_npts_host=tail.get("inv_npts_host", 1.0),
+                               nbits_scale=1.0 / self.n_points_total, counts=self.step_counts if stats else None,
+                               acc=self.epoch_acc, done=self._tail_done, sched=tail.get("sched"))
+        base, esz = self.flat_g.data_ptr(), 4
+        cover = []
+        for j in self._wg.jobs:
+            if j[2] > 0:
+                cover.append(((j[1] - base) // esz, (j[1] - base) // esz + j[3]))
+        for _, o in self._bias_jobs:
+            cover.append(((o.data_ptr() - base) // esz, (o.data_ptr() - base) // esz + o.numel()))
+        for g1 in (gs, gm):
+            cover.append(((g1.data_ptr() - base) // esz, (g1.data_ptr() - base) // esz + g1.numel()))
+        if self._stem_gdn_in_finals:
+            for name in ("reconstructor.activation.beta", "reconstructor.activation.gamma"):
+                off, cnt = self.slices[name]
+                cover.append((off, off + cnt))
+        n = self.flat_g.numel()
+        key = tuple(sorted(c for c in cover if 0 <= c[0] < n))
+        ranges = self._tail_ranges.get(key)
+        if ranges is None:
+            ranges, pos = [], 0
+            for lo, hi in key:
+                if lo < pos:
+                    raise RuntimeError("fused tail: two launches write the same gradient elements")
+                if lo > pos:
+                    ranges.append((pos, lo))
+                pos = hi
+            if pos < n:
+                ranges.append((pos, n))
+            if len(ranges) > 16:
+                raise RuntimeError("fused tail: more than 16 uncovered gradient ranges")
+            self._tail_ranges[key] = ranges
+        return t, ops.adam_fuse_args(t), ranges
 
     # ------------------------------------------------------------------ steps
     def _batch(self, idx_dev):
@@ -636,9 +726,16 @@ class TrainEngine:
                 idx_dev = torch.from_numpy(idx_host).to(self.dev)
             if n_pts is None:
                 n_pts = float(self.counts[idx_host].sum())
-            gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q)
+            gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q, with_rate=not self.allow_overlap)
             a = self.forward(e, "train", idx_dev)
-            self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False)
+            tail = None
+            if update and self.grad_hook is None and not self.allow_overlap:
+                # single GPU: the optimiser rides in the slab reduction and the finals launch (no all-reduce in between)
+                tail = dict(coef_host=ops.adam_coefficients(self.lr, self.opt_step + 1), inv_npts_host=1.0 / n_pts)
+            self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False, tail=tail)
+            if tail is not None and self.tail_done:
+                self.opt_step += 1
+                update = False
         if update:
             self._tail(n_pts)
         elif self.grad_hook is not None:
@@ -751,12 +848,15 @@ class GraphedTrainStep:
 
     def _body(self, tail):
         eng = self.eng
-        gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q)
+        gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q, with_rate=not eng.allow_overlap)
         a = eng.forward(e, "train", self.idx)
-        eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False)
+        spec = None
+        if tail and eng.grad_hook is None and not eng.allow_overlap:      # single GPU: no launch of its own for the tail
+            spec = dict(coef_dev=self.coef, inv_npts_dev=self.inv_npts, sched=(self.buf, self.rows, self.cursor, self.nw))
+        eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False, tail=spec)
         self.out = a
         self.last = dict(eng.last)
-        if tail:
+        if tail and not (spec is not None and eng.tail_done):
             self._tail()
 
     def _tail(self):

@@ -74,6 +74,16 @@ class StepCtx:
         """Run the queued final passes in one launch on the current stream."""
         check(lib().nvf_finals_flush(self.ptr, _stream()), "nvf_finals_flush")
 
+    def flush_tail(self, tail, ranges):
+        """flush() + the optimiser / epoch statistics / schedule hand-over of the step in the same launch
+        (nvf_finals_flush_tail): ``tail`` is the NvfStepTail of ops.step_tail_args, ``ranges`` the [lo, hi) index ranges
+        of gradient elements no fused launch covers."""
+        import ctypes
+        flat = [int(v) for r in ranges for v in r]
+        arr = (ctypes.c_int64 * max(len(flat), 1))(*flat)
+        check(lib().nvf_finals_flush_tail(self.ptr, ctypes.byref(tail), arr, len(ranges), _stream()),
+              "nvf_finals_flush_tail")
+
     def cancel(self):
         lib().nvf_finals_cancel(self.ptr)
         lib().nvf_latent_tail_cancel(self.ptr)
@@ -595,11 +605,15 @@ class WgradBatch:
         for h in range(3):
             self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], cs[h] * 27))
 
-    def finish_with_sums(self, tensors, outs):
-        """finish() and multi_channel_sum(tensors, outs) with the reduction and the partial bias sums in one launch."""
+    def finish_with_sums(self, tensors, outs, addends=None, adam=None):
+        """finish() and multi_channel_sum(tensors, outs) with the reduction and the partial bias sums in one launch.
+        ``addends``: {gradient data_ptr: tensor added to that gradient}; ``adam``: NvfAdamFuse applied to every weight
+        gradient element written (both need the one-launch form: <= 16 jobs)."""
         import ctypes
         jobs = self.jobs
         if not jobs or len(jobs) > 16 or not tensors:
+            if addends or adam is not None:
+                raise RuntimeError("finish_with_sums: addends / fused Adam need the one-launch reduction")
             self.finish()
             if tensors:
                 multi_channel_sum(tensors, outs, ctx=self.ctx)
@@ -610,12 +624,17 @@ class WgradBatch:
         n, nt = len(jobs), len(tensors)
         total = sum(t.shape[1] for t in tensors)
         ws = workspace(lib().nvf_multi_channel_sum_workspace(total), tensors[0].device, "mchsum", self.ctx)
-        check(lib().nvf_wgrad_reduce_multi_and_sums(
+        adds = None
+        if addends:
+            adds = (ctypes.c_void_p * n)(*[(addends[j[1]].data_ptr() if (j[1] in addends and j[2] > 0) else None)
+                                           for j in jobs])
+        check(lib().nvf_wgrad_reduce_multi_and_sums_fused(
             (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
-            (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n,
+            (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n, adds,
+            None if adam is None else ctypes.byref(adam),
             _parr(tensors), _parr(outs), _iarr([t.shape[1] for t in tensors]), _iarr([t[0, 0].numel() for t in tensors]),
             nt, tensors[0].shape[0], _ptr(ws), ws.numel(), _ctx(self.ctx), _stream()),
-            "nvf_wgrad_reduce_multi_and_sums")
+            "nvf_wgrad_reduce_multi_and_sums_fused")
 
     def finish(self):
         import ctypes
@@ -869,6 +888,15 @@ def step_tail(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, 
     non-finite counters in ``acc`` [16], and the hand-over to the next step of a device-resident schedule
     (``sched`` = (buf, rows, cursor, words); see NvfStepTail in include/nvf_hip.h)."""
     import ctypes
+    a = step_tail_args(p, g, m, v, coef_dev, coef_host, loss_terms, lbits, nbits, inv_npts_dev, inv_npts_host,
+                       nbits_scale, counts, acc, done, sched, beta1, beta2, eps)
+    check(lib().nvf_step_tail(ctypes.byref(a), _stream()), "nvf_step_tail")
+
+
+def step_tail_args(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, lbits=None, nbits=None,
+                   inv_npts_dev=None, inv_npts_host=1.0, nbits_scale=1.0, counts=None, acc=None, done=None, sched=None,
+                   beta1=0.9, beta2=0.999, eps=1e-8):
+    """The NvfStepTail struct behind step_tail / StepCtx.flush_tail (the tensors must outlive the launch)."""
     from ._lib import NvfStepTail
     _f32(p, g, m, v, coef_dev, loss_terms, lbits, nbits, inv_npts_dev, counts, acc)
     a = NvfStepTail()
@@ -886,7 +914,39 @@ def step_tail(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, 
         buf, rows, cursor, words = sched
         _chk(buf, rows, cursor)
         a.sched_buf, a.sched_rows, a.sched_cursor, a.sched_words = buf.data_ptr(), rows.data_ptr(), cursor.data_ptr(), int(words)
-    check(lib().nvf_step_tail(ctypes.byref(a), _stream()), "nvf_step_tail")
+    return a
+
+
+def adam_fuse_args(tail):
+    """NvfAdamFuse with the optimiser state of an NvfStepTail (for WgradBatch.finish_with_sums)."""
+    from ._lib import NvfAdamFuse
+    a = NvfAdamFuse()
+    a.g_base, a.p_base, a.m_base, a.v_base, a.n = tail.g, tail.p, tail.m, tail.v, tail.n
+    a.coef_dev, a.coef0_host, a.coef1_host = tail.coef_dev, tail.coef0_host, tail.coef1_host
+    a.beta1, a.beta2, a.eps = tail.beta1, tail.beta2, tail.eps
+    a.bad_count = (tail.acc + 6 * 4) if tail.acc else None
+    return a
+
+
+def rate_job(kernels, dks, sigma, mu, part, g):
+    """NvfRateJob: the weight-rate term's partial pass for nvf_step_head (dks[l] receives g dbits/dk, overwritten)."""
+    from ._lib import NvfRateJob
+    _f32(*kernels, *[d for d in dks if d is not None], sigma, mu, part)
+    j = NvfRateJob()
+    for i, k in enumerate(kernels):
+        j.kernel[i], j.n[i] = k.data_ptr(), k.numel()
+        j.dk[i] = None if dks[i] is None else dks[i].data_ptr()
+    j.nlayers = len(kernels)
+    j.sigma, j.mu, j.part, j.g = sigma.data_ptr(), mu.data_ptr(), part.data_ptr(), float(g)
+    return j
+
+
+def weight_rate_final(job, bits, dsigma=None, dmu=None, ctx=None):
+    """Final pass of a rate job whose partial sums nvf_step_head computed (queued in ``ctx`` while it defers)."""
+    import ctypes
+    _f32(bits, dsigma, dmu)
+    check(lib().nvf_weight_rate_batch_final(ctypes.byref(job), _ptr(bits), _ptr(dsigma), _ptr(dmu), _ctx(ctx), _stream()),
+          "nvf_weight_rate_batch_final")
 
 
 def gather_rows(src, idx):

@@ -26,7 +26,7 @@ def main():
     torch.cuda.set_device(dev)
     for K in [int(k) for k in a.ks.split(",")]:
         b = a.total // K
-        args = SimpleNamespace(ch=3, chanstr="8,16,8,8", blocks=256, distinct=64)
+        args = SimpleNamespace(ch=3, chanstr="8,16,8,8", blocks=256, distinct=64, force_collective=False)
         engs = [bench.build_engine(args, dev, 1) for _ in range(K)]
         streams = [torch.cuda.Stream() for _ in range(K)]
         graphed = []
