@@ -518,6 +518,18 @@ __global__ void weight_rate_batch_final(WeightRateBatch b, const float* __restri
   weight_rate_batch_final_body(b, part, sigma, bits, dsigma, dmu, g_dev, g_host, threadIdx.x);
 }
 
+extern "C" int nvf_weight_rate_batch_final(const NvfRateJob* job, float* bits, float* dsigma, float* dmu,
+                                           NvfStepCtx* ctx, void* stream) {
+  if (!job || !bits || !job->sigma || !job->mu || !job->part) return NVF_EINVAL;
+  WeightRateBatch b{};
+  const int rc = weight_rate_batch_desc(job->kernel, job->dk, job->n, job->nlayers, b);
+  if (rc != NVF_OK) return rc;
+  if (!nvf_finals_push_rate(ctx, b, job->part, job->sigma, bits, dsigma, dmu, nullptr, job->g))
+    weight_rate_batch_final<<<1, 64, 0, nvf_stream(stream)>>>(b, job->part, job->sigma, bits, dsigma, dmu, nullptr, job->g);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 extern "C" size_t nvf_weight_rate_batch_workspace(void) { return (size_t)3 * 512 * sizeof(float); }
 
 extern "C" int nvf_weight_rate_batch(const float* const* kernels, float* const* dks, const int* ns, int nlayers,
