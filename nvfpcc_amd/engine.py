@@ -401,7 +401,7 @@ class TrainEngine:
             self.ctx.cancel()              # never leave final passes or a latent tail queued in the context
             raise
 
-    def _backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb, tail=None):
+    def _backward(self, a, gt, dist, gt16, gt8, n_pts, mode, block_ids, want_w, want_emb, fuse=None):
         """Loss (NVFPCC.py:161-196) and its gradients.  Weight grads land in self.flat_g.
 
         Main stream: the backward-data chain.  Side stream: head backward-data (t0, t1), every weight gradient,
@@ -571,8 +571,8 @@ class TrainEngine:
                     live = {j[1] for j in self._wg.jobs if j[2] > 0}
                     if not all(Ls[n].gk.data_ptr() in live for n in TRUNK) or len(self._wg.jobs) > 16:
                         rate_head, addends = False, None
-                if tail is not None and rate_head:
-                    fused = self._fused_tail(tail, loss, a["lbits"], nbits, gs, gm)
+                if fuse is not None and rate_head:
+                    fused = self._fused_tail(fuse, loss, a["lbits"], nbits, gs, gm)
                 self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs],
                                           addends=addends, adam=None if fused is None else fused[1])
                 if rate_head:
@@ -732,7 +732,7 @@ class TrainEngine:
             if update and self.grad_hook is None and not self.allow_overlap:
                 # single GPU: the optimiser rides in the slab reduction and the finals launch (no all-reduce in between)
                 tail = dict(coef_host=ops.adam_coefficients(self.lr, self.opt_step + 1), inv_npts_host=1.0 / n_pts)
-            self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False, tail=tail)
+            self.backward(a, gt, dist, gt16, gt8, n_pts, "train", idx_dev, want_w=True, want_emb=False, fuse=tail)
             if tail is not None and self.tail_done:
                 self.opt_step += 1
                 update = False
@@ -853,7 +853,7 @@ class GraphedTrainStep:
         spec = None
         if tail and eng.grad_hook is None and not eng.allow_overlap:      # single GPU: no launch of its own for the tail
             spec = dict(coef_dev=self.coef, inv_npts_dev=self.inv_npts, sched=(self.buf, self.rows, self.cursor, self.nw))
-        eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False, tail=spec)
+        eng.backward(a, gt, dist, gt16, gt8, 1.0, "train", self.idx, want_w=True, want_emb=False, fuse=spec)
         self.out = a
         self.last = dict(eng.last)
         if tail and not (spec is not None and eng.tail_done):
