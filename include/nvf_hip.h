@@ -288,6 +288,11 @@ int nvf_wgrad_up1_conv0_partial(const float* const* ps, const float* const* qs, 
  * separate launches.  Like nvf_wgrad_mfma3_partial it carries a queued latent tail as its first workgroup. */
 int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                              int* nslabs, NvfStepCtx* ctx, void* stream);
+/* ... and, with bias_slabs[0] / bias_slabs[2] non-NULL (entry 1 is ignored), the per-workgroup channel sums of conv2's
+ * / conv1's dY: nslabs[j] slabs of 8 floats each, whose sum (a jtotal = 8 job of nvf_wgrad_reduce_multi) is that
+ * layer's bias gradient -- the kernel holds every dY tile in registers, and its tiles partition dY. */
+int nvf_wgrad_trunk5_partial_bias(const float* const* ps, const float* const* qs, float* const* slabs,
+                                  float* const* bias_slabs, int batch, int* nslabs, NvfStepCtx* ctx, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */

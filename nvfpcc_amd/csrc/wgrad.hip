@@ -32,6 +32,8 @@ struct WgDims {
   int tiles_x, tiles_y, tiles_z;
   int items, items_per_wg; // work items (n, tile) and how many each workgroup walks
   int out_mode, jtotal;    // slab layout, slab length A*Bc*K^3
+  float* bias_slab;        // matrix-core 4^3 gradient only, optional: per workgroup the 8 channel sums of the dY tiles it
+                           // walked (the layer's bias gradient: the items partition dY) -- slab [workgroup][8]
 };
 
 // general shape, one WAVE per output: lanes stride over the (n, iz, iy, ix) positions, fixed-order wave sum
@@ -332,6 +334,9 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
     }
   };
 #endif
+  float bsum[UG];                                         // channel sums of dY (this thread's float4s), per u
+#pragma unroll
+  for (int u = 0; u < UG; ++u) bsum[u] = 0.f;
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
@@ -340,6 +345,7 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
         const int xq = i % (W / 4), r = i / (W / 4), c = r / (TZ * TY);
         float* dst = ldsG + c * GCS + (r - c * TZ * TY) * GRS + 4 * xq + 1;      // u = x + 1
         dst[0] = gv[u].x; dst[1] = gv[u].y; dst[2] = gv[u].z; dst[3] = gv[u].w;
+        bsum[u] += (gv[u].x + gv[u].y) + (gv[u].z + gv[u].w);
       }
     }
 #pragma unroll
@@ -393,6 +399,25 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
           for (int t2 = 0; t2 < 16; ++t2) b_cur[t2] = b_nxt[t2];
         }
       }
+    }
+  }
+  // the layer's bias gradient, this workgroup's share: thread t holds channels c0 + u * CSTEP (c0 = t / PER);
+  // wave sums, then the waves of one c0 in ascending order -- a fixed order
+  if (d.bias_slab) {
+    constexpr int PERB = (W / 4) * TY * TZ, CSTEPB = 256 / PERB, WPC = PERB / 64;
+    static_assert(PERB % 64 == 0 && 256 % PERB == 0, "whole waves per channel group");
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const float w = nvf_wave_sum(bsum[u]);
+      if (lane == 0) lds[wave * UG + u] = w;
+    }
+    __syncthreads();
+    if (tid < 8) {
+      const int c0 = tid % CSTEPB, u = tid / CSTEPB;
+      float t = 0.f;
+      for (int w = 0; w < WPC; ++w) t += lds[(c0 * WPC + w) * UG + u];
+      d.bias_slab[(size_t)bx * 8 + tid] = t;
     }
   }
   // cross-wave sum through LDS (reusing the staging area), then one slab per workgroup.  Every wave drops its 4096
@@ -705,7 +730,8 @@ static void fill_up1_conv0(WgTiled2& m, const float* const* ps, const float* con
 
 // njobs = 3: conv2, up2, conv1 (matrix cores); njobs = 5: + up1, conv0 (the VALU tile kernel with 256-thread workgroups)
 static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
-                               int* nslabs, int njobs, NvfStepCtx* ctx, void* stream) {
+                               int* nslabs, int njobs, NvfStepCtx* ctx, void* stream,
+                               float* const* bias_slabs = nullptr) {
   if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
   using C0 = MCfg<32, 4, 4>; using T1 = TWCfg<2, 2>; using C2 = MCfg<16, 2, 8>;
   using U0 = WCfg<16, 5, 2, 2, 8, 4, 2, 0>; using U1 = WCfg<8, 5, 2, 2, 4, 4, 4, 0>;
@@ -729,6 +755,7 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     int n = items[j] < cap ? items[j] : cap;
     d.items_per_wg = (items[j] + n - 1) / n;
     n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
+    if (bias_slabs && j != 1) d.bias_slab = bias_slabs[j];     // conv2 (job 0) and conv1 (job 2): p = dY
     m.d[j] = d; m.n[j] = n; nslabs[j] = n;
   }
   WgTiled2 u{};
@@ -761,6 +788,15 @@ extern "C" int nvf_wgrad_mfma3_partial(const float* const* ps, const float* cons
 extern "C" int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                                         int* nslabs, NvfStepCtx* ctx, void* stream) {
   return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream);
+}
+
+// ... and, with bias_slabs[0] / bias_slabs[2] (either may be NULL; entry 1 is ignored), the channel sums of conv2's and
+// conv1's dY per workgroup: nslabs[j] slabs of 8 floats whose sum (nvf_wgrad_reduce_multi, jtotal 8) is the bias
+// gradient of that layer -- the kernel holds every dY tile in registers anyway, and the tiles partition dY.
+extern "C" int nvf_wgrad_trunk5_partial_bias(const float* const* ps, const float* const* qs, float* const* slabs,
+                                             float* const* bias_slabs, int batch, int* nslabs, NvfStepCtx* ctx,
+                                             void* stream) {
+  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream, bias_slabs);
 }
 
 template <class C>

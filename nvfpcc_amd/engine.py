@@ -478,8 +478,9 @@ class TrainEngine:
         if ev_t1 is not None:
             main.wait_event(ev_t1)
         g3 = self._dx_convT(Ls["up2"], g4, a["y3"], mask=a["y3"], addend=t1)
-        if wg3:     # launched after the latent tail has been queued (below): the tail rides in that launch
-            self._bias_jobs += [(g5, Ls["conv2"].gb), (g4, Ls["up2"].gb), (g3, Ls["conv1"].gb)]
+        if wg3:     # launched after the latent tail has been queued (below): the tail rides in that launch; the bias
+            # gradients of conv2 and conv1 (channel sums of g5, g3) come out of it too
+            self._bias_jobs += [(g4, Ls["up2"].gb)]
         else:
             side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
         g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
@@ -551,7 +552,8 @@ class TrainEngine:
             # and is hidden behind them instead of being the critical path of the slab reduction; up1's and conv0's
             # gradients (small VALU kernels) fill the slots that the short matrix-core workgroups leave
             self._wg.add_trunk5([g5, a["y3"], g3, a["y1"], a["h0"]], [a["y4"], g4, a["y2"], g2, g1],
-                                [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk])
+                                [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk],
+                                bias_outs=(Ls["conv2"].gb, Ls["conv1"].gb))
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
         # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model

@@ -559,13 +559,15 @@ class WgradBatch:
         """up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch, two reduction jobs."""
         self._grouped(lib().nvf_wgrad_up1_conv0_partial, "nvf_wgrad_up1_conv0_partial", ps, qs, outs, (16000, 16000), 512)
 
-    def add_trunk5(self, ps, qs, outs):
+    def add_trunk5(self, ps, qs, outs, bias_outs=None):
         """conv2 / up2 / conv1 / up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch (which also
-        carries a queued latent tail), five reduction jobs.  ps/qs/outs: add_mfma3's three, then add_up1_conv0's two."""
+        carries a queued latent tail), five reduction jobs.  ps/qs/outs: add_mfma3's three, then add_up1_conv0's two.
+        ``bias_outs`` = (conv2's bias gradient, conv1's): the launch also leaves the channel sums of their dY (two more
+        reduction jobs of 8 floats) -- nobody has to read those two tensors again for the bias sums."""
         import ctypes
         _f32(*ps, *qs, *outs)
         B = ps[0].shape[0]
-        jt = (4096, 8000, 4096, 16000, 16000)
+        jt = (4096, 8000, 4096, 16000, 16000) + ((8, 8) if bias_outs is not None else ())
         sizes = [(512 * j * 4 + 255) // 256 * 256 for j in jt]
         if self.offset + sum(sizes) > self.ws.numel():
             if self.jobs:
@@ -577,10 +579,19 @@ class WgradBatch:
             bases.append(self.ws.data_ptr() + self.offset)
             self.offset += sz
         nsl = (ctypes.c_int * 5)()
-        check(lib().nvf_wgrad_trunk5_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases), B, nsl,
-                                             _ctx(self.ctx), _stream()), "nvf_wgrad_trunk5_partial")
+        if bias_outs is None:
+            check(lib().nvf_wgrad_trunk5_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases[:5]), B, nsl,
+                                                 _ctx(self.ctx), _stream()), "nvf_wgrad_trunk5_partial")
+        else:
+            _f32(*bias_outs)
+            check(lib().nvf_wgrad_trunk5_partial_bias(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases[:5]),
+                                                      (ctypes.c_void_p * 3)(bases[5], None, bases[6]), B, nsl,
+                                                      _ctx(self.ctx), _stream()), "nvf_wgrad_trunk5_partial_bias")
         for h in range(5):
             self.jobs.append((bases[h], outs[h].data_ptr(), nsl[h], jt[h]))
+        if bias_outs is not None:
+            self.jobs.append((bases[5], bias_outs[0].data_ptr(), nsl[0], 8))
+            self.jobs.append((bases[6], bias_outs[1].data_ptr(), nsl[2], 8))
 
     def add_heads3(self, dls, xs, outs, max_slabs=256):     # 256: 21 us at batch 16 (128: 26, 512: 24.5, 1024: 32)
         """Weight gradients of the three classifier heads: one partial-sum launch, three reduction jobs."""
