@@ -348,7 +348,7 @@ def run(args):
     # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
     probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
     # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
-    probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs: True)
+    probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs, **kw: True)
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
