@@ -130,6 +130,13 @@ int nvf_pack_mfma_k4_multi(const float* const* gather_ws, float* const* wps, con
 int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* bias, float* y, const float* addend,
                        const float* mask, int batch, int cin, int cout, int pad, int pair_axis, int din, int hin,
                        int win, int dout, int hout, int wout, int act, int variant, void* stream);
+/* ... with bias_part (backward-data through a ReLU mask: bias NULL, act NVF_ACT_NONE, addend NULL, mask given): the
+ * launch also leaves, per (workgroup, wave), the 8 channel sums of the outputs it stored -- *bias_nparts (<= 2048) slabs
+ * of 8 floats whose sum (a jtotal = 8 job of nvf_wgrad_reduce_multi) is the bias gradient of the layer below. */
+int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const float* bias, float* y, const float* addend,
+                            const float* mask, int batch, int cin, int cout, int pad, int pair_axis, int din, int hin,
+                            int win, int dout, int hout, int wout, int act, int variant, float* bias_part,
+                            int* bias_nparts, void* stream);
 
 /* ---- matrix-core form of the transposed convolutions k5 s2 with 8 output channels and padding 0 (up1, up2 of
  * chanstr 8,16,8,8; F.conv_transpose3d network.py:621).  Same contract as nvf_convT3d_k5s2_fwd; the weights are

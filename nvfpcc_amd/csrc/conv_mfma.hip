@@ -29,6 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct MDims {
   int din, hin, win, dout, hout, wout, pad, act, tiles_x, tiles_y, tiles_z;
   int dbg;   // tuning runs only (variant >= 100): 1 = no staging, 2 = no MFMAs; results are then meaningless
+  float* bias_part;   // EPI 1 only, optional: per (workgroup, wave) the 8 channel sums of the outputs it stored -- the
+                      // bias gradient of the layer below (its masked output gradient is what this pass writes)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -254,7 +256,7 @@ template <class C, int EPI>
 __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], const float* __restrict__ bias,
                                            float* __restrict__ y, const float* __restrict__ addend,
                                            const float* __restrict__ mask, const MDims& d, int b, int ozw, int oy0,
-                                           int ox0, int j, int wc, int kq) {
+                                           int ox0, int j, int wc, int kq, float (&bsum)[2]) {
   const size_t cstride = (size_t)d.dout * d.hout * d.wout;
   const size_t base = ((size_t)b * 8 + 2 * kq) * cstride;
   float bv[2] = {0.f, 0.f};
@@ -290,6 +292,8 @@ __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], con
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? acc[c][q][r] : 0.f;
+        bsum[0] += second ? v[0] + v[1] : v[0];
+        bsum[1] += second ? v[2] + v[3] : v[2];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -330,7 +334,11 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
   const int per = (total + 7) >> 3;
   const int t_lo = xcd * per, t_hi = min(t_lo + per, total);
   int t = t_lo + slot;
-  if (t >= t_hi) return;
+  if (t >= t_hi) {                     // nothing to do: its share of the bias partials is zero
+    if (EPI == 1 && d.bias_part && (lane & 15) == 0)
+      for (int h = 0; h < 2; ++h) d.bias_part[((size_t)blockIdx.x * C::NW + wave) * 8 + 2 * (lane >> 4) + h] = 0.f;
+    return;
+  }
   const int ntile = d.tiles_x * d.tiles_y * d.tiles_z;
   const int j = lane & 15, kq = lane >> 4;
   const int laneB = kq * CS;
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
 
   bool more = false;
   int bn = 0, ozn = 0, oyn = 0, oxn = 0;
+  float bsum[2] = {0.f, 0.f};                                // channels 2 kq, 2 kq + 1 of the outputs this lane stored
   auto tile = [&](auto firstc) {
     constexpr bool FIRST = decltype(firstc)::value;
     const int tn = t + wpx;                                  // this workgroup's next tile
@@ -397,13 +406,22 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
     if constexpr (NG > 1) { step(std::integral_constant<int, 1>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 1 ? 1 : 0)>(lds + BUF, colbase, A, acc); }
     if constexpr (NG > 2) { step(std::integral_constant<int, 2>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 2 ? 2 : 0)>(lds, colbase, A, acc); }
     if constexpr (NG > 3) { step(std::integral_constant<int, 3>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 3 ? 3 : 0)>(lds + BUF, colbase, A, acc); }
-    mfma_store<C, EPI>(acc, bias, y, addend, mask, d, b, oz0 + ZS * wz * NT, oy0, ox0, j, wc, kq);
+    mfma_store<C, EPI>(acc, bias, y, addend, mask, d, b, oz0 + ZS * wz * NT, oy0, ox0, j, wc, kq, bsum);
   };
   tile(std::true_type{});
 #pragma unroll 1
   while (more) {
     t += wpx; b = bn; oz0 = ozn; oy0 = oyn; ox0 = oxn;
     tile(std::false_type{});
+  }
+  if (EPI == 1 && d.bias_part) {       // the 16 lanes j of a kq row, in a fixed butterfly order; lane j = 0 writes
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v = bsum[h];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (j == 0) d.bias_part[((size_t)blockIdx.x * C::NW + wave) * 8 + 2 * kq + h] = v;
+    }
   }
 }
 
@@ -420,7 +438,7 @@ static int nvf_cu_count() {
 
 template <class C>
 static int launch_mfma(const float* x, const float* wp, const float* bias, float* y, const float* addend,
-                       const float* mask, int batch, MDims d, hipStream_t s) {
+                       const float* mask, int batch, MDims d, hipStream_t s, int* bias_nparts = nullptr) {
   d.tiles_x = (d.wout + C::OX - 1) / C::OX;
   d.tiles_y = (d.hout + C::OY - 1) / C::OY;
   d.tiles_z = (d.dout + C::OZ - 1) / C::OZ;
@@ -428,6 +446,7 @@ static int launch_mfma(const float* x, const float* wp, const float* bias, float
   int grid = (nvf_cu_count() + 7) / 8 * 8;                  // one workgroup per CU, a multiple of the 8 XCDs
   const int need = ((total + 7) / 8) * 8;
   if (grid > need) grid = need;
+  if (bias_nparts) *bias_nparts = grid * C::NW;
   if (bias && d.act == NVF_ACT_RELU && !addend && !mask)
     conv_k4_mfma<C, 0><<<grid, C::NW * 64, 0, s>>>(x, wp, bias, y, addend, mask, d, total);
   else if (!bias && d.act == NVF_ACT_NONE && !addend && mask)
@@ -440,18 +459,35 @@ static int launch_mfma(const float* x, const float* wp, const float* bias, float
 // y[b,co,o] = act(bias[co] + sum_{ci,k} x[b,ci,o - pad + k] w[ci][k][co]) (+ addend) (masked), k = 4^3, 8 output
 // channels; wp = nvf_pack_mfma_k4 of w with pair_axis 0 (pad 0: the forward pass) or 2 (pad 3: backward-data).
 // Returns NVF_EINVAL for shapes without an instantiation (the caller then uses nvf_conv3d_gather).
+extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const float* bias, float* y,
+                                       const float* addend, const float* mask, int batch, int cin, int cout, int pad,
+                                       int pair_axis, int din, int hin, int win, int dout, int hout, int wout, int act,
+                                       int variant, float* bias_part, int* bias_nparts, void* stream);
+
 extern "C" int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* bias, float* y, const float* addend,
                                   const float* mask, int batch, int cin, int cout, int pad, int pair_axis, int din,
                                   int hin, int win, int dout, int hout, int wout, int act, int variant, void* stream) {
+  return nvf_conv3d_k4_mfma_bias(x, wp, bias, y, addend, mask, batch, cin, cout, pad, pair_axis, din, hin, win, dout,
+                                 hout, wout, act, variant, nullptr, nullptr, stream);
+}
+
+// ... with bias_part (backward-data through a ReLU mask only: no bias, act none, mask given): per (workgroup, wave) the
+// 8 channel sums of the stored outputs, *bias_nparts slabs of 8 floats (at most 2048) whose sum is the bias gradient of
+// the layer whose masked output gradient this pass writes.
+extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const float* bias, float* y,
+                                       const float* addend, const float* mask, int batch, int cin, int cout, int pad,
+                                       int pair_axis, int din, int hin, int win, int dout, int hout, int wout, int act,
+                                       int variant, float* bias_part, int* bias_nparts, void* stream) {
   if (!x || !wp || !y || batch <= 0 || cout != 8) return NVF_EINVAL;
   if (dout != din + 2 * pad - 3 || hout != hin + 2 * pad - 3 || wout != win + 2 * pad - 3) return NVF_EINVAL;
-  MDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0, 0};
+  if (bias_part && (!bias_nparts || bias || act != NVF_ACT_NONE || addend || !mask)) return NVF_EINVAL;
+  MDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0, 0, bias_part};
   if (variant >= 100) { d.dbg = variant / 100; variant %= 100; }
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
 #define NVF_M(VAR, CI, PA, WLO, WHI, CTY, CTX, RY, RX, NWC, NWZ, NT)                                   \
   if (rc == 1 && variant == VAR && cin == CI && pair_axis == PA && wout >= WLO && wout <= WHI)        \
-    rc = launch_mfma<MCv<CI, PA, CTY, CTX, RY, RX, NWC, NWZ, NT>>(x, wp, bias, y, addend, mask, batch, d, s);
+    rc = launch_mfma<MCv<CI, PA, CTY, CTX, RY, RX, NWC, NWZ, NT>>(x, wp, bias, y, addend, mask, batch, d, s, bias_nparts);
   NVF_M(0, 8, 0, 17, 32, 1, 16, 8, 1, 4, 2, 2)    // conv2 forward: 8 rows x 4 planes x 32 per workgroup, 8 waves
   NVF_M(0, 8, 0, 9, 16, 2, 8, 4, 1, 4, 1, 2)      // conv1 forward: 8 rows x 2 planes x 16
   NVF_M(0, 8, 2, 21, 36, 4, 4, 3, 3, 1, 4, 1)     // conv2 backward-data: 12 x 12 patch x 8 planes, waves along z
@@ -473,7 +509,7 @@ extern "C" int nvf_conv3d_k4_mfma(const float* x, const float* wp, const float* 
 #undef NVF_M
 #define NVF_MF(VAR, CI, WLO, WHI, CPR, RY, NWC, NWZ, NT)                                               \
   if (rc == 1 && variant == VAR && cin == CI && pair_axis == 0 && pad == 3 && wout >= WLO && wout <= WHI) \
-    rc = launch_mfma<MCvFlat<CI, CPR, RY, NWC, NWZ, NT>>(x, wp, bias, y, addend, mask, batch, d, s);
+    rc = launch_mfma<MCvFlat<CI, CPR, RY, NWC, NWZ, NT>>(x, wp, bias, y, addend, mask, batch, d, s, bias_nparts);
   // backward-data with pair axis x and flattened columns (weights packed with pair_axis 0 from w_bwd)
   NVF_MF(0, 8, 33, 36, 18, 7, 4, 2, 2)     // conv2 backward-data: 7 rows x 4 planes x 36 = 8 column tiles, 8 waves
   NVF_MF(2, 8, 33, 36, 18, 7, 4, 1, 7)

@@ -374,12 +374,25 @@ class TrainEngine:
         self._wg.add(x_in, g_out, 5, 2, L.pad, 0, L.gk)
         self._bias_jobs.append((g_out, L.gb))
 
-    def _dx_conv(self, L, g_out, x_in, mask=None, addend=None):
+    def _dx_conv(self, L, g_out, x_in, mask=None, addend=None, bias_out=None):
+        """Backward-data of a 4^3 convolution.  ``bias_out``: the bias gradient of the layer BELOW (whose masked output
+        gradient this pass writes): the matrix-core kernel leaves its channel sums as slabs for the reduction launch;
+        returns (dx, True) then, (dx, False) when the caller has to sum dx itself."""
         if L.wp_gb is not None:
-            return ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 4, 1, 3, tuple(x_in.shape[2:]), addend=addend,
-                                       mask=mask)
+            dx = ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 4, 1, 3, tuple(x_in.shape[2:]), addend=addend,
+                                     mask=mask)
+            return dx if bias_out is None else (dx, False)
         if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
-            return ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, addend=addend, mask=mask)
+            if bias_out is not None and mask is not None and addend is None:
+                base = self._wg.reserve(2048 * 8 * 4)
+                dx, nparts = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, mask=mask, bias_part=base)
+                self._wg.add_job(base, bias_out, nparts, 8)
+                return dx, True
+            dx = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, addend=addend, mask=mask)
+            return dx if bias_out is None else (dx, False)
+        if bias_out is not None:
+            return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
+                                     addend=addend, mask=mask), False
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),
                                  addend=addend, mask=mask)
 
@@ -472,26 +485,31 @@ class TrainEngine:
         wg3 = want_w and self.narrow and _NAIVE_OFF()      # conv2 / up2 / conv1 weight gradients in one launch
         if not wg3:
             side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
-        g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])
-        if not wg3:
+        if wg3:     # up2's bias gradient = the channel sums of g4: left by the kernel that writes g4
+            g4, up2_bias_done = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"], bias_out=Ls["up2"].gb)
+        else:
+            g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])
             side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"])
         if ev_t1 is not None:
             main.wait_event(ev_t1)
         g3 = self._dx_convT(Ls["up2"], g4, a["y3"], mask=a["y3"], addend=t1)
         if wg3:     # launched after the latent tail has been queued (below): the tail rides in that launch; the bias
             # gradients of conv2 and conv1 (channel sums of g5, g3) come out of it too
-            self._bias_jobs += [(g4, Ls["up2"].gb)]
+            if not up2_bias_done:
+                self._bias_jobs += [(g4, Ls["up2"].gb)]
         else:
             side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
-        g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
-        if not wg3:
+        if wg3:
+            g2, up1_bias_done = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"], bias_out=Ls["up1"].gb)
+        else:
+            g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
             side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"])
         if ev_t0 is not None:
             main.wait_event(ev_t0)
         g1 = self._dx_convT(Ls["up1"], g2, a["y1"], mask=a["y1"], addend=t0)
         stem_wg0 = want_w and self.fused_stem and defer and not wg3   # conv0's weight gradient rides in the stem's backward
         if wg3:                                      # up1 and conv0 weight gradients: with the other three, below
-            self._bias_jobs += [(g2, Ls["up1"].gb), (g1, Ls["conv0"].gb)]
+            self._bias_jobs += ([] if up1_bias_done else [(g2, Ls["up1"].gb)]) + [(g1, Ls["conv0"].gb)]
         elif stem_wg0:
             self._bias_jobs.append((g1, Ls["conv0"].gb))
         else:

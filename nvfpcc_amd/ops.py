@@ -203,8 +203,12 @@ def pack_mfma_all(jobs):
                                   (ctypes.c_int * n)(*[j[4] for j in jobs]), n, _stream()), "nvf_pack_mfma_all")
 
 
-def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=None, out=None, variant=None):
-    """Matrix-core 4^3 convolution, 8 output channels: same contract as conv3d_gather(k=4, stride=1)."""
+def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=None, out=None, variant=None,
+                   bias_part=None):
+    """Matrix-core 4^3 convolution, 8 output channels: same contract as conv3d_gather(k=4, stride=1).
+    ``bias_part`` (device address of >= 2048 x 8 floats; backward-data through a ReLU mask only): the launch also
+    leaves per-(workgroup, wave) channel sums of what it stored there; returns (y, number of 8-float slabs)."""
+    import ctypes
     _f32(x, wp, bias, addend, mask)
     B, cin, di, hi, wi = x.shape
     do, ho, wo = di + 2 * pad - 3, hi + 2 * pad - 3, wi + 2 * pad - 3
@@ -212,6 +216,13 @@ def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=
     for t in (addend, mask):
         if t is not None and t.shape != y.shape:
             raise RuntimeError("addend/mask shape must equal the output shape")
+    if bias_part is not None:
+        nparts = ctypes.c_int(0)
+        check(lib().nvf_conv3d_k4_mfma_bias(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(addend), _ptr(mask), B, cin, 8,
+                                            pad, pair_axis, di, hi, wi, do, ho, wo, act,
+                                            _MFMA_VARIANT if variant is None else int(variant), int(bias_part),
+                                            ctypes.byref(nparts), _stream()), "nvf_conv3d_k4_mfma_bias")
+        return y, nparts.value
     check(lib().nvf_conv3d_k4_mfma(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(addend), _ptr(mask), B, cin, 8, pad,
                                    pair_axis, di, hi, wi, do, ho, wo, act,
                                    _MFMA_VARIANT if variant is None else int(variant), _stream()),
@@ -494,6 +505,24 @@ class WgradBatch:
         self.ctx = ctx          # StepCtx: a queued latent tail rides in add_mfma3 / add_trunk5 / finish_with_sums
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self._retired = []      # outgrown buffers stay alive: kernels on another stream may still read them
+
+    def reserve(self, nbytes):
+        """Device address of ``nbytes`` of slab space that stays untouched until finish() (for partial sums a kernel
+        other than the weight-gradient ones leaves: see add_job)."""
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        if self.offset + nbytes > self.ws.numel():
+            if self.jobs:
+                self.finish()
+            self._retired.append(self.ws)
+            self.ws = torch.empty(max(nbytes, 2 * self.ws.numel()), dtype=torch.uint8, device=self.device)
+        base = self.ws.data_ptr() + self.offset
+        self.offset += nbytes
+        return base
+
+    def add_job(self, base, out, nslab, jtotal):
+        """A reduction job over slabs someone else wrote: out[j] = sum of nslab slabs of jtotal floats at ``base``."""
+        _f32(out)
+        self.jobs.append((int(base), out.data_ptr(), int(nslab), int(jtotal)))
 
     def add(self, p, q, k, stride, pad, out_mode, out):
         import ctypes
