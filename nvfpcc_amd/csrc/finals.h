@@ -91,8 +91,12 @@ __device__ __forceinline__ void focal_multi_final_body(const FocalMulti& m, cons
                                                        float* __restrict__ loss, int nterm, int tid) {
   const int t = tid >> 6, lane = tid & 63;
   if (t >= nterm) return;
+  float v[kLossMaxWG / 64];                      // every load in flight before the first add (one round trip, not 16)
+#pragma unroll
+  for (int i = 0; i < kLossMaxWG / 64; ++i) v[i] = lane + 64 * i < m.nwg[t] ? part[t * kLossMaxWG + lane + 64 * i] : 0.f;
   float s = 0.f;
-  for (int g = lane; g < m.nwg[t]; g += 64) s += part[t * kLossMaxWG + g];
+#pragma unroll
+  for (int i = 0; i < kLossMaxWG / 64; ++i) s += v[i];
   s = nvf_wave_sum(s);
   if (lane == 0) loss[t] = s;
 }
@@ -103,7 +107,13 @@ __device__ __forceinline__ int multi_channel_sum_final_body(const MultiSumDesc& 
   int t = 0;
   while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
   float s = 0.f;
-  for (int g = 0; g < d.nchunk; ++g) s += part[(size_t)g * d.total_channels + gch];
+  for (int g0 = 0; g0 < d.nchunk; g0 += 16) {     // 16 loads in flight, added in ascending chunk order
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = g0 + i < d.nchunk ? part[(size_t)(g0 + i) * d.total_channels + gch] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+  }
   float* o = d.out[t] + (gch - d.chan_base[t]);
   *o = s;
   return adam ? adam_fused_elem(*adam, o, s) : 0;
@@ -116,13 +126,28 @@ __device__ __forceinline__ int weight_rate_batch_final_body(const WeightRateBatc
                                                             const float* __restrict__ g_dev, float g_host, int lane,
                                                             const NvfAdamFuse* adam = nullptr) {
   const float g = g_host * (g_dev ? g_dev[0] : 1.f);
+  // lane i holds the partials of workgroups i, i + 64, ... (at most 512 of them): every load is in flight before the
+  // first sum -- one memory round trip instead of one per layer
+  constexpr int SLOTS = 8;
+  const int nwg = b.first_wg[b.nlayers];
+  float pb[SLOTS], ps[SLOTS], pm[SLOTS];
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int wg = lane + 64 * i;
+    const bool ok = wg < nwg;
+    pb[i] = ok ? part[3 * wg] : 0.f;
+    ps[i] = ok ? part[3 * wg + 1] : 0.f;
+    pm[i] = ok ? part[3 * wg + 2] : 0.f;
+  }
   float acc_s = 0.f, acc_m = 0.f;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) { acc_s += ps[i]; acc_m += pm[i]; }
   for (int l = 0; l < b.nlayers; ++l) {
     float tb = 0.f;
-    for (int wg = b.first_wg[l] + lane; wg < b.first_wg[l + 1]; wg += 64) {
-      tb += part[3 * wg];
-      acc_s += part[3 * wg + 1];
-      acc_m += part[3 * wg + 2];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int wg = lane + 64 * i;
+      tb += (wg >= b.first_wg[l] && wg < b.first_wg[l + 1]) ? pb[i] : 0.f;
     }
     tb = nvf_wave_sum(tb);
     if (lane == 0) bits[l] = tb;
@@ -162,7 +187,13 @@ __device__ __forceinline__ int stem_gdn_final_body(const StemGdnFinal& f, int p0
   int bad = 0;
   for (int p = p0; p < ncol; p += stride) {
     float s = 0.f;
-    for (int g = 0; g < f.nslab; ++g) s += f.slab_gdn[(size_t)g * ncol + p];
+    for (int g0 = 0; g0 < f.nslab; g0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = g0 + i < f.nslab ? f.slab_gdn[(size_t)(g0 + i) * ncol + p] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += v[i];
+    }
     float* o;
     float v;
     if (p < f.c0) {
@@ -188,7 +219,13 @@ __device__ __forceinline__ void metrics_final_body(const float* __restrict__ par
   if (tid >= 6 * nterm) return;
   const int t = tid / 6, k = tid - 6 * t;
   float s = 0.f;
-  for (int g = 0; g < nwg[t]; ++g) s += part[((size_t)t * kLossMaxWG + g) * 6 + k];
+  for (int g0 = 0; g0 < nwg[t]; g0 += 16) {        // 16 loads in flight, added in ascending row order
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = g0 + i < nwg[t] ? part[((size_t)t * kLossMaxWG + g0 + i) * 6 + k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+  }
   out[tid] = accumulate ? out[tid] + s : s;
 }
 

@@ -32,6 +32,14 @@ struct TailRanges { long lo[16], hi[16]; int n; };
 __global__ __launch_bounds__(256) void finals_tail_kernel(FinalsArgs a, int sum_blocks, NvfStepTail t, TailRanges rg) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const NvfAdamFuse ad = adam_fuse_of(t);
+  // the next schedule row, fetched now (the cursor only moves at the very end of this launch): whichever workgroup
+  // turns out to be the last has it in registers instead of starting three dependent round trips then
+  unsigned long long cur = 0;
+  int64_t next_word = 0;
+  if (t.sched_rows) {
+    cur = t.sched_cursor[0];
+    if (tid < t.sched_words) next_word = t.sched_rows[cur * (unsigned long long)t.sched_words + tid];
+  }
   int bad = 0;
   if (blockIdx.x == 0) {
     if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
@@ -85,10 +93,10 @@ __global__ __launch_bounds__(256) void finals_tail_kernel(FinalsArgs a, int sum_
   if (tid == 0) last = atomicAdd(t.done, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  const unsigned long long c = t.sched_cursor[0];
-  const int64_t* row = t.sched_rows + c * (unsigned long long)t.sched_words;
-  for (int w = tid; w < t.sched_words; w += blockDim.x) t.sched_buf[w] = row[w];
-  if (tid == 0) { t.sched_cursor[0] = c + 1; t.done[0] = 0u; }
+  if (tid < t.sched_words) t.sched_buf[tid] = next_word;
+  for (int w = tid + blockDim.x; w < t.sched_words; w += blockDim.x)
+    t.sched_buf[w] = t.sched_rows[cur * (unsigned long long)t.sched_words + w];
+  if (tid == 0) { t.sched_cursor[0] = cur + 1; t.done[0] = 0u; }
 }
 
 }  // namespace

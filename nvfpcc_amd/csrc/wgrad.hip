@@ -819,18 +819,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ s
   __shared__ float part[16][64];
   const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jl;
-  // four independent partial sums keep four loads in flight; the order (4 strided chains, then a fixed tree) is
-  // the same in wgrad_reduce and wgrad_reduce_multi
+  // slice sl of 16 takes slabs sl, sl + 16, ...: up to 16 of them are fetched before the first add (one round trip
+  // for <= 256 slabs), then added in ascending order in four interleaved chains and a fixed tree
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < jtotal) {
-    int g = sl;
-    for (; g + 48 < nslab; g += 64) {
-      s0 += slabs[(size_t)g * jtotal + j];
-      s1 += slabs[(size_t)(g + 16) * jtotal + j];
-      s2 += slabs[(size_t)(g + 32) * jtotal + j];
-      s3 += slabs[(size_t)(g + 48) * jtotal + j];
+    for (int g0 = sl; g0 < nslab; g0 += 256) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = g0 + 16 * i < nslab ? slabs[(size_t)(g0 + 16 * i) * jtotal + j] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
     }
-    for (; g < nslab; g += 16) s0 += slabs[(size_t)g * jtotal + j];
   }
   const float s = (s0 + s1) + (s2 + s3);
   part[sl][jl] = s;
@@ -1017,16 +1016,17 @@ __device__ __forceinline__ void wgrad_reduce_multi_body(const WgReduceMulti& d, 
   const int j = (bid - d.blk_base[t]) * 64 + jl;
   // four independent partial sums keep four loads in flight; the order (4 strided chains, then a fixed tree) is
   // the same in wgrad_reduce and wgrad_reduce_multi
+  // (slice sl of 16 takes slabs sl, sl + 16, ...: up to 16 of them are fetched before the first add -- one round trip
+  // for <= 256 slabs -- then added in ascending order in four interleaved chains)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < jtotal) {
-    int g = sl;
-    for (; g + 48 < nslab; g += 64) {
-      s0 += slabs[(size_t)g * jtotal + j];
-      s1 += slabs[(size_t)(g + 16) * jtotal + j];
-      s2 += slabs[(size_t)(g + 32) * jtotal + j];
-      s3 += slabs[(size_t)(g + 48) * jtotal + j];
+    for (int g0 = sl; g0 < nslab; g0 += 256) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = g0 + 16 * i < nslab ? slabs[(size_t)(g0 + 16 * i) * jtotal + j] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
     }
-    for (; g < nslab; g += 16) s0 += slabs[(size_t)g * jtotal + j];
   }
   const float s = (s0 + s1) + (s2 + s3);
   part[sl][jl] = s;
