@@ -32,14 +32,10 @@ struct TailRanges { long lo[16], hi[16]; int n; };
 __global__ __launch_bounds__(256) void finals_tail_kernel(FinalsArgs a, int sum_blocks, NvfStepTail t, TailRanges rg) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const NvfAdamFuse ad = adam_fuse_of(t);
-  // the next schedule row, fetched now (the cursor only moves at the very end of this launch): whichever workgroup
-  // turns out to be the last has it in registers instead of starting three dependent round trips then
-  unsigned long long cur = 0;
-  int64_t next_word = 0;
-  if (t.sched_rows) {
-    cur = t.sched_cursor[0];
-    if (tid < t.sched_words) next_word = t.sched_rows[cur * (unsigned long long)t.sched_words + tid];
-  }
+  // the schedule cursor is fetched now (it only moves at the very end of this launch) and the row it points at right
+  // before the arrival counter is bumped: whichever workgroup turns out to be the last already holds the row when it
+  // learns so -- one round trip at the end instead of three dependent ones
+  const unsigned long long cur = t.sched_rows ? t.sched_cursor[0] : 0ull;   // in flight under the work below
   int bad = 0;
   if (blockIdx.x == 0) {
     if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
@@ -90,6 +86,8 @@ __global__ __launch_bounds__(256) void finals_tail_kernel(FinalsArgs a, int sum_
   }
   if (!t.sched_rows) return;
   __shared__ int last;
+  int64_t next_word = 0;
+  if (tid < t.sched_words) next_word = t.sched_rows[cur * (unsigned long long)t.sched_words + tid];
   if (tid == 0) last = atomicAdd(t.done, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;

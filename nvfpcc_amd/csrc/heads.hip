@@ -14,6 +14,10 @@
 //     reads) feeds 12 FMAs per input channel.
 #include "nvf_common.h"
 #include "step_ctx.h"
+#include <cstdlib>
+
+int nvf_heads3_wgrad_mfma_launch(const float* const* dls, const float* const* xs, float* const* slabs, int narrow,
+                                 int batch, int max_slabs, int* nslabs, hipStream_t s);
 
 namespace {
 
@@ -688,6 +692,16 @@ extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* co
                                         void* stream) {
   if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
   const int t = heads3_tuple(cs, ss);
+  // narrow decoder: on the matrix cores (heads_wgrad_mfma.hip; NVF_HEADS_WG_VALU=1 keeps the VALU kernels: tuning)
+  static const bool valu = getenv("NVF_HEADS_WG_VALU") != nullptr;
+  if (t == 0 && !valu) {
+    const int rc = nvf_heads3_wgrad_mfma_launch(dls, xs, slabs, 1, batch, max_slabs, nslabs, nvf_stream(stream));
+    if (rc != 1) {
+      if (rc != NVF_OK) return rc;
+      NVF_LAUNCH_CHECK();
+      return NVF_OK;
+    }
+  }
   // the big head in 2 x 8-row tiles: larger tiles (4 x 8, 2 x 16, 8 x 8) re-read less halo but were 10-30 % slower --
   // the kernel is bound by how many staging round trips are in flight, not by bytes
   if (t == 0)
