@@ -91,12 +91,8 @@ __device__ __forceinline__ void focal_multi_final_body(const FocalMulti& m, cons
                                                        float* __restrict__ loss, int nterm, int tid) {
   const int t = tid >> 6, lane = tid & 63;
   if (t >= nterm) return;
-  float v[kLossMaxWG / 64];                      // every load in flight before the first add (one round trip, not 16)
-#pragma unroll
-  for (int i = 0; i < kLossMaxWG / 64; ++i) v[i] = lane + 64 * i < m.nwg[t] ? part[t * kLossMaxWG + lane + 64 * i] : 0.f;
   float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < kLossMaxWG / 64; ++i) s += v[i];
+  for (int g = lane; g < m.nwg[t]; g += 64) s += part[t * kLossMaxWG + g];
   s = nvf_wave_sum(s);
   if (lane == 0) loss[t] = s;
 }
@@ -107,13 +103,7 @@ __device__ __forceinline__ int multi_channel_sum_final_body(const MultiSumDesc& 
   int t = 0;
   while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
   float s = 0.f;
-  for (int g0 = 0; g0 < d.nchunk; g0 += 16) {     // 16 loads in flight, added in ascending chunk order
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = g0 + i < d.nchunk ? part[(size_t)(g0 + i) * d.total_channels + gch] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += v[i];
-  }
+  for (int g = 0; g < d.nchunk; ++g) s += part[(size_t)g * d.total_channels + gch];
   float* o = d.out[t] + (gch - d.chan_base[t]);
   *o = s;
   return adam ? adam_fused_elem(*adam, o, s) : 0;
@@ -187,13 +177,7 @@ __device__ __forceinline__ int stem_gdn_final_body(const StemGdnFinal& f, int p0
   int bad = 0;
   for (int p = p0; p < ncol; p += stride) {
     float s = 0.f;
-    for (int g0 = 0; g0 < f.nslab; g0 += 16) {
-      float v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = g0 + i < f.nslab ? f.slab_gdn[(size_t)(g0 + i) * ncol + p] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s += v[i];
-    }
+    for (int g = 0; g < f.nslab; ++g) s += f.slab_gdn[(size_t)g * ncol + p];
     float* o;
     float v;
     if (p < f.c0) {

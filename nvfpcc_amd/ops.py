@@ -231,6 +231,8 @@ def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=
 
 
 _MFMA_VARIANT = int(os.environ.get("NVF_MFMA_VARIANT", "0"))
+# slabs (= workgroups) of the big head's weight gradient; VALU kernels: 256 was best (21 us at batch 16; 128: 26, 512: 24.5)
+_HEADS_SLABS = int(os.environ.get("NVF_HEADS_SLABS", "256"))
 
 
 def set_mfma_variant(v):
@@ -622,9 +624,11 @@ class WgradBatch:
             self.jobs.append((bases[5], bias_outs[0].data_ptr(), nsl[0], 8))
             self.jobs.append((bases[6], bias_outs[1].data_ptr(), nsl[2], 8))
 
-    def add_heads3(self, dls, xs, outs, max_slabs=256):     # 256: 21 us at batch 16 (128: 26, 512: 24.5, 1024: 32)
+    def add_heads3(self, dls, xs, outs, max_slabs=None):
         """Weight gradients of the three classifier heads: one partial-sum launch, three reduction jobs."""
         import ctypes
+        if max_slabs is None:
+            max_slabs = _HEADS_SLABS
         _f32(*dls, *xs, *outs)
         B = xs[0].shape[0]
         cs = [x.shape[1] for x in xs]
