@@ -300,6 +300,13 @@ int nvf_wgrad_trunk5_partial(const float* const* ps, const float* const* qs, flo
  * layer's bias gradient -- the kernel holds every dY tile in registers, and its tiles partition dY. */
 int nvf_wgrad_trunk5_partial_bias(const float* const* ps, const float* const* qs, float* const* slabs,
                                   float* const* bias_slabs, int batch, int* nslabs, NvfStepCtx* ctx, void* stream);
+/* ... and the weight gradients of the narrow decoder's three classifier heads (the contract of
+ * nvf_heads3_wgrad_partial: three entries each, at most head_max_slabs slabs of cs[h] * 27 floats) as further workgroups
+ * of the same launch: they depend on nothing it produces and run in the slots its other jobs leave. */
+int nvf_wgrad_trunk5_heads_partial(const float* const* ps, const float* const* qs, float* const* slabs,
+                                   float* const* bias_slabs, const float* const* head_dls, const float* const* head_xs,
+                                   float* const* head_slabs, int head_max_slabs, int batch, int* nslabs,
+                                   int* head_nslabs, NvfStepCtx* ctx, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */

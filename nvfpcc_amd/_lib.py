@@ -64,6 +64,7 @@ PROTOTYPES = {
     "nvf_wgrad_up1_conv0_partial": (I, [P, P, P, I, P, P]),
     "nvf_wgrad_trunk5_partial": (I, [P, P, P, I, P, P, P]),
     "nvf_wgrad_trunk5_partial_bias": (I, [P, P, P, P, I, P, P, P]),
+    "nvf_wgrad_trunk5_heads_partial": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
     "nvf_channel_sum_workspace": (Z, [I]),
     "nvf_channel_sum": (I, [P, P, P, Z, I, I, I, I, P]),
     "nvf_multi_channel_sum_workspace": (Z, [I]),

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "step_ctx.h"
+#include "heads_wgrad_mfma.h"
 
 static const int kMaxSlabs = 512;
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
@@ -682,10 +683,11 @@ struct WgMfma3 {
 constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 template <class C0, class T1, class C2, class U0, class U1, bool TAIL>
-__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u, LatentTail tail) {
+__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u, LatentTail tail, HeadsW3 hw) {
   static_assert(U0::NT == 256 && U1::NT == 256, "one workgroup size");
   __shared__ __attribute__((aligned(16))) float lds[wg_max3(wg_max3(C0::LDSF, T1::LDSF, C2::LDSF), kWgEpiFloats,
-                                                            wg_max3(kTailLds, U0::LDSF, U1::LDSF))];
+                                                            wg_max3(wg_max3(kTailLds, U0::LDSF, U1::LDSF),
+                                                                    wg_max3(HeadW0::SMEM, HeadW1::SMEM, HeadW2::SMEM), 0))];
   int bid = blockIdx.x;
   if (TAIL) {                          // the latent tail: one workgroup, dispatched first, hidden behind the gradients
     if (bid == 0) { latent_tail_body(tail, lds); return; }
@@ -704,7 +706,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
     return;
   }
   bid -= u.nx[0] * u.ny[0];
-  wgrad_tiled_body<U1>(u.p[1], u.q[1], u.slabs[1], u.d[1], bid % u.nx[1], bid / u.nx[1], lds);
+  if (bid < u.nx[1] * u.ny[1]) {
+    wgrad_tiled_body<U1>(u.p[1], u.q[1], u.slabs[1], u.d[1], bid % u.nx[1], bid / u.nx[1], lds);
+    return;
+  }
+  bid -= u.nx[1] * u.ny[1];
+  // the three classifier heads' weight gradients (matrix cores, 22 KB of LDS, short): they depend on nothing this
+  // launch produces and run in the slots the other jobs have left by then
+  heads3_wgrad_mfma_dispatch<HeadW0, HeadW1, HeadW2>(hw, bid, lds);
 }
 
 // geometry of the up1 / conv0 jobs (nvf_wgrad_up1_conv0_partial, nvf_wgrad_trunk5_partial)
@@ -729,9 +738,17 @@ static void fill_up1_conv0(WgTiled2& m, const float* const* ps, const float* con
 }
 
 // njobs = 3: conv2, up2, conv1 (matrix cores); njobs = 5: + up1, conv0 (the VALU tile kernel with 256-thread workgroups)
+struct HeadsJob {                       // optional: the heads' gradients in the same launch (njobs = 5 only)
+  const float* const* dls;
+  const float* const* xs;
+  float* const* slabs;
+  int max_slabs;
+  int* nslabs;
+};
+
 static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                                int* nslabs, int njobs, NvfStepCtx* ctx, void* stream,
-                               float* const* bias_slabs = nullptr) {
+                               float* const* bias_slabs = nullptr, const HeadsJob* heads = nullptr) {
   if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
   using C0 = MCfg<32, 4, 4>; using T1 = TWCfg<2, 2>; using C2 = MCfg<16, 2, 8>;
   using U0 = WCfg<16, 5, 2, 2, 8, 4, 2, 0>; using U1 = WCfg<8, 5, 2, 2, 4, 4, 4, 0>;
@@ -764,11 +781,19 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     fill_up1_conv0<U0, U1>(u, ps + 3, qs + 3, slabs + 3, batch, nslabs + 3);
     grid += u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1];
   }
+  HeadsW3 hw{};
+  if (heads) {
+    if (njobs != 5) return NVF_EINVAL;
+    const int rc = heads3_wgrad_mfma_fill<HeadW0, HeadW1, HeadW2>(hw, heads->dls, heads->xs, heads->slabs, batch,
+                                                                  heads->max_slabs, heads->nslabs);
+    if (rc != NVF_OK) return rc;
+    grid += hw.n[0] + hw.n[1] + hw.n[2];
+  }
   if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
     ctx->tail_pending = 0;
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail);
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail, hw);
   } else {
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{});
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{}, hw);
   }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -797,6 +822,19 @@ extern "C" int nvf_wgrad_trunk5_partial_bias(const float* const* ps, const float
                                              float* const* bias_slabs, int batch, int* nslabs, NvfStepCtx* ctx,
                                              void* stream) {
   return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream, bias_slabs);
+}
+
+// ... and the weight gradients of the narrow decoder's three classifier heads (nvf_heads3_wgrad_partial's contract:
+// head_dls / head_xs / head_slabs / head_nslabs have three entries, at most head_max_slabs slabs each) as further
+// workgroups of the same launch.
+extern "C" int nvf_wgrad_trunk5_heads_partial(const float* const* ps, const float* const* qs, float* const* slabs,
+                                              float* const* bias_slabs, const float* const* head_dls,
+                                              const float* const* head_xs, float* const* head_slabs,
+                                              int head_max_slabs, int batch, int* nslabs, int* head_nslabs,
+                                              NvfStepCtx* ctx, void* stream) {
+  if (!head_dls || !head_xs || !head_slabs || !head_nslabs || head_max_slabs <= 0) return NVF_EINVAL;
+  const HeadsJob h{head_dls, head_xs, head_slabs, head_max_slabs, head_nslabs};
+  return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream, bias_slabs, &h);
 }
 
 template <class C>

@@ -29,6 +29,7 @@ R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
 _TAIL = os.environ.get("NVF_TAIL", "1") != "0"   # latent backward as one workgroup of a later launch (0: three launches)
 _STEM = os.environ.get("NVF_STEM", "1") != "0"   # fused stem launches (0: per-layer kernels)
 _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wide decoder (0: the VALU tile kernels)
+_HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
 
 
 def _NAIVE_OFF():
@@ -454,8 +455,12 @@ class TrainEngine:
             else:
                 t0, t1, g5 = ops.heads3_bwd_data([dl0, dl1, dl2], [L.w_bwd for L in hl], [L.cin for L in hl],
                                                  [None, None, a["y5"]])
+            heads_job = None
             if want_w:
-                self._wg.add_heads3([dl0, dl1, dl2], [a["y1"], a["y3"], a["y5"]], [L.gk for L in hl])
+                heads_job = ([dl0, dl1, dl2], [a["y1"], a["y3"], a["y5"]], [L.gk for L in hl])
+                if not (self.narrow and _NAIVE_OFF() and _HEADS_IN_TRUNK5):   # else: workgroups of the five-gradient launch
+                    self._wg.add_heads3(*heads_job)
+                    heads_job = None
                 self._bias_jobs += [(dl2, hl[2].gb), (dl1, hl[1].gb), (dl0, hl[0].gb)]
         else:
             self._fork()
@@ -571,7 +576,7 @@ class TrainEngine:
             # gradients (small VALU kernels) fill the slots that the short matrix-core workgroups leave
             self._wg.add_trunk5([g5, a["y3"], g3, a["y1"], a["h0"]], [a["y4"], g4, a["y2"], g2, g1],
                                 [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk],
-                                bias_outs=(Ls["conv2"].gb, Ls["conv1"].gb))
+                                bias_outs=(Ls["conv2"].gb, Ls["conv1"].gb), heads=heads_job if self.heads3 else None)
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
         # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model

@@ -590,16 +590,23 @@ class WgradBatch:
         """up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch, two reduction jobs."""
         self._grouped(lib().nvf_wgrad_up1_conv0_partial, "nvf_wgrad_up1_conv0_partial", ps, qs, outs, (16000, 16000), 512)
 
-    def add_trunk5(self, ps, qs, outs, bias_outs=None):
+    def add_trunk5(self, ps, qs, outs, bias_outs=None, heads=None):
         """conv2 / up2 / conv1 / up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch (which also
         carries a queued latent tail), five reduction jobs.  ps/qs/outs: add_mfma3's three, then add_up1_conv0's two.
         ``bias_outs`` = (conv2's bias gradient, conv1's): the launch also leaves the channel sums of their dY (two more
-        reduction jobs of 8 floats) -- nobody has to read those two tensors again for the bias sums."""
+        reduction jobs of 8 floats) -- nobody has to read those two tensors again for the bias sums.
+        ``heads`` = (dls, xs, outs) of add_heads3 (narrow decoder, needs bias_outs): the heads' weight gradients as
+        further workgroups of the same launch."""
         import ctypes
         _f32(*ps, *qs, *outs)
         B = ps[0].shape[0]
         jt = (4096, 8000, 4096, 16000, 16000) + ((8, 8) if bias_outs is not None else ())
         sizes = [(512 * j * 4 + 255) // 256 * 256 for j in jt]
+        if heads is not None:
+            hd, hx, ho = heads
+            _f32(*hd, *hx, *ho)
+            hcs = [x.shape[1] for x in hx]
+            sizes += [(_HEADS_SLABS * c * 27 * 4 + 255) // 256 * 256 for c in hcs]
         if self.offset + sum(sizes) > self.ws.numel():
             if self.jobs:
                 self.finish()
@@ -610,7 +617,15 @@ class WgradBatch:
             bases.append(self.ws.data_ptr() + self.offset)
             self.offset += sz
         nsl = (ctypes.c_int * 5)()
-        if bias_outs is None:
+        if heads is not None:
+            hn = (ctypes.c_int * 3)()
+            check(lib().nvf_wgrad_trunk5_heads_partial(
+                _parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases[:5]), (ctypes.c_void_p * 3)(bases[5], None, bases[6]),
+                _parr(hd), _parr(hx), (ctypes.c_void_p * 3)(*bases[7:10]), _HEADS_SLABS, B, nsl, hn, _ctx(self.ctx),
+                _stream()), "nvf_wgrad_trunk5_heads_partial")
+            for h in range(3):
+                self.jobs.append((bases[7 + h], ho[h].data_ptr(), hn[h], hcs[h] * 27))
+        elif bias_outs is None:
             check(lib().nvf_wgrad_trunk5_partial(_parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases[:5]), B, nsl,
                                                  _ctx(self.ctx), _stream()), "nvf_wgrad_trunk5_partial")
         else:
