@@ -319,8 +319,13 @@ __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], con
   }
 }
 
+// Four-wave configurations whose two LDS buffers fit twice into a CU run TWO workgroups per CU (256 VGPRs each): one's
+// epilogue / tile hand-over / A-fragment prologue overlaps the other's MFMAs.
+template <class C>
+constexpr bool kTwoPerCU = C::NW == 4 && 2 * (2 * C::BUF * 4) <= 160 * 1024;
+
 template <class C, int EPI>
-__global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(C::NW * 64, kTwoPerCU<C> ? 2 : 1) void conv_k4_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             const float* __restrict__ addend,
                                                             const float* __restrict__ mask, MDims d, int total) {
@@ -444,6 +449,7 @@ static int launch_mfma(const float* x, const float* wp, const float* bias, float
   d.tiles_z = (d.dout + C::OZ - 1) / C::OZ;
   const int total = d.tiles_x * d.tiles_y * d.tiles_z * batch;
   int grid = (nvf_cu_count() + 7) / 8 * 8;                  // one workgroup per CU, a multiple of the 8 XCDs
+  if (kTwoPerCU<C>) grid *= 2;
   const int need = ((total + 7) / 8) * 8;
   if (grid > need) grid = need;
   if (bias_nparts) *bias_nparts = grid * C::NW;
@@ -498,6 +504,7 @@ extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const fl
   NVF_M(4, 8, 0, 17, 32, 1, 16, 8, 1, 8, 1, 4)
   NVF_M(5, 8, 0, 17, 32, 1, 16, 16, 1, 8, 1, 4)
   NVF_M(6, 8, 0, 17, 32, 1, 16, 8, 1, 4, 1, 4)
+  NVF_M(7, 8, 0, 17, 32, 1, 16, 4, 1, 4, 1, 2)    // conv2 forward: 4 rows x 2 planes, four waves, two workgroups per CU
   NVF_M(2, 8, 2, 21, 36, 4, 4, 3, 3, 3, 1, 3)
   NVF_M(3, 8, 2, 21, 36, 4, 4, 2, 2, 4, 1, 3)
   NVF_M(4, 8, 2, 21, 36, 4, 4, 1, 9, 1, 4, 1)
@@ -515,6 +522,7 @@ extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const fl
   NVF_MF(2, 8, 33, 36, 18, 7, 4, 1, 7)
   NVF_MF(3, 8, 33, 36, 18, 7, 8, 1, 4)
   NVF_MF(4, 8, 33, 36, 18, 7, 4, 1, 4)
+  NVF_MF(5, 8, 33, 36, 18, 7, 4, 1, 2)     // 7 rows x 2 planes, four waves, two workgroups per CU
   NVF_MF(0, 8, 17, 20, 10, 8, 5, 1, 4)     // conv1 backward-data: 19 wide = 10 cells; 8 rows = 5 column tiles
   NVF_MF(2, 8, 17, 20, 10, 8, 5, 1, 2)
   NVF_MF(3, 8, 17, 20, 10, 19, 4, 2, 1)    // whole 19 x 20 planes (12 column tiles), 2 planes per workgroup: 36.5 us

@@ -29,6 +29,8 @@ R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
 _TAIL = os.environ.get("NVF_TAIL", "1") != "0"   # latent backward as one workgroup of a later launch (0: three launches)
 _STEM = os.environ.get("NVF_STEM", "1") != "0"   # fused stem launches (0: per-layer kernels)
 _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wide decoder (0: the VALU tile kernels)
+_CONV2_FWD_VAR = int(os.environ.get("NVF_CONV2_FWD_VAR", "0"))   # tile-shape variants of conv_k4_mfma (tuning)
+_CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
 _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
 
 
@@ -296,6 +298,8 @@ class TrainEngine:
             # conv1 at large batch: four planes per wave (variant 2: 124 vs 141 us at batch 256).  Every variant runs
             # the same per-output fmaf chain, so the bits -- and encode-at-any-batch == decode-at-batch-1 -- do not change
             var = 2 if (x.shape[-1] == 19 and x.shape[0] > 64) else None
+            if x.shape[-1] == 35 and _CONV2_FWD_VAR:
+                var = _CONV2_FWD_VAR
             return ops.conv3d_k4_mfma(x, L.wp_f, L.b_eff, 0, 0, act, variant=var)
         osz = tuple(s + 2 * L.pad - L.k + 1 for s in x.shape[2:])
         return ops.conv3d_gather(x, L.w_fwd, L.b_eff, L.cout, L.k, 1, L.pad, osz, act)
@@ -384,12 +388,14 @@ class TrainEngine:
                                      mask=mask)
             return dx if bias_out is None else (dx, False)
         if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
+            var = _CONV2_BWD_VAR if (g_out.shape[-1] == 32 and _CONV2_BWD_VAR) else None
             if bias_out is not None and mask is not None and addend is None:
-                base = self._wg.reserve(2048 * 8 * 4)
-                dx, nparts = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, mask=mask, bias_part=base)
+                base = self._wg.reserve(4096 * 8 * 4)
+                dx, nparts = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, mask=mask, bias_part=base,
+                                                variant=var)
                 self._wg.add_job(base, bias_out, nparts, 8)
                 return dx, True
-            dx = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, addend=addend, mask=mask)
+            dx = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, addend=addend, mask=mask, variant=var)
             return dx if bias_out is None else (dx, False)
         if bias_out is not None:
             return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, L.k, 1, L.k - 1 - L.pad, tuple(x_in.shape[2:]),

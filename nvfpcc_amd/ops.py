@@ -231,8 +231,9 @@ def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=
 
 
 _MFMA_VARIANT = int(os.environ.get("NVF_MFMA_VARIANT", "0"))
-# slabs (= workgroups) of the big head's weight gradient; VALU kernels: 256 was best (21 us at batch 16; 128: 26, 512: 24.5)
-_HEADS_SLABS = int(os.environ.get("NVF_HEADS_SLABS", "256"))
+# slabs (= workgroups) of the big head's weight gradient: 512 (matrix-core kernel inside the five-gradient launch:
+# 447.7 us of step kernels against 449.6 with 256 and 450.4 with 1024); the VALU kernels did best with 256
+_HEADS_SLABS = int(os.environ.get("NVF_HEADS_SLABS", "512"))
 
 
 def set_mfma_variant(v):

@@ -18,10 +18,17 @@ for r in csv.DictReader(open(f)):
 print(f"{name:24s} sum {tot:7.1f}  " + "  ".join(show))
 P
 }
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_engine.py tests/test_gpu_net.py -m gpu -q -x > gpurun_out/t10.log 2>&1; tail -3 gpurun_out/t10.log
-run sep256 NVF_HEADS_IN_TRUNK5=0 NVF_HEADS_SLABS=256
-run sep1024 NVF_HEADS_IN_TRUNK5=0 NVF_HEADS_SLABS=1024
-run in256 NVF_HEADS_IN_TRUNK5=1 NVF_HEADS_SLABS=256
-run in512 NVF_HEADS_IN_TRUNK5=1 NVF_HEADS_SLABS=512
-run in1024 NVF_HEADS_IN_TRUNK5=1 NVF_HEADS_SLABS=1024
-run in256b NVF_HEADS_IN_TRUNK5=1 NVF_HEADS_SLABS=256
+show_conv() { python3 - "$1" <<'P'
+import csv,glob,sys
+f=glob.glob(f"gpurun_out/ab_{sys.argv[1]}/**/*kernel_stats.csv",recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "conv_k4_mfma" in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-60:], r["Calls"], round(float(r["AverageNs"])/1000,1))
+P
+}
+python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "mfma or conv" > gpurun_out/t11.log 2>&1; tail -3 gpurun_out/t11.log
+run base A=1; show_conv base
+run fwd3 NVF_CONV2_FWD_VAR=3; show_conv fwd3
+run fwd7 NVF_CONV2_FWD_VAR=7; show_conv fwd7
+run bwd5 NVF_CONV2_BWD_VAR=5; show_conv bwd5
+run both NVF_CONV2_FWD_VAR=3 NVF_CONV2_BWD_VAR=5; show_conv both
+run base2 A=1
