@@ -319,13 +319,11 @@ __device__ __forceinline__ void mfma_store(const f32x4 (&acc)[C::NC][C::NT], con
   }
 }
 
-// Four-wave configurations whose two LDS buffers fit twice into a CU run TWO workgroups per CU (256 VGPRs each): one's
-// epilogue / tile hand-over / A-fragment prologue overlaps the other's MFMAs.
-template <class C>
-constexpr bool kTwoPerCU = C::NW == 4 && 2 * (2 * C::BUF * 4) <= 160 * 1024;
-
+// (Measured and dropped, round 3: four-wave configurations with TWO workgroups per CU -- 256 VGPRs each, both LDS buffer
+// pairs resident, one's epilogue / tile hand-over under the other's MFMAs -- conv2 forward 52.4 vs 51.0 us, backward-data
+// 81.5 vs 79.9: the kernels are bound by the MFMA rate at the clock the chip holds, not by their bubbles.)
 template <class C, int EPI>
-__global__ __launch_bounds__(C::NW * 64, kTwoPerCU<C> ? 2 : 1) void conv_k4_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             const float* __restrict__ addend,
                                                             const float* __restrict__ mask, MDims d, int total) {
@@ -449,7 +447,6 @@ static int launch_mfma(const float* x, const float* wp, const float* bias, float
   d.tiles_z = (d.dout + C::OZ - 1) / C::OZ;
   const int total = d.tiles_x * d.tiles_y * d.tiles_z * batch;
   int grid = (nvf_cu_count() + 7) / 8 * 8;                  // one workgroup per CU, a multiple of the 8 XCDs
-  if (kTwoPerCU<C>) grid *= 2;
   const int need = ((total + 7) / 8) * 8;
   if (grid > need) grid = need;
   if (bias_nparts) *bias_nparts = grid * C::NW;
