@@ -322,8 +322,7 @@ def run(args):
         while i < hi:
             e = min(hi, i + graphed.CAP)
             graphed.load_schedule([shares(k) for k in range(i, e)])
-            for _ in range(i, e):
-                graphed.replay()
+            graphed.replay_all()
             i = e
 
     probe = KernelProbe()
@@ -447,7 +446,8 @@ def run(args):
     launch_desc = "host" if (graphed is None and args.mode == "step") else (
         "hip-graph replay (step head .. backward), then all-reduce + Adam from the host"
         if (graphed is not None and graphed.collective == "host") else
-        "hip-graph replay (step head .. Adam in one graph; per-step scalars from a device-resident schedule)")
+        "hip-graph replay (step head .. Adam in one graph, %d steps per replay; per-step scalars from a "
+        "device-resident schedule)" % (graphed.unroll if graphed is not None and graphed.graph_u is not None else 1))
     collective_desc = None if eng.grad_hook is None else (
         "all-reduce captured in the step graph" if (graphed is not None and graphed.collective == "graph")
         else "all-reduce launched from the host")

@@ -25,10 +25,10 @@ for r in csv.DictReader(open(f)):
     if "conv_k4_mfma" in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-60:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "mfma or conv" > gpurun_out/t11.log 2>&1; tail -3 gpurun_out/t11.log
-run base A=1; show_conv base
-run fwd3 NVF_CONV2_FWD_VAR=3; show_conv fwd3
-run fwd7 NVF_CONV2_FWD_VAR=7; show_conv fwd7
-run bwd5 NVF_CONV2_BWD_VAR=5; show_conv bwd5
-run both NVF_CONV2_FWD_VAR=3 NVF_CONV2_BWD_VAR=5; show_conv both
+run base A=1
+run c256_256_128 NVF_WG_CAPS=256,256,128
+run c256_256_256 NVF_WG_CAPS=256,256,256
+run c256_512_256 NVF_WG_CAPS=256,512,256
+run c512_256_128 NVF_WG_CAPS=512,256,128
+run c256_128_64 NVF_WG_CAPS=256,128,64
 run base2 A=1
