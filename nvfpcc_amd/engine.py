@@ -882,12 +882,14 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._body(tail=tail)
+        self.out1, self.last1 = self.out, self.last          # each graph writes tensors of its own
         self.graph_u = None
         if tail and self.unroll > 1:
             self.graph_u = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_u):
                 for _ in range(self.unroll):
                     self._body(tail=tail)
+            self.out_u, self.last_u = self.out, self.last     # ... the unrolled one: those of its last step
 
     def _body(self, tail):
         eng = self.eng
@@ -954,6 +956,7 @@ class GraphedTrainStep:
         eng.noise_step += 1
         eng.opt_step += 1
         self.graph.replay()
+        self.out, self.last = self.out1, self.last1
         eng.last = dict(self.last)
         eng.last["n_pts"] = n_pts
         if self.collective == "host":
@@ -969,6 +972,7 @@ class GraphedTrainStep:
             eng.noise_step += U
             eng.opt_step += U
             self.graph_u.replay()
+            self.out, self.last = self.out_u, self.last_u
             eng.last = dict(self.last)
             eng.last["n_pts"] = n_pts
         while self.pending:
