@@ -17,6 +17,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef NVF_CT_DBG
+#define NVF_CT_DBG 0     // tuning builds: 1 = no MFMAs, 2 = no epilogue stores, 4 = no A-fragment staging (bit mask)
+#endif
+
 namespace {
 
 // number of A fragments per channel group: sum over classes (ez,ey) of (3-ez)(3-ey) * 3
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < NA4; ++u) {
       const int i = tid + u * 256;
-      av[u] = i < T::AS / 4 ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[u] = (i < T::AS / 4 && !(NVF_CT_DBG & 4)) ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if ((int)blockIdx.x < items) load_x(blockIdx.x);
     for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
             const float bv = bias ? bias[co] : 0.f;
             float* o = y + ((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox;
             const float v0 = nvf_act(res[c][ez][ey][r] + bv, act), v1 = nvf_act(res[c][ez][ey][r + 1] + bv, act);
+            if (NVF_CT_DBG & 2) { if (v0 == 12345.f) o[0] = v1; continue; }
             if (ox + 1 < NOUT) *(nvf_f2u*)o = nvf_f2u{v0, v1};
             else if (ox < NOUT) o[0] = v0;
           }
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
               for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
                 for (int ey = 0; ey < 2; ++ey)
-                  if (jz <= 2 - ez && jy <= 2 - ey)
+                  if (jz <= 2 - ez && jy <= 2 - ey && !(NVF_CT_DBG & 1))
                     acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
             }
           }

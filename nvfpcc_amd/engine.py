@@ -29,6 +29,7 @@ R, S, NONE = ops.ACT_RELU, ops.ACT_SIGMOID, ops.ACT_NONE
 _TAIL = os.environ.get("NVF_TAIL", "1") != "0"   # latent backward as one workgroup of a later launch (0: three launches)
 _STEM = os.environ.get("NVF_STEM", "1") != "0"   # fused stem launches (0: per-layer kernels)
 _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wide decoder (0: the VALU tile kernels)
+_VAR = {k: int(os.environ.get("NVF_VAR_" + k, "0")) for k in ("UP1F", "UP2F", "UP1B", "UP2B", "C1F", "C1B")}   # tile variants
 _CONV2_FWD_VAR = int(os.environ.get("NVF_CONV2_FWD_VAR", "0"))   # tile-shape variants of conv_k4_mfma (tuning)
 _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
 _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
@@ -287,7 +288,7 @@ class TrainEngine:
         if L.wp_t16 is not None:
             return ops.convT3d_k5s2_mfma16(x, L.wp_t16, L.b_eff, act, cout=L.cout, pad=L.pad)
         if L.wp_t is not None:
-            return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act)
+            return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act, variant=_VAR["UP1F" if L.cin == 16 else "UP2F"] or None)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
     def _conv(self, L, x, act):
@@ -300,6 +301,8 @@ class TrainEngine:
             var = 2 if (x.shape[-1] == 19 and x.shape[0] > 64) else None
             if x.shape[-1] == 35 and _CONV2_FWD_VAR:
                 var = _CONV2_FWD_VAR
+            if x.shape[-1] == 19 and _VAR["C1F"] and x.shape[0] <= 64:
+                var = _VAR["C1F"]
             return ops.conv3d_k4_mfma(x, L.wp_f, L.b_eff, 0, 0, act, variant=var)
         osz = tuple(s + 2 * L.pad - L.k + 1 for s in x.shape[2:])
         return ops.conv3d_gather(x, L.w_fwd, L.b_eff, L.cout, L.k, 1, L.pad, osz, act)
@@ -389,6 +392,8 @@ class TrainEngine:
             return dx if bias_out is None else (dx, False)
         if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
             var = _CONV2_BWD_VAR if (g_out.shape[-1] == 32 and _CONV2_BWD_VAR) else None
+            if g_out.shape[-1] == 16 and _VAR["C1B"]:
+                var = _VAR["C1B"]
             if bias_out is not None and mask is not None and addend is None:
                 base = self._wg.reserve(4096 * 8 * 4)
                 dx, nparts = ops.conv3d_k4_mfma(g_out, L.wp_b, None, 3, L.bwd_pair, NONE, mask=mask, bias_part=base,
@@ -409,7 +414,7 @@ class TrainEngine:
                                        mask=mask)
         if L.wp_s is not None:
             # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256)
-            var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else None
+            var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else (_VAR["UP1B" if L.cin == 16 else "UP2B"] or None)
             return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask, variant=var)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)

@@ -25,10 +25,24 @@ for r in csv.DictReader(open(f)):
     if "conv_k4_mfma" in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-60:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-run base A=1
-run c256_256_128 NVF_WG_CAPS=256,256,128
-run c256_256_256 NVF_WG_CAPS=256,256,256
-run c256_512_256 NVF_WG_CAPS=256,512,256
-run c512_256_128 NVF_WG_CAPS=512,256,128
-run c256_128_64 NVF_WG_CAPS=256,128,64
-run base2 A=1
+show_ct() { python3 - "$1" <<'P'
+import csv,glob,sys
+f=glob.glob(f"gpurun_out/ab_{sys.argv[1]}/**/*kernel_stats.csv",recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "convT_k5s2_mfma" in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-40:], r["Calls"], round(float(r["AverageNs"])/1000,1))
+P
+}
+showk() { python3 - "$1" "$2" <<'P'
+import csv,glob,sys
+f=glob.glob(f"gpurun_out/ab_{sys.argv[1]}/**/*kernel_stats.csv",recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
+P
+}
+run base A=1; showk base convT_k5s2; showk base conv_s2k5
+run up1f2 NVF_VAR_UP1F=2; showk up1f2 convT_k5s2
+for v in 2 3 4; do run up2f$v NVF_VAR_UP2F=$v; showk up2f$v convT_k5s2; done
+for v in 2 3; do run up2b$v NVF_VAR_UP2B=$v; showk up2b$v conv_s2k5; done
+for v in 2 3; do run up1b$v NVF_VAR_UP1B=$v; showk up1b$v conv_s2k5; done
+for v in 2 3; do run c1f$v NVF_VAR_C1F=$v; showk c1f$v "MCv<8, 0, 2"; done
+for v in 2 3; do run c1b$v NVF_VAR_C1B=$v; showk c1b$v "conv_k4_mfma"; done
