@@ -48,12 +48,12 @@ __global__ void pack_convT_mfma_kernel(const float* __restrict__ wf /* [cin][125
   }
 }
 
-template <int CIN_, int NIN_, int NCT_, int NSPLIT_>
+template <int CIN_, int NIN_, int NCT_, int NSPLIT_, int NW_ = 4>
 struct TMCfg {
   static constexpr int CIN = CIN_, NIN = NIN_, NCT = NCT_, NSPLIT = NSPLIT_;
   static constexpr int NCELL = NIN + 2;                        // cells per axis; outputs 2 NIN + 3
   static constexpr int NPT = (NCELL * NCELL + 15) / 16;        // column tiles of a cell plane
-  static constexpr int NW = 4, CPW = NW * NCT;                 // column tiles per workgroup
+  static constexpr int NW = NW_, NTH = NW_ * 64, CPW = NW * NCT;  // waves, threads, column tiles per workgroup
   static_assert(CPW * NSPLIT >= NPT, "the splits cover the plane");
   static constexpr int PLANE = (NCELL + 3) * NCELL + 18;       // LDS words per (channel, plane), zero margins
   static constexpr int cs_for(int v) { while (v % 32 != 16) ++v; return v; }
@@ -68,27 +68,27 @@ struct TMCfg {
 // (batch element, cell plane cz, column split) w, w + G, w + 2 G ... with the next item's three input planes already
 // in registers while this item's MFMAs issue (two workgroups share a CU and fill each other's barriers).
 template <class T>
-__global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ y, int act,
                                                        int items) {
   constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
-                NG = T::NG, NOUT = 2 * NIN + 3;
+                NG = T::NG, NOUT = 2 * NIN + 3, NTH = T::NTH;
   __shared__ __attribute__((aligned(16))) float xs[T::XS];
   __shared__ __attribute__((aligned(16))) float as[T::AS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- stage: every global load (A fragments, the three input planes cz-2 .. cz of every channel of the first
   // item) is issued before anything is waited for; the image is zeroed while they are in flight
-  constexpr int NA4 = (T::AS / 4 + 255) / 256;                 // float4 A loads per thread
+  constexpr int NA4 = (T::AS / 4 + NTH - 1) / NTH;             // float4 A loads per thread
   constexpr int ITEMS = CIN * 3 * NIN * NIN / 4;               // float4 input loads (rows are NIN = 8 or 16 floats)
-  constexpr int NX4 = (ITEMS + 255) / 256;
+  constexpr int NX4 = (ITEMS + NTH - 1) / NTH;
   float4 xv[NX4];
   auto load_x = [&](int item) {
     const int cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
     const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTH;
       const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
       const int zi = cz - 2 + pl;
       const bool ok = i < ITEMS && zi >= 0 && zi < NIN;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
   auto store_x = [&]() {                                       // planes outside the input are written as zeros
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTH;
       if (i < ITEMS) {
         const int xq = i % (NIN / 4), iy = (i / (NIN / 4)) % NIN, pl = (i / (NIN / 4 * NIN)) % 3, c = i / (NIN / 4 * NIN * 3);
         float* dst = xs + c * CS + pl * PLANE + (iy + 2) * NCELL + 4 * xq + 2;
@@ -111,14 +111,14 @@ __global__ __launch_bounds__(256) void convT_k5s2_mfma(const float* __restrict__
     float4 av[NA4];
 #pragma unroll
     for (int u = 0; u < NA4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTH;
       av[u] = (i < T::AS / 4 && !(NVF_CT_DBG & 4)) ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if ((int)blockIdx.x < items) load_x(blockIdx.x);
-    for (int i = tid * 4; i < T::XS; i += 256 * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid * 4; i < T::XS; i += NTH * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < NA4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTH;
       if (i < T::AS / 4) ((float4*)as)[i] = av[u];
     }
   }
@@ -224,12 +224,12 @@ extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const floa
   if (!x || !wp || !y || batch <= 0 || cout != 8) return NVF_EINVAL;
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
-#define NVF_TM(VAR, CI, NIN, NCT, NSPLIT)                                                              \
+#define NVF_TM(VAR, CI, NIN, NCT, NSPLIT, ...)                                                         \
   if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
-    using T = TMCfg<CI, NIN, NCT, NSPLIT>;                                                             \
+    using T = TMCfg<CI, NIN, NCT, NSPLIT, ##__VA_ARGS__>;                                              \
     const int items = batch * T::NCELL * NSPLIT;                                                       \
     constexpr int cap = 512;                               /* two resident workgroups per CU */        \
-    convT_k5s2_mfma<T><<<items < cap ? items : cap, 256, 0, s>>>(x, wp, bias, y, act, items);          \
+    convT_k5s2_mfma<T><<<items < cap ? items : cap, T::NTH, 0, s>>>(x, wp, bias, y, act, items);       \
     rc = NVF_OK;                                                                                       \
   }
   NVF_TM(0, 8, 16, 2, 3)     // up2: 21 column tiles per cell plane, 8 per workgroup
@@ -238,6 +238,9 @@ extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const floa
   NVF_TM(3, 8, 16, 6, 1)
   NVF_TM(4, 8, 16, 1, 6)
   NVF_TM(2, 16, 8, 1, 2)
+  NVF_TM(5, 16, 8, 1, 1, 8)  // up1: eight waves, one column tile each (two waves per SIMD instead of one on 160 CUs)
+  NVF_TM(5, 8, 16, 1, 3, 8)  // up2: eight waves x one tile, three splits
+  NVF_TM(6, 8, 16, 2, 2, 8)  // up2: eight waves x two tiles = 16 of 21 column tiles, two splits (11 empty slots of 32)
 #undef NVF_TM
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();
