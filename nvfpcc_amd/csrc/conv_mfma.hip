@@ -508,6 +508,8 @@ extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const fl
   NVF_M(5, 8, 2, 21, 36, 4, 4, 3, 3, 3, 2, 1)
   NVF_M(2, 8, 0, 9, 16, 2, 8, 4, 1, 4, 1, 4)
   NVF_M(3, 8, 0, 9, 16, 2, 8, 4, 1, 2, 1, 2)
+  NVF_M(4, 8, 0, 9, 16, 2, 8, 4, 1, 4, 2, 1)      // conv1 forward: the same 8 x 2 x 16 tile on eight waves (one plane each)
+  NVF_M(5, 8, 0, 9, 16, 2, 8, 4, 1, 4, 2, 2)      // 8 rows x 4 planes x 16 on eight waves
   NVF_M(2, 8, 2, 9, 20, 4, 4, 5, 1, 1, 2, 1)
   NVF_M(3, 8, 2, 9, 20, 4, 4, 5, 5, 5, 1, 1)
 #undef NVF_M

@@ -39,24 +39,6 @@ for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-python3 - <<'P'
-import torch, sys
-sys.path.insert(0, ".")
-from nvfpcc_amd import ops
-g = torch.Generator().manual_seed(1)
-for cin, din, vs in ((16, 8, (5,)), (8, 16, (5, 6))):
-    x = torch.randn(3, cin, din, din, din, generator=g).cuda()
-    w = (torch.randn(cin, 8, 5, 5, 5, generator=g) * 0.1).cuda()
-    b = torch.randn(8, generator=g).cuda()
-    wf, wb = ops.pack_convT_weight(w)
-    wp = ops.pack_convT_mfma(wf, cin)
-    ref = ops.convT3d_k5s2_mfma(x, wp, b, ops.ACT_RELU, variant=0)
-    for v in vs:
-        y = ops.convT3d_k5s2_mfma(x, wp, b, ops.ACT_RELU, variant=v)
-        print("cin", cin, "variant", v, "bit-identical to the default:", torch.equal(y, ref))
-P
-run base A=1; showk base convT_k5s2
-run up1f5 NVF_VAR_UP1F=5; showk up1f5 convT_k5s2
-run up2f5 NVF_VAR_UP2F=5; showk up2f5 convT_k5s2
-run up2f6 NVF_VAR_UP2F=6; showk up2f6 convT_k5s2
-run both55 NVF_VAR_UP1F=5 NVF_VAR_UP2F=5; showk both55 convT_k5s2
+run base A=1; showk base "MCv<8, 0, 2"
+run c1f4 NVF_VAR_C1F=4; showk c1f4 "MCv<8, 0, 2"
+run c1f5 NVF_VAR_C1F=5; showk c1f5 "MCv<8, 0, 2"
