@@ -26,8 +26,8 @@ struct S2Cfg {
   static constexpr int COG = PAIR ? 8 : 16;
   static constexpr int KEX = PAIR ? 7 : 5;                 // x taps of a row pair / of a row
   static constexpr int XSTEP = PAIR ? 4 : 2;               // input words between neighbouring columns
-  static constexpr int NW = RY * NWZ;
-  static_assert(NW == 4, "four waves");
+  static constexpr int NW = RY * NWZ, NTH = NW * 64;
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
   static constexpr int OY = 2 * RY, OZ = NWZ * NT;         // output rows / planes of a workgroup
   static constexpr int IZ = 2 * (OZ - 1) + 5, IY = 2 * (OY - 1) + 5;
   static constexpr int IZW = 2 * (NT - 1) + 5;             // input planes one wave reads
@@ -38,7 +38,7 @@ struct S2Cfg {
   static constexpr int AW = NFR * 64;
   static constexpr int ROWCH = (NIN + 3) / 4;              // float4 chunks per input row
   static constexpr int XITEMS = 4 * IZ * IY * ROWCH;
-  static constexpr int NX4 = (XITEMS + 255) / 256, NA4 = (AW / 4 + 255) / 256;
+  static constexpr int NX4 = (XITEMS + NTH - 1) / NTH, NA4 = (AW / 4 + NTH - 1) / NTH;
   static_assert(RS >= NIN && (XW + AW) * 4 <= 160 * 1024, "LDS");
 };
 
@@ -60,7 +60,7 @@ __global__ void pack_s2k5_mfma_kernel(const float* __restrict__ gw /* [cig][125]
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void conv_s2k5_mfma(const float* __restrict__ g, const float* __restrict__ wp,
+__global__ __launch_bounds__(C::NTH) void conv_s2k5_mfma(const float* __restrict__ g, const float* __restrict__ wp,
                                                       float* __restrict__ dx, const float* __restrict__ addend,
                                                       const float* __restrict__ mask, int cig) {
   constexpr int NIN = C::NIN, NOUT = C::NOUT, RS = C::RS, PS = C::PS, CS = C::CS, KEX = C::KEX, NT = C::NT,
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_s2k5_mfma(const float* __restrict__ 
     const float* gg = gb + (size_t)grp * 4 * NIN * NIN * NIN;
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * C::NTH;
       const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
       const int gz = gz0 + zi, gy = gy0 + yi;
       const bool ok = i < C::XITEMS && gz < NIN && gy < NIN;
@@ -104,14 +104,14 @@ __global__ __launch_bounds__(256) void conv_s2k5_mfma(const float* __restrict__ 
     const float4* ap = (const float4*)(wp + (size_t)grp * C::AW);
 #pragma unroll
     for (int u = 0; u < NA4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * C::NTH;
       av[u] = i < C::AW / 4 ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * C::NTH;
       if (i < C::XITEMS) {
         const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
         float* d = xs + c * CS + zi * PS + yi * RS + 4 * xq;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_s2k5_mfma(const float* __restrict__ 
     }
 #pragma unroll
     for (int u = 0; u < NA4; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * C::NTH;
       if (i < C::AW / 4) ((float4*)as)[i] = av[u];
     }
   };
@@ -209,7 +209,7 @@ extern "C" int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, 
 #define NVF_S2(VAR, CIG, COGV, NIN, NOUT, RY, NWZ, NT, RS)                                             \
   if (rc == 1 && variant == VAR && cig == CIG && cog == COGV && din == NIN) {                          \
     using C = S2Cfg<(COGV == 8), NIN, NOUT, RY, NWZ, NT, RS>;                                          \
-    conv_s2k5_mfma<C><<<batch * (NOUT / C::OY) * (NOUT / C::OZ), 256, 0, s>>>(g, wp, dx, addend, mask, cig); \
+    conv_s2k5_mfma<C><<<batch * (NOUT / C::OY) * (NOUT / C::OZ), C::NTH, 0, s>>>(g, wp, dx, addend, mask, cig); \
     rc = NVF_OK;                                                                                       \
   }
   NVF_S2(0, 8, 8, 35, 16, 2, 2, 2, 37)     // up2 backward-data: 4 rows x 4 planes per workgroup
@@ -218,6 +218,9 @@ extern "C" int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, 
   NVF_S2(3, 8, 8, 35, 16, 1, 4, 2, 37)
   NVF_S2(2, 8, 16, 19, 8, 2, 2, 2, 24)
   NVF_S2(3, 8, 16, 19, 8, 1, 4, 1, 24)
+  NVF_S2(5, 8, 8, 35, 16, 2, 4, 1, 37)     // up2: the same 4 rows x 4 planes on eight waves (one plane each)
+  NVF_S2(6, 8, 8, 35, 16, 4, 2, 1, 37)     // up2: 8 rows x 2 planes on eight waves
+  NVF_S2(5, 8, 16, 19, 8, 4, 2, 1, 24)     // up1: 8 rows x 2 planes on eight waves (64 workgroups)
 #undef NVF_S2
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();
