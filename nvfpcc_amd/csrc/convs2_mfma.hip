@@ -80,25 +80,31 @@ __global__ __launch_bounds__(C::NTH) void conv_s2k5_mfma(const float* __restrict
   const int gz0 = 2 * oz0, gy0 = 2 * oy0;
 
   float4 xv[NX4], av[NA4];
+  // input tile through buffer loads: descriptor = the channel group of this batch element (scalar), soffset = the
+  // tile's origin (scalar), voffset = a per-thread constant (or beyond the range when the row lies outside the tensor:
+  // the load returns 0) -- no per-element address arithmetic.  Rows are NIN = 35 / 19 words: 4-byte aligned 16-byte
+  // loads; the last chunk of a row holds NIN % 4 elements, its other components are cleared.
+  int xvoff[NX4];
+#pragma unroll
+  for (int u = 0; u < NX4; ++u) {
+    const int i = tid + u * C::NTH;
+    const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
+    const bool ok = i < C::XITEMS && gz0 + zi < NIN && gy0 + yi < NIN;
+    xvoff[u] = ok ? (((c * NIN + zi) * NIN + yi) * NIN + 4 * xq) * 4 : 0x7ffffff0;
+  }
+  const int xsoff = ((gz0 * NIN + gy0) * NIN) * 4;
   auto load = [&](int grp) {
-    const float* gg = gb + (size_t)grp * 4 * NIN * NIN * NIN;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gb + (size_t)grp * 4 * NIN * NIN * NIN), 0, 4 * NIN * NIN * NIN * 4, 0x00020000);
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
-      const int i = tid + u * C::NTH;
-      const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
-      const int gz = gz0 + zi, gy = gy0 + yi;
-      const bool ok = i < C::XITEMS && gz < NIN && gy < NIN;
-      const float* p = gg + (((size_t)c * NIN + gz) * NIN + gy) * NIN + 4 * xq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        if (4 * xq + 3 < NIN) {
-          v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
-        } else {                                  // the last chunk of a row holds NIN % 4 elements
-          v.x = p[0];
-          if (4 * xq + 1 < NIN) v.y = p[1];
-          if (4 * xq + 2 < NIN) v.z = p[2];
-        }
-      }
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 w = __builtin_amdgcn_raw_buffer_load_b128(rg, xvoff[u], xsoff, 0);
+      float4 v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+      const int xq = (tid + u * C::NTH) % ROWCH;
+      if (4 * xq + 1 >= NIN) v.y = 0.f;
+      if (4 * xq + 2 >= NIN) v.z = 0.f;
+      if (4 * xq + 3 >= NIN) v.w = 0.f;
       xv[u] = v;
     }
     const float4* ap = (const float4*)(wp + (size_t)grp * C::AW);

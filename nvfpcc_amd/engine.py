@@ -417,7 +417,9 @@ class TrainEngine:
                                        mask=mask)
         if L.wp_s is not None:
             # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256)
-            var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else (_VAR["UP1B" if L.cin == 16 else "UP2B"] or None)
+            # up2 at batch <= 64: 8 rows x 2 planes on eight waves (variant 6: 25.3 -> 22.8 us at batch 16; bit-identical)
+            var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else (
+                _VAR["UP1B" if L.cin == 16 else "UP2B"] or (6 if (L.cin == 8 and g_out.shape[0] <= 64) else None))
             return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask, variant=var)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)
