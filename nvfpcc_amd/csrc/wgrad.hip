@@ -307,11 +307,18 @@ __device__ __forceinline__ void wgrad_k4_mfma_body(const float* __restrict__ g, 
 #pragma unroll
     for (int u = 0; u < UG; ++u) gv[u] = wg_ld4(rg, gvoff, gs + u * CSTEP * W * W * W * 4);
     const __amdgpu_buffer_rsrc_t rx = wg_rsrc(x + (size_t)n * 8 * WQ * WQ * WQ, 8 * WQ * WQ * WQ * 4);
-    const int xs = ((z0 * WQ + y0) * WQ) * 4;
+    // a RUNNING scalar offset (one s_add between two loads): with independent offsets the compiler computes all 56
+    // up front and spills scalar registers
+    int xs = ((z0 * WQ + y0) * WQ) * 4;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
       const int seg = u / PPS, part = u % PPS, c = seg / (TZ + 3), zz = seg % (TZ + 3);
-      xv[u] = wg_ld(rx, xvoff[part], xs + (c * WQ + zz) * WQ * WQ * 4);
+      xv[u] = wg_ld(rx, xvoff[part], xs);
+      if (part == PPS - 1) {
+        const int nseg = seg + 1, nc = nseg / (TZ + 3), nz = nseg % (TZ + 3);
+        xs += ((nc * WQ + nz) - (c * WQ + zz)) * WQ * WQ * 4;
+        asm volatile("" : "+s"(xs));
+      }
     }
   };
 #else
@@ -497,18 +504,21 @@ static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* s
 // round-robin to the four waves (no cross-wave reduction); a workgroup walks items (n, 2 input planes, 2 input
 // rows) with the next item's global loads already in registers, and writes one slab at the end.
 // ---------------------------------------------------------------------------------------------------
-template <int TZ_, int TY_>
+// W = input extent (16: up2, 8: up1), CIB = row blocks of eight input channels (1: up2, 2: up1's 16 channels -- two A
+// fragments and two accumulator sets per step, the same B fragments)
+template <int TZ_, int TY_, int W_ = 16, int CIB_ = 1>
 struct TWCfg {
-  static constexpr int W = 16, WG = 35, TZ = TZ_, TY = TY_;
+  static constexpr int W = W_, WG = 2 * W_ + 3, TZ = TZ_, TY = TY_, CIB = CIB_, CI = 8 * CIB_;
   static constexpr int GZ = 2 * TZ + 3, GY = 2 * TY + 3;
-  static constexpr int GRS = 36, XRS = 22;                  // g row: 35 words; x row: u = ix + 1 in 0..20, zero outside 1..16
+  static constexpr int GRS = WG + 1, XRS = W + 6;           // g row: WG words; x row: u = ix + 1 in 0..W + 4, zero outside 1..W
   static constexpr int mod32(int v, int r) { return v + ((r - v % 32) + 32) % 32; }
   static constexpr int GCS = mod32(GZ * GY * GRS, 8), XCS = mod32(TZ * TY * XRS, 8);
-  static constexpr int GOFF = 0, XOFF = 8 * GCS, LDSF = 8 * GCS + 8 * XCS;
-  static constexpr int NXE = 8 * TZ * TY * W;                             // x elements to load per item
-  // g tile: for one (channel, plane) the GY rows of 35 words are contiguous: NSEG segments of SEG words
+  static constexpr int GOFF = 0, XOFF = 8 * GCS, LDSF = 8 * GCS + CI * XCS;
+  static constexpr int NXE = CI * TZ * TY * W;                            // x elements to load per item
+  // g tile: for one (channel, plane) the GY rows of WG words are contiguous: NSEG segments of SEG words
   static constexpr int SEG = GY * WG, PPS = (SEG + 255) / 256, NSEG = 8 * GZ;
   static constexpr int UG = NSEG * PPS, UX = (NXE + 255) / 256;
+  static constexpr int JT = CI * 8 * 125;                                 // slab length
   static_assert(LDSF * 4 <= 160 * 1024, "LDS");
 };
 
@@ -516,7 +526,7 @@ template <class C>
 __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x, const float* __restrict__ g,
                                                      float* __restrict__ slabs, const WgDims& d, int bx, float* lds) {
   constexpr int W = C::W, WG = C::WG, TZ = C::TZ, TY = C::TY, GZ = C::GZ, GY = C::GY, GRS = C::GRS, XRS = C::XRS,
-                GCS = C::GCS, XCS = C::XCS, UG = C::UG, UX = C::UX;
+                GCS = C::GCS, XCS = C::XCS, UG = C::UG, UX = C::UX, CIB = C::CIB, CI = C::CI;
   float* ldsG = lds + C::GOFF;
   float* ldsX = lds + C::XOFF;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -527,11 +537,12 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
   // rows ky = 2 (ty - 5) + sB (sA = 0 rows only).  Wave w owns tiles j = w + 4 i, i < 10 -- the same instruction
   // stream for every wave, the per-lane LDS word of tile i sits in boff[i].
   constexpr int NTW = 10;
-  f32x4 acc[NTW];
+  f32x4 acc[CIB][NTW];
   int boff[NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
-    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rb = 0; rb < CIB; ++rb) acc[rb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int j = wave + 4 * i, kz = j >> 3, ty = j & 7;
     boff[i] = ty < 5 ? ch * GCS + 2 * kk + sh + (kz * GY + ty) * GRS
                      : ch * GCS + 2 * kk + 4 + (kz * GY + 2 * (ty - 5) + sh) * GRS;
@@ -558,13 +569,18 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
     const int n = item / tiles, t = item % tiles;
     const int y0 = (t % tiles_y) * TY, z0 = (t / tiles_y) * TZ;
     const __amdgpu_buffer_rsrc_t rg = wg_rsrc(g + (size_t)n * 8 * WG * WG * WG, 8 * WG * WG * WG * 4);
-    const int gs = ((2 * z0 * WG + 2 * y0) * WG) * 4;
+    int gs = ((2 * z0 * WG + 2 * y0) * WG) * 4;           // running scalar offset (see wgrad_k4_mfma_body)
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
       const int seg = u / C::PPS, part = u % C::PPS, c = seg / GZ, zz = seg % GZ;
-      gv[u] = wg_ld(rg, gvoff[part], gs + (c * WG + zz) * WG * WG * 4);
+      gv[u] = wg_ld(rg, gvoff[part], gs);
+      if (part == C::PPS - 1) {
+        const int nseg = seg + 1, nc = nseg / GZ, nz = nseg % GZ;
+        gs += ((nc * WG + nz) - (c * WG + zz)) * WG * WG * 4;
+        asm volatile("" : "+s"(gs));
+      }
     }
-    const __amdgpu_buffer_rsrc_t rx = wg_rsrc(x + (size_t)n * 8 * W * W * W, 8 * W * W * W * 4);
+    const __amdgpu_buffer_rsrc_t rx = wg_rsrc(x + (size_t)n * CI * W * W * W, CI * W * W * W * 4);
     const int xs = ((z0 * W + y0) * W) * 4;
 #pragma unroll
     for (int u = 0; u < UX; ++u) xv[u] = wg_ld(rx, xvoff, xs + u * CSTEP * W * W * W * 4);
@@ -580,7 +596,7 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
       const int e = tid + part * 256;
       gv[u] = e < C::SEG ? gt[(c * WG + zz) * WG * WG + e] : 0.f;
     }
-    const float* xn = x + (size_t)n * 8 * W * W * W;
+    const float* xn = x + (size_t)n * CI * W * W * W;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
       const int e = tid + u * 256;
@@ -622,21 +638,28 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
         const int r = st / NXG, zl = r / TY, yl = r % TY;
         return ((2 * zl) * GY + 2 * yl) * GRS + 8 * (st % NXG);
       };
-      float a_cur = pa[a_off(0)], b_cur[NTW];
+      float a_cur[CIB], b_cur[NTW];
+#pragma unroll
+      for (int rb = 0; rb < CIB; ++rb) a_cur[rb] = pa[rb * 8 * XCS + a_off(0)];
 #pragma unroll
       for (int i = 0; i < NTW; ++i) b_cur[i] = ldsG[boff[i] + b_off(0)];
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {
-        float a_nxt = 0.f, b_nxt[NTW];
+        float a_nxt[CIB], b_nxt[NTW];
         if (st + 1 < NSTEP) {
-          a_nxt = pa[a_off(st + 1)];
+#pragma unroll
+          for (int rb = 0; rb < CIB; ++rb) a_nxt[rb] = pa[rb * 8 * XCS + a_off(st + 1)];
 #pragma unroll
           for (int i = 0; i < NTW; ++i) b_nxt[i] = ldsG[boff[i] + b_off(st + 1)];
         }
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[i], acc[i], 0, 0, 0);
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+          for (int rb = 0; rb < CIB; ++rb)
+            acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[rb], b_cur[i], acc[rb][i], 0, 0, 0);
         if (st + 1 < NSTEP) {
-          a_cur = a_nxt;
+#pragma unroll
+          for (int rb = 0; rb < CIB; ++rb) a_cur[rb] = a_nxt[rb];
 #pragma unroll
           for (int i = 0; i < NTW; ++i) b_cur[i] = b_nxt[i];
         }
@@ -644,19 +667,21 @@ __device__ __forceinline__ void wgrad_s2k5_mfma_body(const float* __restrict__ x
     }
   }
   // lane holds column n = (co, sB) = lane & 15 and rows m = 4 (lane >> 4) + r = (ci, sA)
-  float* slab = slabs + (size_t)bx * 8000;
+  float* slab = slabs + (size_t)bx * C::JT;
   const int co = (lane & 15) >> 1, sB = lane & 1;
 #pragma unroll
-  for (int i = 0; i < NTW; ++i) {
-    const int j = wave + 4 * i, kz = j >> 3, ty = j & 7;
+  for (int rb = 0; rb < CIB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 4 * (lane >> 4) + r, ci = m >> 1, sA = m & 1;
-      float* o = slab + (ci * 8 + co) * 125 + kz * 25;
-      if (ty < 5) o[ty * 5 + 2 * sA + sB] = acc[i][r];
-      else if (sA == 0 && 2 * (ty - 5) + sB < 5) o[(2 * (ty - 5) + sB) * 5 + 4] = acc[i][r];
+    for (int i = 0; i < NTW; ++i) {
+      const int j = wave + 4 * i, kz = j >> 3, ty = j & 7;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (lane >> 4) + r, ci = 8 * rb + (m >> 1), sA = m & 1;
+        float* o = slab + (ci * 8 + co) * 125 + kz * 25;
+        if (ty < 5) o[ty * 5 + 2 * sA + sB] = acc[rb][i][r];
+        else if (sA == 0 && 2 * (ty - 5) + sB < 5) o[(2 * (ty - 5) + sB) * 5 + 4] = acc[rb][i][r];
+      }
     }
-  }
 }
 
 template <class C>
@@ -673,13 +698,17 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
 // the latent tail queued in the caller's NvfStepCtx by nvf_latent_tail_queue: consumed by the next
 // nvf_wgrad_mfma3_partial / nvf_wgrad_trunk5_partial or nvf_wgrad_reduce_multi_and_sums call with that context
 
-struct WgMfma3 {
-  const float* p[3];
-  const float* q[3];
-  float* slabs[3];
-  WgDims d[3];
-  int32_t n[3];
+struct WgMfma3 {                 // jobs 0-2: conv2, up2, conv1; job 3 (n[3] may be 0): up1 on the matrix cores
+  const float* p[4];
+  const float* q[4];
+  float* slabs[4];
+  WgDims d[4];
+  int32_t n[4];
 };
+#ifndef NVF_UP1_MFMA
+#define NVF_UP1_MFMA 1           // 0: up1's gradient as a VALU tile job (wgrad_tiled), as before round 3
+#endif
+using WgUp1 = TWCfg<2, 2, 8, 2>;
 constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 template <class C0, class T1, class C2, class U0, class U1, bool TAIL>
@@ -687,18 +716,28 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
   static_assert(U0::NT == 256 && U1::NT == 256, "one workgroup size");
   __shared__ __attribute__((aligned(16))) float lds[wg_max3(wg_max3(C0::LDSF, T1::LDSF, C2::LDSF), kWgEpiFloats,
                                                             wg_max3(wg_max3(kTailLds, U0::LDSF, U1::LDSF),
-                                                                    wg_max3(HeadW0::SMEM, HeadW1::SMEM, HeadW2::SMEM), 0))];
+                                                                    wg_max3(HeadW0::SMEM, HeadW1::SMEM, HeadW2::SMEM),
+                                                                    WgUp1::LDSF))];
+#ifndef NVF_WG_SKIP
+#define NVF_WG_SKIP 0                  // tuning builds: bit j set = job j does nothing (results are then meaningless)
+#endif
   int bid = blockIdx.x;
   if (TAIL) {                          // the latent tail: one workgroup, dispatched first, hidden behind the gradients
-    if (bid == 0) { latent_tail_body(tail, lds); return; }
+    if (bid == 0) { if (!(NVF_WG_SKIP & 32)) latent_tail_body(tail, lds); return; }
     --bid;
   }
-  if (bid < m.n[0]) { wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds); return; }
+  if (bid < m.n[0]) { if (!(NVF_WG_SKIP & 1)) wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds); return; }
   bid -= m.n[0];
-  if (bid < m.n[1]) { wgrad_s2k5_mfma_body<T1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid, lds); return; }
+  if (bid < m.n[1]) { if (!(NVF_WG_SKIP & 2)) wgrad_s2k5_mfma_body<T1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid, lds); return; }
   bid -= m.n[1];
-  if (bid < m.n[2]) { wgrad_k4_mfma_body<C2>(m.p[2], m.q[2], m.slabs[2], m.d[2], bid, lds); return; }
+  if (bid < m.n[2]) { if (!(NVF_WG_SKIP & 4)) wgrad_k4_mfma_body<C2>(m.p[2], m.q[2], m.slabs[2], m.d[2], bid, lds); return; }
   bid -= m.n[2];
+  // up1 (16 -> 8 channels, 8^3 -> 19^3) on the matrix cores: as a VALU tile job it cost 13 us of this launch for 4 % of
+  // its multiply-adds (measured by skipping it); the stride-2 body with two row blocks of eight input channels
+  if (bid < m.n[3]) { if (!(NVF_WG_SKIP & 8)) wgrad_s2k5_mfma_body<WgUp1>(m.p[3], m.q[3], m.slabs[3], m.d[3], bid, lds); return; }
+  bid -= m.n[3];
+  if (NVF_WG_SKIP & 8) { if (bid < u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return; }
+  if ((NVF_WG_SKIP & 16) && bid >= u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return;
   // the two small transposed convolutions' gradients (VALU kernels, latency-bound on their own) fill the slots the
   // short matrix-core workgroups leave while conv2's are still running
   if (bid < u.nx[0] * u.ny[0]) {
@@ -779,6 +818,19 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
   int grid = m.n[0] + m.n[1] + m.n[2];
   if (njobs == 5) {
     fill_up1_conv0<U0, U1>(u, ps + 3, qs + 3, slabs + 3, batch, nslabs + 3);
+#if NVF_UP1_MFMA
+    {
+      WgDims d{};
+      d.batch = batch; d.bc = 8; d.items = batch * (WgUp1::W / WgUp1::TZ) * (WgUp1::W / WgUp1::TY);
+      int n = d.items < 128 ? d.items : 128;
+      d.items_per_wg = (d.items + n - 1) / n;
+      n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
+      m.p[3] = ps[3]; m.q[3] = qs[3]; m.slabs[3] = slabs[3]; m.d[3] = d; m.n[3] = n;
+      nslabs[3] = n;
+      u.nx[0] = 0;                       // the tile job of up1 is not dispatched
+      grid += n;
+    }
+#endif
     grid += u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1];
   }
   HeadsW3 hw{};

@@ -195,8 +195,11 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     outs5 = [torch.empty_like(o) for o in outs + outs2]
     wg.add_trunk5([g5, y3, g3, y1, h0], [y4, g4, y2, g2, g1], outs5)
     wg.finish()
-    for got, ref in zip(outs5, outs + outs2):
-        assert torch.equal(got, ref)
+    for i, (got, ref) in enumerate(zip(outs5, outs + outs2)):
+        if i == 3:     # up1 runs on the matrix cores inside the five-gradient launch (another summation order)
+            assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+        else:
+            assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("mode,c", [("train", 3), ("eval", 8)])

@@ -39,24 +39,6 @@ for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-python3 - <<'P'
-import torch, sys
-sys.path.insert(0, ".")
-from nvfpcc_amd import ops
-g = torch.Generator().manual_seed(1)
-for cin, dout, vs in ((8, 16, (5, 6)), (16, 8, (5,))):
-    din = 2 * dout + 3
-    gy = torch.randn(3, 8, din, din, din, generator=g).cuda()
-    w = (torch.randn(cin, 8, 5, 5, 5, generator=g) * 0.1).cuda()
-    mask = torch.randn(3, cin, dout, dout, dout, generator=g).cuda()
-    wf, wb = ops.pack_convT_weight(w)
-    wp = ops.pack_s2k5_mfma(wb, 8, cin)
-    ref = ops.conv3d_s2k5_mfma(gy, wp, cin, mask=mask, variant=0)
-    for v in vs:
-        y = ops.conv3d_s2k5_mfma(gy, wp, cin, mask=mask, variant=v)
-        print("cin", cin, "variant", v, "bit-identical to the default:", torch.equal(y, ref))
-P
-run base A=1; showk base conv_s2k5
-run up2b5 NVF_VAR_UP2B=5; showk up2b5 conv_s2k5
-run up2b6 NVF_VAR_UP2B=6; showk up2b6 conv_s2k5
-run up1b5 NVF_VAR_UP1B=5; showk up1b5 conv_s2k5
+run base A=1
+for v in 1 2 4 8 16 32 30 62; do run wgs$v NVF_LIB=$PWD/nvfpcc_amd/ab/libnvf_hip_wgs$v.so; done
+run wgd2 NVF_LIB=$PWD/nvfpcc_amd/ab/libnvf_hip_wgd2.so
