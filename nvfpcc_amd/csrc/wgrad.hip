@@ -803,7 +803,7 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     // two half of that -- fewer slabs to add up afterwards, same launch time
     static int caps[3] = {0, 0, 0};
     if (!caps[0]) {                                          // tuning hook: NVF_WG_CAPS=a,b,c (each <= 512)
-      int c[3] = {256, 128, 128};
+      int c[3] = {256, 128, 64};     // conv1: 64 (with up1 at 64: 86.9 us for the launch against 92-93 with 128 / 128)
       if (const char* e = getenv("NVF_WG_CAPS")) sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
       for (int i = 0; i < 3; ++i) caps[i] = c[i] < 1 ? 1 : (c[i] > 512 ? 512 : c[i]);
     }
@@ -822,7 +822,9 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     {
       WgDims d{};
       d.batch = batch; d.bc = 8; d.items = batch * (WgUp1::W / WgUp1::TZ) * (WgUp1::W / WgUp1::TY);
-      int n = d.items < 128 ? d.items : 128;
+      static int up1_cap = 0;
+      if (!up1_cap) { const char* e = getenv("NVF_UP1_CAP"); up1_cap = e ? atoi(e) : 64; if (up1_cap < 1) up1_cap = 64; }
+      int n = d.items < up1_cap ? d.items : up1_cap;
       d.items_per_wg = (d.items + n - 1) / n;
       n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
       m.p[3] = ps[3]; m.q[3] = qs[3]; m.slabs[3] = slabs[3]; m.d[3] = d; m.n[3] = n;
@@ -911,6 +913,14 @@ __global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ s
   const int j = blockIdx.x * 64 + jl;
   // slice sl of 16 takes slabs sl, sl + 16, ...: up to 16 of them are fetched before the first add (one round trip
   // for <= 256 slabs), then added in ascending order in four interleaved chains and a fixed tree
+  // the optimiser state of this output (slice 0 applies the update at the end): requested now, under the slab loads
+  float pm = 0.f, pv = 0.f, pp = 0.f;
+  long ai = -1;
+  if (d.fuse && sl == 0 && j < jtotal) {
+    ai = (d.dw[t] + j) - d.adam.g_base;
+    if (ai >= 0 && ai < d.adam.n) { pm = d.adam.m_base[ai]; pv = d.adam.v_base[ai]; pp = d.adam.p_base[ai]; }
+    else ai = -1;
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < jtotal) {
     for (int g0 = sl; g0 < nslab; g0 += 256) {
@@ -1108,6 +1118,14 @@ __device__ __forceinline__ void wgrad_reduce_multi_body(const WgReduceMulti& d, 
   // the same in wgrad_reduce and wgrad_reduce_multi
   // (slice sl of 16 takes slabs sl, sl + 16, ...: up to 16 of them are fetched before the first add -- one round trip
   // for <= 256 slabs -- then added in ascending order in four interleaved chains)
+  // the optimiser state of this output (slice 0 applies the update at the end): requested now, under the slab loads
+  float pm = 0.f, pv = 0.f, pp = 0.f;
+  long ai = -1;
+  if (d.fuse && sl == 0 && j < jtotal) {
+    ai = (d.dw[t] + j) - d.adam.g_base;
+    if (ai >= 0 && ai < d.adam.n) { pm = d.adam.m_base[ai]; pv = d.adam.v_base[ai]; pp = d.adam.p_base[ai]; }
+    else ai = -1;
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < jtotal) {
     for (int g0 = sl; g0 < nslab; g0 += 256) {
@@ -1129,7 +1147,7 @@ __device__ __forceinline__ void wgrad_reduce_multi_body(const WgReduceMulti& d, 
       for (int k = 1; k < 16; ++k) v += part[k][jl];
       if (d.add[t]) v += d.add[t][j];
       d.dw[t][j] = v;
-      if (d.fuse) bad = adam_fused_elem(d.adam, d.dw[t] + j, v);
+      if (d.fuse && ai >= 0) bad = adam_fused_apply(d.adam, ai, v, pm, pv, pp);
     }
     if (d.fuse && d.adam.bad_count) {          // wave 0 of the workgroup: integer-valued, order-free
       const unsigned long long any = __ballot(bad);

@@ -39,6 +39,10 @@ for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-run base A=1
-for v in 1 2 4 8 16 32 30 62; do run wgs$v NVF_LIB=$PWD/nvfpcc_amd/ab/libnvf_hip_wgs$v.so; done
-run wgd2 NVF_LIB=$PWD/nvfpcc_amd/ab/libnvf_hip_wgd2.so
+run a NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=64
+run b NVF_WG_CAPS=256,128,32 NVF_UP1_CAP=64
+run c NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=48
+run d NVF_WG_CAPS=256,96,64 NVF_UP1_CAP=64
+run e NVF_WG_CAPS=256,64,64 NVF_UP1_CAP=64
+run f NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=64 NVF_HEADS_SLABS=256
+run a2 NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=64
