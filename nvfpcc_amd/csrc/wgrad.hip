@@ -913,14 +913,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce(const float* __restrict__ s
   const int j = blockIdx.x * 64 + jl;
   // slice sl of 16 takes slabs sl, sl + 16, ...: up to 16 of them are fetched before the first add (one round trip
   // for <= 256 slabs), then added in ascending order in four interleaved chains and a fixed tree
-  // the optimiser state of this output (slice 0 applies the update at the end): requested now, under the slab loads
-  float pm = 0.f, pv = 0.f, pp = 0.f;
-  long ai = -1;
-  if (d.fuse && sl == 0 && j < jtotal) {
-    ai = (d.dw[t] + j) - d.adam.g_base;
-    if (ai >= 0 && ai < d.adam.n) { pm = d.adam.m_base[ai]; pv = d.adam.v_base[ai]; pp = d.adam.p_base[ai]; }
-    else ai = -1;
-  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < jtotal) {
     for (int g0 = sl; g0 < nslab; g0 += 256) {
