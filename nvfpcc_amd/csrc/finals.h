@@ -28,18 +28,6 @@ __device__ __forceinline__ int adam_fused_elem(const NvfAdamFuse& a, const float
   a.p_base[i] = a.p_base[i] - step_size * (mi / denom);
   return 0;
 }
-// the same update with the element's state already in registers (the caller fetched it early)
-__device__ __forceinline__ int adam_fused_apply(const NvfAdamFuse& a, long i, float gi, float m0, float v0, float p0) {
-  if (!(fabsf(gi) <= 3.402823466e38f)) return 1;
-  const float step_size = a.coef_dev ? a.coef_dev[0] : a.coef0_host, bc2_sqrt = a.coef_dev ? a.coef_dev[1] : a.coef1_host;
-  const float mi = m0 * a.beta1 + gi * (1.f - a.beta1);
-  const float vi = v0 * a.beta2 + (gi * gi) * (1.f - a.beta2);
-  a.m_base[i] = mi;
-  a.v_base[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
-  a.p_base[i] = p0 - step_size * (mi / denom);
-  return 0;
-}
 __device__ __forceinline__ NvfAdamFuse adam_fuse_of(const NvfStepTail& t) {
   NvfAdamFuse a{};
   a.g_base = t.g; a.p_base = t.p; a.m_base = t.m; a.v_base = t.v; a.n = t.n; a.coef_dev = t.coef_dev;
