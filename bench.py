@@ -38,6 +38,7 @@ UP2_MACS = {"8,16,8,8": 32768000, "16,32,16,16": 131072000}
 CONV1_MACS = {"8,16,8,8": 16777216, "16,32,16,16": 67108864}
 UP1_MACS = {"8,16,8,8": 8192000, "16,32,16,16": 32768000}
 CONV0_MACS = {"8,16,8,8": 1024000, "16,32,16,16": 4096000}
+HEADS_MACS = {"8,16,8,8": 27 * (8 * 32 ** 3 + 8 * 16 ** 3 + 16 * 8 ** 3), "16,32,16,16": 27 * (16 * 32 ** 3 + 16 * 16 ** 3 + 32 * 8 ** 3)}
 BYTES_PER_BLOCK = {"8,16,8,8": 15050624, "16,32,16,16": 29092224}  # layer-granular HBM model, SURVEY.md 8(d)
 PEAK_FP32_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: fp32 vector = matrix peak
 PEAK_HBM_GBS = 8000.0
@@ -515,8 +516,11 @@ def run(args):
             # algorithmic MACs of what the launch computes (not the halo / padding lanes it also executes);
             # the three-gradient launch: conv2 + up2 + conv1; the five-gradient launch adds up1 and conv0
             cs = args.chanstr
+            from nvfpcc_amd import engine as _E
+            heads_in = _E._HEADS_IN_TRUNK5 and cs == "8,16,8,8"     # the three heads' gradients ride in that launch
             layer_macs = {"wgrad_conv2_up2_conv1": macs + UP2_MACS[cs] + CONV1_MACS[cs],
-                          "wgrad_trunk5": macs + UP2_MACS[cs] + CONV1_MACS[cs] + UP1_MACS[cs] + CONV0_MACS[cs]}
+                          "wgrad_trunk5": macs + UP2_MACS[cs] + CONV1_MACS[cs] + UP1_MACS[cs] + CONV0_MACS[cs]
+                                          + (HEADS_MACS[cs] if heads_in else 0)}
             flops = 2.0 * layer_macs.get(label, macs) * B
             achieved = flops / (us * 1e-6) / 1e12
             traffic, tnote, kname = None, "not measured (--no-pmc or N > 1)", None
