@@ -5,6 +5,10 @@ for several lambda.  Reports bpp from the REAL stream lengths (NVFPCC.py:542-547
 PSNR1 (NVFPCC.py:259-260) and a symmetric D1 PSNR (point-to-point, peak 1023) computed with a KD-tree.
 
     python tools/rd_sweep.py --lambdas 50,200,800 --epochs 301 --out profiles/r01_rd_sweep.md
+    python tools/rd_sweep.py --lambdas 200 --qps 16,8,32 --thhs 0.5,0.6,0.65     # + the README's --qp / --thh knobs
+
+One training run per lambda; per (lambda, qp) one weight quantisation (manipulate_weights.py, README step 3a) and per
+(lambda, qp, thh) one encode + decode (README steps 3b-3c).
 """
 import argparse
 import os
@@ -57,6 +61,8 @@ def main():
     ap.add_argument("--chanstr", default="8,16,8,8")
     ap.add_argument("--ch", type=int, default=3)
     ap.add_argument("--thh", type=float, default=0.6)
+    ap.add_argument("--qps", default="16", help="weight quantisation parameters (manipulate_weights.py's third argument, --qp)")
+    ap.add_argument("--thhs", default="", help="occupancy thresholds (--thh of encode / decode); default: --thh only")
     ap.add_argument("--wemb", type=float, default=5.0)
     ap.add_argument("--out", default="")
     ap.add_argument("--workdir", default="")
@@ -87,27 +93,33 @@ def main():
              str(a.phase_change)] + common, wd, log)
         t_train = time.time() - t0
         last = (a.epochs - 1) // 10 * 10
-        run([os.path.join(ROOT, "manipulate_weights.py"), f"{ck}/{last:04d}.ckpt", f"q4_{lam:g}.ckpt", "16"], wd, log)
-        out = run([cli, "encode", "cloud.ply", "--batchsize", "64", "--load_weights", f"q4_{lam:g}.ckpt", "--load_emb",
-                   f"{ck}/{last:04d}_emb.ckpt", "--thh", str(a.thh), "--pack_fn", f"pack_{lam:g}.pk"] + common, wd, log)
-        psnr1 = float(out.split("PSNR1: ")[-1].split()[0])
-        run([cli, "decode", f"pack_{lam:g}.pk", "--batchsize", "64", "--thh", str(a.thh), "--N", str(n_blk)] + common, wd, log)
-        enc, dec = read_ply_ascii("rc_enc.ply"), read_ply_ascii("rc_dec.ply")
-        same = enc.shape == dec.shape and np.array_equal(enc, dec)
-        pack = pickle.load(open(f"pack_{lam:g}.pk", "rb"))
-        bits_lat = 8 * len(pack["latent_pack"]["latent_byte_stream"])
-        bits_net = 8 * len(pack["net_weight_pack"]["bit_stream"])
-        rows.append((lam, (bits_lat + bits_net) / n_pts, bits_lat / n_pts, bits_net / n_pts, psnr1, d1_psnr(pts, dec),
-                     len(dec), same, t_train))
-        print(rows[-1])
-    lines = ["| lambda | bpp | bpp latents | bpp weights | PSNR1 (dB) | D1 PSNR sym. (dB) | decoded points | rc_enc == rc_dec | train s |",
-             "|---|---|---|---|---|---|---|---|---|"]
+        for qp in [int(v) for v in a.qps.split(",")]:
+            tagq = f"{lam:g}_q{qp}"
+            run([os.path.join(ROOT, "manipulate_weights.py"), f"{ck}/{last:04d}.ckpt", f"q_{tagq}.ckpt", str(qp)], wd, log)
+            for thh in ([float(v) for v in a.thhs.split(",")] if a.thhs else [a.thh]):
+                out = run([cli, "encode", "cloud.ply", "--batchsize", "64", "--load_weights", f"q_{tagq}.ckpt", "--load_emb",
+                           f"{ck}/{last:04d}_emb.ckpt", "--thh", str(thh), "--qp", str(qp), "--pack_fn", f"pack_{tagq}.pk"]
+                          + common, wd, log)
+                psnr1 = float(out.split("PSNR1: ")[-1].split()[0])
+                run([cli, "decode", f"pack_{tagq}.pk", "--batchsize", "64", "--thh", str(thh), "--qp", str(qp), "--N",
+                     str(n_blk)] + common, wd, log)
+                enc, dec = read_ply_ascii("rc_enc.ply"), read_ply_ascii("rc_dec.ply")
+                same = enc.shape == dec.shape and np.array_equal(enc, dec)
+                pack = pickle.load(open(f"pack_{tagq}.pk", "rb"))
+                bits_lat = 8 * len(pack["latent_pack"]["latent_byte_stream"])
+                bits_net = 8 * len(pack["net_weight_pack"]["bit_stream"])
+                rows.append((lam, qp, thh, (bits_lat + bits_net) / n_pts, bits_lat / n_pts, bits_net / n_pts, psnr1,
+                             d1_psnr(pts, dec) if len(dec) else float("nan"), len(dec), same, t_train))
+                print(rows[-1])
+    lines = ["| lambda | qp | thh | bpp | bpp latents | bpp weights | PSNR1 (dB) | D1 PSNR sym. (dB) | decoded points | rc_enc == rc_dec | train s |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
-        lines.append(f"| {r[0]:g} | {r[1]:.4f} | {r[2]:.4f} | {r[3]:.4f} | {r[4]:.2f} | {r[5]:.2f} | {r[6]} | {r[7]} | {r[8]:.0f} |")
+        lines.append(f"| {r[0]:g} | {r[1]} | {r[2]:g} | {r[3]:.4f} | {r[4]:.4f} | {r[5]:.4f} | {r[6]:.2f} | {r[7]:.2f} | {r[8]} | "
+                     f"{r[9]} | {r[10]:.0f} |")
     table = "\n".join(lines)
     head = (f"RD sweep on a synthetic 10-bit surface: {n_pts} points, {n_blk} level-5 cubes; ch={a.ch}, chanstr={a.chanstr}, "
-            f"{a.epochs} epochs (phase change {a.phase_change}), batch 16, lr 1e-3, w1 10, w2 57, wemb {a.wemb:g}, 4-bit weights, "
-            f"thh {a.thh}; 1 x MI355X.\n\n")
+            f"{a.epochs} epochs (phase change {a.phase_change}), batch 16, lr 1e-3, w1 10, w2 57, wemb {a.wemb:g}, weights on "
+            f"the 1/qp grid (qp 16 = the reference's 4-bit setting); 1 x MI355X.\n\n")
     print(head + table)
     if a.out:
         with open(os.path.join(ROOT, a.out) if not os.path.isabs(a.out) else a.out, "w") as f:
