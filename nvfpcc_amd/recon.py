@@ -46,4 +46,6 @@ def read_ply_ascii(path):
                 n = int(line.split()[-1])
             if line.strip() == "end_header":
                 break
+        if n == 0:
+            return np.zeros((0, 3), np.float64)
         return np.loadtxt(f, dtype=np.float64).reshape(n, -1)[:, :3]
