@@ -307,6 +307,20 @@ int nvf_wgrad_trunk5_heads_partial(const float* const* ps, const float* const* q
                                    float* const* bias_slabs, const float* const* head_dls, const float* const* head_xs,
                                    float* const* head_slabs, int head_max_slabs, int batch, int* nslabs,
                                    int* head_nslabs, NvfStepCtx* ctx, void* stream);
+/* ... and the FIRST pass of nvf_multi_channel_sum over sum_xs (bias gradients sum_outs that no other kernel leaves
+ * behind) as further workgroups of the launch; its final pass is queued in ctx (an open nvf_finals_begin) or launched
+ * here.  sum_workspace: nvf_multi_channel_sum_workspace(total channels) bytes, untouched until the flush.  With the
+ * partial sums made here, no final pass of the step reads what the slab reduction writes: nvf_wgrad_reduce_finals_tail.
+ * coef_src / coef_live (both or neither): the launch copies two floats (the optimiser's step coefficients) from
+ * coef_src to coef_live for that call. */
+int nvf_wgrad_trunk5_heads_sums_partial(const float* const* ps, const float* const* qs, float* const* slabs,
+                                        float* const* bias_slabs, const float* const* head_dls,
+                                        const float* const* head_xs, float* const* head_slabs, int head_max_slabs,
+                                        const float* const* sum_xs, float* const* sum_outs, const int* sum_channels,
+                                        const int* sum_spatials, int sum_n, void* sum_workspace,
+                                        size_t sum_workspace_bytes, const float* coef_src, float* coef_live,
+                                        int batch, int* nslabs, int* head_nslabs,
+                                        NvfStepCtx* ctx, void* stream);
 
 /* per-channel sum over batch and space: out[c] (+)= sum x[b,c,:]  (bias gradients);
  * two launches through a caller-owned workspace of nvf_channel_sum_workspace(c) bytes */
@@ -531,6 +545,14 @@ int nvf_step_tail(const NvfStepTail* args, void* stream);
  * the next schedule row.  Together with nvf_wgrad_reduce_multi_and_sums_fused (the weight gradients) this covers what
  * nvf_step_tail does; the caller makes the ranges the exact complement. */
 int nvf_finals_flush_tail(NvfStepCtx* ctx, const NvfStepTail* tail, const int64_t* ranges, int nranges, void* stream);
+/* nvf_wgrad_reduce_multi_and_sums_fused (slab reduction with addends and the fused optimiser; no channel sums) and
+ * nvf_finals_flush_tail in ONE launch -- for steps whose queued final passes read nothing that reduction writes.
+ * Only the final passes' workgroups wait for one another before the schedule hand-over, so the reduction must read
+ * nothing from the step buffer: adam->coef_dev may not point into tail->sched_buf (NVF_EINVAL) -- use the copy that
+ * nvf_wgrad_trunk5_heads_sums_partial(coef_src, coef_live) staged earlier in the step, or host coefficients. */
+int nvf_wgrad_reduce_finals_tail(const float* const* slabs, float* const* dws, const int* nslabs, const int* jtotals,
+                                 int n, const float* const* addends, const NvfAdamFuse* adam, NvfStepCtx* ctx,
+                                 const NvfStepTail* tail, const int64_t* ranges, int nranges, void* stream);
 int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
 
 /* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose

@@ -235,6 +235,93 @@ struct FinalsArgs {
   int32_t f_nterm, has_f, has_s, has_r, has_g, has_m;
 };
 
+struct TailRanges { long lo[16], hi[16]; int n; };
+
+// finals + the tail of a single-GPU training step (nvf_finals_flush_tail).  Workgroup 0 runs the passes the epoch
+// statistics read -- the focal terms (waves 0-2), the weight-rate term (wave 3), then the metric counts -- and adds the
+// statistics itself, so no sum crosses a workgroup; workgroup 1 the stem's IGDN parameter gradients; workgroups
+// 2 .. 2 + sum_blocks - 1 the bias sums; the last one the index ranges whose gradients earlier launches wrote.  Every
+// gradient element gets its Adam update from the thread that produced (or owns) it.  The last workgroup to arrive --
+// all of them have read the step buffer's coefficients by then -- copies the next schedule row over the step buffer.
+// bid / nblocks: this workgroup's index among, and the number of, workgroups that run this body or -- in a launch shared
+// with other work -- take part in the arrival count (every workgroup of the launch must then call finals_tail_arrive).
+// Workgroups may be larger than 256 threads: threads >= 256 only take part in the barriers.
+__device__ __forceinline__ void finals_tail_arrive(const NvfStepTail& t, unsigned long long cur, int nblocks) {
+  if (!t.sched_rows) return;
+  const int tid = threadIdx.x;
+  __shared__ int last;
+  int64_t next_word = 0;
+  if (tid < t.sched_words) next_word = t.sched_rows[cur * (unsigned long long)t.sched_words + tid];
+  // (no device-scope fence: it writes the L2 back, +10 us over ~800 workgroups.  The callers' barrier before this call
+  // waits for the workgroup's loads -- the step buffer's words among them -- so they precede the arrival.)
+  if (tid == 0) last = atomicAdd(t.done, 1u) == (unsigned)nblocks - 1;
+  __syncthreads();
+  if (!last) return;
+  if (tid < t.sched_words) t.sched_buf[tid] = next_word;
+  for (int w = tid + blockDim.x; w < t.sched_words; w += blockDim.x)
+    t.sched_buf[w] = t.sched_rows[cur * (unsigned long long)t.sched_words + w];
+  if (tid == 0) { t.sched_cursor[0] = cur + 1; t.done[0] = 0u; }
+}
+
+__device__ __forceinline__ void finals_tail_body(const FinalsArgs& a, int sum_blocks, const NvfStepTail& t,
+                                                 const TailRanges& rg, int bid, int nblocks) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const NvfAdamFuse ad = adam_fuse_of(t);
+  // the schedule cursor is fetched now (it only moves at the very end of this launch) and the row it points at right
+  // before the arrival counter is bumped: whichever workgroup turns out to be the last already holds the row when it
+  // learns so -- one round trip at the end instead of three dependent ones
+  const unsigned long long cur = t.sched_rows ? t.sched_cursor[0] : 0ull;   // in flight under the work below
+  int bad = 0;
+  if (bid == 0) {
+    if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
+    if (a.has_r && wave == 3)
+      bad += weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost,
+                                          lane, &ad);
+    if (a.has_m) metrics_final_body(a.m_part, a.m_out, a.m_nwg, a.m_nterm, a.m_accumulate, tid);
+  } else if (bid == 1) {
+    if (a.has_g && tid < 256) bad += stem_gdn_final_body(a.g, tid, 256, &ad);
+  } else if (bid < 2 + sum_blocks) {
+    if (a.has_s && tid < 64) bad += multi_channel_sum_final_body(a.s, a.s_part, (bid - 2) * 64 + tid, &ad);
+  } else {
+    for (int r = 0; r < rg.n; ++r)
+      for (long i = rg.lo[r] + tid; i < rg.hi[r]; i += blockDim.x) bad += adam_fused_elem(ad, t.g + i, t.g[i]);
+  }
+  if (t.acc) {
+    const unsigned long long any = __ballot(bad != 0);
+    // a lane's count is 0 .. a few: add the lanes' counts (integer-valued floats: order-free)
+    float c = (float)bad;
+    c = nvf_wave_sum(c);
+    if (any && lane == 0) atomicAdd(t.acc + 6, c);
+  }
+  __syncthreads();                                            // workgroup 0: the sums it wrote are visible to its thread 0
+  if (bid == 0 && tid == 0 && t.acc) {
+    int bad_terms = 0;
+    for (int k = 0; k < 3; ++k) {
+      const float x = t.loss_terms[k];
+      t.acc[k] += x;
+      bad_terms += !(fabsf(x) <= 3.402823466e38f);
+    }
+    const float bl = t.lbits[0] * (t.inv_npts_dev ? t.inv_npts_dev[0] : t.inv_npts_host);
+    float nb = 0.f;
+    for (int l = 0; l < t.nnb; ++l) nb += t.nbits[l];
+    nb *= t.nbits_scale;
+    t.acc[3] += bl;
+    t.acc[4] += nb;
+    bad_terms += !(fabsf(bl) <= 3.402823466e38f) + !(fabsf(nb) <= 3.402823466e38f);
+    t.acc[5] += (float)bad_terms;
+    t.acc[7] += 1.f;
+    if (t.counts) {
+      for (int k = 0; k < 3; ++k) {
+        t.acc[8 + 2 * k] += t.counts[6 * k] / t.counts[6 * k + 1];
+        t.acc[9 + 2 * k] += t.counts[6 * k + 2] / t.counts[6 * k + 3];
+      }
+      t.acc[14] += t.counts[4];
+      t.acc[15] += t.counts[5];
+    }
+  }
+  finals_tail_arrive(t, cur, nblocks);
+}
+
 // Queue (finals.hip), held in the caller's NvfStepCtx (step_ctx.h); ctx == nullptr means "nothing is deferred".  A push
 // returns false when nothing is being deferred or a job of that kind is already waiting: the caller then launches its
 // own final pass as usual.

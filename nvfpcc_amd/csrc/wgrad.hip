@@ -22,6 +22,10 @@
 #include "heads_wgrad_mfma.h"
 
 static const int kMaxSlabs = 512;
+static const int kSumChunks = 128;
+struct MultiSumDesc;
+__global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part);
+extern "C" size_t nvf_multi_channel_sum_workspace(int total_channels);
 __global__ void wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ dw, int nslab, int jtotal,
                              int accumulate);
 
@@ -698,6 +702,47 @@ __global__ __launch_bounds__(256) void wgrad_s2k5_mfma(const float* __restrict__
 // the latent tail queued in the caller's NvfStepCtx by nvf_latent_tail_queue: consumed by the next
 // nvf_wgrad_mfma3_partial / nvf_wgrad_trunk5_partial or nvf_wgrad_reduce_multi_and_sums call with that context
 
+#ifndef NVF_SUM_T
+#define NVF_SUM_T 512      // threads that load a row (256: 17.6 us for the step's reduction launch, 512 / 1024: 15.9)
+#endif
+// `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
+// workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
+template <int T>
+__device__ __forceinline__ void multi_channel_sum_partial_body(const MultiSumDesc& d, float* __restrict__ part, int gch,
+                                                               int g, float* red) {
+  int t = 0;
+  while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
+  const int ch = gch - d.chan_base[t], c = d.c[t], spatial = d.spatial[t];
+  const int per = (d.batch + d.nchunk - 1) / d.nchunk;
+  const int n_lo = g * per, n_hi = min(n_lo + per, d.batch);
+  const float* x = d.x[t];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int n = n_lo; n < n_hi && (int)threadIdx.x < T; ++n) {
+    const float* row = x + ((size_t)n * c + ch) * spatial;     // one contiguous row per (n, channel)
+    // rows of 35^3 or 19^3 floats start at any 4-byte phase: a scalar head up to the next 16-byte boundary, then
+    // aligned float4s (four per thread in flight), then a scalar tail
+    const int head = (int)((4 - (((uintptr_t)row >> 2) & 3)) & 3);
+    const int body = (spatial - head) & ~3;
+    if ((int)threadIdx.x < head) s0 += row[threadIdx.x];
+    const float4* r4 = (const float4*)(row + head);
+    const int n4 = body >> 2;
+    int i = threadIdx.x;
+    for (; i + 3 * (int)T < n4; i += 4 * T) {
+      const float4 a = r4[i], b4 = r4[i + T], c4 = r4[i + 2 * T], d4 = r4[i + 3 * T];
+      s0 += (a.x + b4.x) + (c4.x + d4.x); s1 += (a.y + b4.y) + (c4.y + d4.y);
+      s2 += (a.z + b4.z) + (c4.z + d4.z); s3 += (a.w + b4.w) + (c4.w + d4.w);
+    }
+    for (; i < n4; i += T) {
+      const float4 v = r4[i];
+      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    const int tail = head + body + threadIdx.x;
+    if (tail < spatial) s1 += row[tail];
+  }
+  const float s = nvf_block_sum((s0 + s1) + (s2 + s3), red);
+  if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
+}
+
 struct WgMfma3 {                 // jobs 0-2: conv2, up2, conv1; job 3 (n[3] may be 0): up1 on the matrix cores
   const float* p[4];
   const float* q[4];
@@ -712,7 +757,9 @@ using WgUp1 = TWCfg<2, 2, 8, 2>;
 constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 template <class C0, class T1, class C2, class U0, class U1, bool TAIL>
-__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u, LatentTail tail, HeadsW3 hw) {
+__global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u, LatentTail tail, HeadsW3 hw,
+                                                          MultiSumDesc sums, float* __restrict__ sum_part,
+                                                          const float* __restrict__ coef_src, float* coef_live) {
   static_assert(U0::NT == 256 && U1::NT == 256, "one workgroup size");
   __shared__ __attribute__((aligned(16))) float lds[wg_max3(wg_max3(C0::LDSF, T1::LDSF, C2::LDSF), kWgEpiFloats,
                                                             wg_max3(wg_max3(kTailLds, U0::LDSF, U1::LDSF),
@@ -752,7 +799,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
   bid -= u.nx[1] * u.ny[1];
   // the three classifier heads' weight gradients (matrix cores, 22 KB of LDS, short): they depend on nothing this
   // launch produces and run in the slots the other jobs have left by then
-  heads3_wgrad_mfma_dispatch<HeadW0, HeadW1, HeadW2>(hw, bid, lds);
+  const int nheads = hw.n[0] + hw.n[1] + hw.n[2];
+  if (bid < nheads) { heads3_wgrad_mfma_dispatch<HeadW0, HeadW1, HeadW2>(hw, bid, lds); return; }
+  bid -= nheads;
+  // partial channel sums of the (small) tensors whose bias gradients no other kernel leaves behind: with these here, the
+  // final passes of the step depend on nothing the slab reduction produces and share its launch
+  // (and the optimiser's two step coefficients leave the step buffer for a place the schedule hand-over does not touch:
+  // the slab reduction that shares the hand-over's launch reads them there -- nvf_wgrad_reduce_finals_tail)
+  if (bid == 0 && threadIdx.x < 2 && coef_live) coef_live[threadIdx.x] = coef_src[threadIdx.x];
+  multi_channel_sum_partial_body<256>(sums, sum_part, bid % sums.total_channels, bid / sums.total_channels, lds);
 }
 
 // geometry of the up1 / conv0 jobs (nvf_wgrad_up1_conv0_partial, nvf_wgrad_trunk5_partial)
@@ -784,10 +839,17 @@ struct HeadsJob {                       // optional: the heads' gradients in the
   int max_slabs;
   int* nslabs;
 };
+struct SumsJob {                        // optional: partial channel sums (nvf_multi_channel_sum's first pass) in the launch
+  MultiSumDesc d;
+  float* part;
+  const float* coef_src;                // optional: two floats copied to coef_live by the launch
+  float* coef_live;
+};
 
 static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, float* const* slabs, int batch,
                                int* nslabs, int njobs, NvfStepCtx* ctx, void* stream,
-                               float* const* bias_slabs = nullptr, const HeadsJob* heads = nullptr) {
+                               float* const* bias_slabs = nullptr, const HeadsJob* heads = nullptr,
+                               const SumsJob* sums = nullptr) {
   if (!ps || !qs || !slabs || !nslabs || batch <= 0) return NVF_EINVAL;
   using C0 = MCfg<32, 4, 4>; using T1 = TWCfg<2, 2>; using C2 = MCfg<16, 2, 8>;
   using U0 = WCfg<16, 5, 2, 2, 8, 4, 2, 0>; using U1 = WCfg<8, 5, 2, 2, 4, 4, 4, 0>;
@@ -843,11 +905,21 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     if (rc != NVF_OK) return rc;
     grid += hw.n[0] + hw.n[1] + hw.n[2];
   }
+  MultiSumDesc sd{};
+  float* spart = nullptr;
+  const float* csrc = nullptr;
+  float* clive = nullptr;
+  if (sums) {
+    if (!heads) return NVF_EINVAL;        // the block ranges assume the heads' job in front of the sums
+    sd = sums->d; spart = sums->part;
+    grid += sd.total_channels * sd.nchunk;
+    csrc = sums->coef_src; clive = sums->coef_live;
+  }
   if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
     ctx->tail_pending = 0;
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail, hw);
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail, hw, sd, spart, csrc, clive);
   } else {
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{}, hw);
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{}, hw, sd, spart, csrc, clive);
   }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -889,6 +961,50 @@ extern "C" int nvf_wgrad_trunk5_heads_partial(const float* const* ps, const floa
   if (!head_dls || !head_xs || !head_slabs || !head_nslabs || head_max_slabs <= 0) return NVF_EINVAL;
   const HeadsJob h{head_dls, head_xs, head_slabs, head_max_slabs, head_nslabs};
   return launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream, bias_slabs, &h);
+}
+
+static int fill_sum_desc(const float* const* xs, float* const* outs, const int* channels, const int* spatials,
+                         int ntensors, int batch, MultiSumDesc& d) {
+  if (!xs || !outs || !channels || !spatials || ntensors <= 0 || ntensors > 12 || batch <= 0) return NVF_EINVAL;
+  int cb = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    if (!xs[i] || !outs[i] || channels[i] <= 0 || spatials[i] <= 0) return NVF_EINVAL;
+    d.x[i] = xs[i]; d.out[i] = outs[i]; d.c[i] = channels[i]; d.spatial[i] = spatials[i]; d.chan_base[i] = cb;
+    cb += channels[i];
+  }
+  d.ntensors = ntensors; d.batch = batch; d.total_channels = cb;
+  d.nchunk = batch < kSumChunks ? batch : kSumChunks;
+  return NVF_OK;
+}
+
+// ... and the first pass of nvf_multi_channel_sum over sum_xs (the bias gradients sum_outs no other kernel leaves
+// behind) as further workgroups of the launch; its final pass is queued in ctx (nvf_finals_begin must be open) or
+// launched here.  sum_workspace: nvf_multi_channel_sum_workspace(total channels) bytes, untouched until the flush.
+// coef_src / coef_live (both or neither): two floats copied by the launch (see nvf_wgrad_reduce_finals_tail).
+extern "C" int nvf_wgrad_trunk5_heads_sums_partial(const float* const* ps, const float* const* qs, float* const* slabs,
+                                                   float* const* bias_slabs, const float* const* head_dls,
+                                                   const float* const* head_xs, float* const* head_slabs,
+                                                   int head_max_slabs, const float* const* sum_xs,
+                                                   float* const* sum_outs, const int* sum_channels,
+                                                   const int* sum_spatials, int sum_n, void* sum_workspace,
+                                                   size_t sum_workspace_bytes, const float* coef_src,
+                                                   float* coef_live, int batch, int* nslabs, int* head_nslabs,
+                                                   NvfStepCtx* ctx, void* stream) {
+  if (!head_dls || !head_xs || !head_slabs || !head_nslabs || head_max_slabs <= 0 || !sum_workspace) return NVF_EINVAL;
+  if ((coef_src == nullptr) != (coef_live == nullptr)) return NVF_EINVAL;
+  const HeadsJob h{head_dls, head_xs, head_slabs, head_max_slabs, head_nslabs};
+  SumsJob sj{};
+  const int rc = fill_sum_desc(sum_xs, sum_outs, sum_channels, sum_spatials, sum_n, batch, sj.d);
+  if (rc != NVF_OK) return rc;
+  if (sum_workspace_bytes < nvf_multi_channel_sum_workspace(sj.d.total_channels)) return NVF_EWORKSPACE;
+  sj.part = (float*)sum_workspace;
+  sj.coef_src = coef_src; sj.coef_live = coef_live;
+  const int rc2 = launch_trunk_wgrads(ps, qs, slabs, batch, nslabs, 5, ctx, stream, bias_slabs, &h, &sj);
+  if (rc2 != NVF_OK) return rc2;
+  if (!nvf_finals_push_sums(ctx, sj.d, sj.part))
+    multi_channel_sum_final<<<(sj.d.total_channels + 63) / 64, 64, 0, nvf_stream(stream)>>>(sj.d, sj.part);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 template <class C>
@@ -1171,7 +1287,6 @@ extern "C" int nvf_wgrad_reduce_multi(const float* const* slabs, float* const* d
 // per-channel sums (bias gradients): out[c] (+)= sum_{n,s} x[n,c,s]
 // stage 1: grid (c, G) partial sums over contiguous chunks; stage 2: fixed-order add.
 // ---------------------------------------------------------------------------
-static const int kSumChunks = 128;
 
 __global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, float* __restrict__ part,
                                                            int batch, int c, int spatial, int chunk) {
@@ -1220,47 +1335,6 @@ extern "C" int nvf_channel_sum(const float* x, float* out, void* workspace, size
 // all bias gradients of a backward pass in two launches: out_i[c] = sum_{n,s} x_i[n,c,s] for up to 12 tensors
 // ---------------------------------------------------------------------------
 
-#ifndef NVF_SUM_T
-#define NVF_SUM_T 512      // threads that load a row (256: 17.6 us for the step's reduction launch, 512 / 1024: 15.9)
-#endif
-// `T` threads do the work (the arithmetic does not depend on the launch's workgroup size: in the one-launch tail the
-// workgroups have 1024 threads, the extra ones only take part in the block sum with zeros)
-template <int T>
-__device__ __forceinline__ void multi_channel_sum_partial_body(const MultiSumDesc& d, float* __restrict__ part, int gch,
-                                                               int g, float* red) {
-  int t = 0;
-  while (t + 1 < d.ntensors && gch >= d.chan_base[t + 1]) ++t;
-  const int ch = gch - d.chan_base[t], c = d.c[t], spatial = d.spatial[t];
-  const int per = (d.batch + d.nchunk - 1) / d.nchunk;
-  const int n_lo = g * per, n_hi = min(n_lo + per, d.batch);
-  const float* x = d.x[t];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int n = n_lo; n < n_hi && (int)threadIdx.x < T; ++n) {
-    const float* row = x + ((size_t)n * c + ch) * spatial;     // one contiguous row per (n, channel)
-    // rows of 35^3 or 19^3 floats start at any 4-byte phase: a scalar head up to the next 16-byte boundary, then
-    // aligned float4s (four per thread in flight), then a scalar tail
-    const int head = (int)((4 - (((uintptr_t)row >> 2) & 3)) & 3);
-    const int body = (spatial - head) & ~3;
-    if ((int)threadIdx.x < head) s0 += row[threadIdx.x];
-    const float4* r4 = (const float4*)(row + head);
-    const int n4 = body >> 2;
-    int i = threadIdx.x;
-    for (; i + 3 * (int)T < n4; i += 4 * T) {
-      const float4 a = r4[i], b4 = r4[i + T], c4 = r4[i + 2 * T], d4 = r4[i + 3 * T];
-      s0 += (a.x + b4.x) + (c4.x + d4.x); s1 += (a.y + b4.y) + (c4.y + d4.y);
-      s2 += (a.z + b4.z) + (c4.z + d4.z); s3 += (a.w + b4.w) + (c4.w + d4.w);
-    }
-    for (; i < n4; i += T) {
-      const float4 v = r4[i];
-      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-    }
-    const int tail = head + body + threadIdx.x;
-    if (tail < spatial) s1 += row[tail];
-  }
-  const float s = nvf_block_sum((s0 + s1) + (s2 + s3), red);
-  if (threadIdx.x == 0) part[(size_t)g * d.total_channels + gch] = s;
-}
-
 __global__ __launch_bounds__(NVF_SUM_T) void multi_channel_sum_partial(MultiSumDesc d, float* __restrict__ part) {
   __shared__ float red[16];
   multi_channel_sum_partial_body<NVF_SUM_T>(d, part, blockIdx.x, blockIdx.y, red);
@@ -1285,6 +1359,71 @@ __global__ __launch_bounds__(1024, 8) void wgrad_reduce_sums_tail(WgReduceMulti 
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, (float(*)[64])sm); return; }
   const int q = bid - r_blocks;
   multi_channel_sum_partial_body<NVF_SUM_T>(m, part, q % m.total_channels, q / m.total_channels, sm);
+}
+
+// The slab reduction (+ fused optimiser) and the step's final passes + tail (finals_tail_body) in ONE launch: possible
+// when no final pass reads anything this launch's reduction writes (the partial bias sums were made by an earlier
+// launch: nvf_wgrad_trunk5_heads_sums_partial).  The reduction's workgroups read NOTHING from the step buffer (their
+// optimiser coefficients are the copy that earlier launch staged), so the schedule hand-over waits only for the final
+// passes' workgroups.  (With the ~800 reduction workgroups in the arrival count -- on one counter or through ~sqrt(n)
+// group counters -- the launch took 18 us instead of 13: the device-scope atomics' round trips end up behind the last
+// of them.)
+__global__ __launch_bounds__(1024) void wgrad_reduce_finals_tail(WgReduceMulti r, int f_blocks, FinalsArgs a,
+                                                                 int sum_blocks, NvfStepTail t, TailRanges rg) {
+  __shared__ float sm[16][64];
+  // the final passes are dependent-load chains (~10 us alone): they take the FIRST workgroups so that they start with
+  // the launch and run beside the reduction, not after its first wave of workgroups
+  const int bid = blockIdx.x;
+  if (bid < f_blocks) finals_tail_body(a, sum_blocks, t, rg, bid, f_blocks);
+  else wgrad_reduce_multi_body(r, bid - f_blocks, sm);
+}
+
+extern "C" int nvf_wgrad_reduce_finals_tail(const float* const* slabs, float* const* dws, const int* nslabs,
+                                            const int* jtotals, int n, const float* const* addends,
+                                            const NvfAdamFuse* adam, NvfStepCtx* ctx, const NvfStepTail* tail,
+                                            const int64_t* ranges, int nranges, void* stream) {
+  if (!slabs || !dws || !nslabs || !jtotals || n <= 0 || n > 16 || !adam || !tail || !nvf_ctx_ok(ctx)) return NVF_EINVAL;
+  if (nranges < 0 || nranges > 16 || (nranges > 0 && !ranges)) return NVF_EINVAL;
+  const NvfStepTail t = *tail;
+  if (!t.p || !t.g || !t.m || !t.v || t.n <= 0) return NVF_EINVAL;
+  if (t.acc && (!t.loss_terms || !t.lbits || !t.nbits || t.nnb <= 0 || t.nnb > 16)) return NVF_EINVAL;
+  if (t.sched_rows && (!t.sched_buf || !t.sched_cursor || t.sched_words <= 0 || !t.done)) return NVF_EINVAL;
+  if (!adam->g_base || !adam->p_base || !adam->m_base || !adam->v_base || adam->n <= 0) return NVF_EINVAL;
+  if (t.sched_rows && adam->coef_dev) {     // the reduction must not read what the hand-over of this launch overwrites
+    const char* c = (const char*)adam->coef_dev;
+    const char* b = (const char*)t.sched_buf;
+    if (c + 2 * sizeof(float) > b && c < b + (size_t)t.sched_words * sizeof(int64_t)) return NVF_EINVAL;
+  }
+  WgReduceMulti r{};
+  int base = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (nslabs[i] == 0) continue;
+    if (!slabs[i] || !dws[i] || nslabs[i] < 0 || jtotals[i] <= 0) return NVF_EINVAL;
+    r.slabs[m] = slabs[i]; r.dw[m] = dws[i]; r.nslab[m] = nslabs[i]; r.jtotal[m] = jtotals[i];
+    r.add[m] = addends ? addends[i] : nullptr;
+    r.blk_base[m] = base;
+    base += (jtotals[i] + 63) / 64;
+    ++m;
+  }
+  r.blk_base[m] = base;
+  r.n = m;
+  r.fuse = 1;
+  r.adam = *adam;
+  TailRanges rg{};
+  for (int q = 0; q < nranges; ++q) {
+    if (ranges[2 * q] < 0 || ranges[2 * q + 1] > t.n || ranges[2 * q] > ranges[2 * q + 1]) return NVF_EINVAL;
+    rg.lo[q] = (long)ranges[2 * q]; rg.hi[q] = (long)ranges[2 * q + 1];
+  }
+  rg.n = nranges;
+  const FinalsArgs a = ctx->args;
+  ctx->args = FinalsArgs{};
+  ctx->deferring = 0;
+  if (a.has_f && a.f_nterm > 3) return NVF_EINVAL;
+  const int sum_blocks = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
+  const int f_blocks = 2 + sum_blocks + 1;
+  wgrad_reduce_finals_tail<<<f_blocks + base, 1024, 0, nvf_stream(stream)>>>(r, f_blocks, a, sum_blocks, t, rg);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 // Queue the latent tail of a training step (NVFPCC.py:186-196 backward of the latent generator): the gradient of the

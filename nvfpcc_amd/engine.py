@@ -32,6 +32,7 @@ _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wi
 _VAR = {k: int(os.environ.get("NVF_VAR_" + k, "0")) for k in ("UP1F", "UP2F", "UP1B", "UP2B", "C1F", "C1B")}   # tile variants
 _CONV2_FWD_VAR = int(os.environ.get("NVF_CONV2_FWD_VAR", "0"))   # tile-shape variants of conv_k4_mfma (tuning)
 _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
+_SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
 _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
 
 
@@ -114,6 +115,7 @@ class TrainEngine:
         self.ctx = ops.StepCtx()  # deferred final passes + queued latent tail of the step in flight (caller-owned)
         self.epoch_acc = None     # float[16] epoch sums written by nvf_step_tail (enable_epoch_stats)
         self._tail_done = torch.zeros(2, dtype=torch.int32, device=self.dev)   # nvf_step_tail's arrival counter
+        self._coef_live = torch.zeros(2, device=self.dev)   # the step's Adam coefficients, staged outside the step buffer
         self._rate = None         # (NvfRateJob, {gk data_ptr: its weight-rate gradient}, rate_grad_scale) of the step head
         self._rate_ready = False  # the step head of the step in flight carried the weight-rate partial pass
         self.tail_done = False    # the last backward pass applied the optimiser itself (fused tail)
@@ -592,7 +594,12 @@ class TrainEngine:
             # gradients (small VALU kernels) fill the slots that the short matrix-core workgroups leave
             self._wg.add_trunk5([g5, a["y3"], g3, a["y1"], a["h0"]], [a["y4"], g4, a["y2"], g2, g1],
                                 [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk],
-                                bias_outs=(Ls["conv2"].gb, Ls["conv1"].gb), heads=heads_job if self.heads3 else None)
+                                bias_outs=(Ls["conv2"].gb, Ls["conv1"].gb), heads=heads_job if self.heads3 else None,
+                                sums=(([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
+                                      if (self.heads3 and heads_job is not None and defer and fuse is not None and self._rate_ready
+                                          and want_w and _SUMS_IN_TRUNK5) else None),
+                                coef=((fuse["coef_dev"], self._coef_live)
+                                      if (fuse is not None and fuse.get("coef_dev") is not None) else None))
         # weight rate: bits of the 7 quantised kernels and, for the decoder update, their gradients (added to the
         # weight gradients, so it follows the wgrads on the side stream); every bias gradient in one reduction
         lm = net.reconstructor.likelihood_model
@@ -614,16 +621,29 @@ class TrainEngine:
                         rate_head, addends = False, None
                 if fuse is not None and rate_head:
                     fused = self._fused_tail(fuse, loss, a["lbits"], nbits, gs, gm)
-                self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs],
-                                          addends=addends, adam=None if fused is None else fused[1])
-                if rate_head:
+                sums_done = wg3 and getattr(self._wg, "sums_done", False)    # the partial bias sums rode in add_trunk5
+                one_launch = fused is not None and sums_done and rate_head
+                if one_launch:      # nothing the final passes read is written by the slab reduction: ONE launch for both
                     ops.weight_rate_final(job, nbits, gs, gm, ctx=ctx)
+                    adam = fused[1]
+                    if fuse.get("coef_dev") is not None:     # the copy add_trunk5 staged: not the step buffer's words
+                        adam.coef_dev = self._coef_live.data_ptr()
+                    self._wg.finish_and_flush_tail(addends, adam, fused[0], fused[2])
                 else:
-                    ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
-                                          g_host=g_net * self.rate_grad_scale, ctx=ctx)
+                    if sums_done:
+                        self._wg.finish_with_sums([], [], addends=addends, adam=None if fused is None else fused[1])
+                    else:
+                        self._wg.finish_with_sums([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs],
+                                                  addends=addends, adam=None if fused is None else fused[1])
+                    if rate_head:
+                        ops.weight_rate_final(job, nbits, gs, gm, ctx=ctx)
+                    else:
+                        ops.weight_rate_batch(kernels, [Ls[n].gk for n in TRUNK], lm.sigma, lm.mu, nbits, gs, gm,
+                                              g_host=g_net * self.rate_grad_scale, ctx=ctx)
             else:
+                one_launch = False
                 ops.weight_rate_batch(kernels, None, lm.sigma, lm.mu, nbits)
-            if defer:
+            if defer and not one_launch:
                 if fused is not None:
                     self.ctx.flush_tail(fused[0], fused[2])
                 else:

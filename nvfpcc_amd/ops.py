@@ -591,16 +591,19 @@ class WgradBatch:
         """up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch, two reduction jobs."""
         self._grouped(lib().nvf_wgrad_up1_conv0_partial, "nvf_wgrad_up1_conv0_partial", ps, qs, outs, (16000, 16000), 512)
 
-    def add_trunk5(self, ps, qs, outs, bias_outs=None, heads=None):
+    def add_trunk5(self, ps, qs, outs, bias_outs=None, heads=None, sums=None, coef=None):
         """conv2 / up2 / conv1 / up1 / conv0 weight gradients of the narrow trunk: one partial-sum launch (which also
         carries a queued latent tail), five reduction jobs.  ps/qs/outs: add_mfma3's three, then add_up1_conv0's two.
         ``bias_outs`` = (conv2's bias gradient, conv1's): the launch also leaves the channel sums of their dY (two more
         reduction jobs of 8 floats) -- nobody has to read those two tensors again for the bias sums.
         ``heads`` = (dls, xs, outs) of add_heads3 (narrow decoder, needs bias_outs): the heads' weight gradients as
-        further workgroups of the same launch."""
+        further workgroups of the same launch.  ``sums`` = (tensors, outs) of multi_channel_sum (needs heads): its first
+        pass rides in the launch too, its final pass is queued in the context (self.sums_done is set); ``coef`` =
+        (src, live): two floats the launch copies for finish_and_flush_tail's reduction."""
         import ctypes
         _f32(*ps, *qs, *outs)
         B = ps[0].shape[0]
+        self.sums_done = False
         jt = (4096, 8000, 4096, 16000, 16000) + ((8, 8) if bias_outs is not None else ())
         sizes = [(512 * j * 4 + 255) // 256 * 256 for j in jt]
         if heads is not None:
@@ -618,7 +621,22 @@ class WgradBatch:
             bases.append(self.ws.data_ptr() + self.offset)
             self.offset += sz
         nsl = (ctypes.c_int * 5)()
-        if heads is not None:
+        if heads is not None and sums is not None:
+            st, so = sums
+            _f32(*st, *so)
+            hn = (ctypes.c_int * 3)()
+            total = sum(t.shape[1] for t in st)
+            ws = workspace(lib().nvf_multi_channel_sum_workspace(total), st[0].device, "mchsum", self.ctx)
+            check(lib().nvf_wgrad_trunk5_heads_sums_partial(
+                _parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases[:5]), (ctypes.c_void_p * 3)(bases[5], None, bases[6]),
+                _parr(hd), _parr(hx), (ctypes.c_void_p * 3)(*bases[7:10]), _HEADS_SLABS, _parr(st), _parr(so),
+                _iarr([t.shape[1] for t in st]), _iarr([t[0, 0].numel() for t in st]), len(st), _ptr(ws), ws.numel(),
+                _ptr(coef[0]) if coef else None, _ptr(coef[1]) if coef else None, B,
+                nsl, hn, _ctx(self.ctx), _stream()), "nvf_wgrad_trunk5_heads_sums_partial")
+            for h in range(3):
+                self.jobs.append((bases[7 + h], ho[h].data_ptr(), hn[h], hcs[h] * 27))
+            self.sums_done = True
+        elif heads is not None:
             hn = (ctypes.c_int * 3)()
             check(lib().nvf_wgrad_trunk5_heads_partial(
                 _parr(ps), _parr(qs), (ctypes.c_void_p * 5)(*bases[:5]), (ctypes.c_void_p * 3)(bases[5], None, bases[6]),
@@ -695,6 +713,27 @@ class WgradBatch:
             _parr(tensors), _parr(outs), _iarr([t.shape[1] for t in tensors]), _iarr([t[0, 0].numel() for t in tensors]),
             nt, tensors[0].shape[0], _ptr(ws), ws.numel(), _ctx(self.ctx), _stream()),
             "nvf_wgrad_reduce_multi_and_sums_fused")
+
+    def finish_and_flush_tail(self, addends, adam, tail, ranges):
+        """The slab reduction (addends, fused optimiser) and the context's queued final passes + step tail in ONE
+        launch (nvf_wgrad_reduce_finals_tail): for steps whose partial bias sums were made earlier (add_trunk5 sums=)."""
+        import ctypes
+        jobs = self.jobs
+        n = len(jobs)
+        if not (0 < n <= 16) or self.ctx is None:
+            raise RuntimeError("finish_and_flush_tail: 1..16 reduction jobs and a step context are required")
+        self.jobs, self.offset = [], 0
+        adds = None
+        if addends:
+            adds = (ctypes.c_void_p * n)(*[(addends[j[1]].data_ptr() if (j[1] in addends and j[2] > 0) else None)
+                                           for j in jobs])
+        flat = [int(v) for r in ranges for v in r]
+        arr = (ctypes.c_int64 * max(len(flat), 1))(*flat)
+        check(lib().nvf_wgrad_reduce_finals_tail(
+            (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
+            (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n, adds,
+            ctypes.byref(adam), _ctx(self.ctx), ctypes.byref(tail), arr, len(ranges), _stream()),
+            "nvf_wgrad_reduce_finals_tail")
 
     def finish(self):
         import ctypes

@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     c=int(r["Calls"]); a=float(r["AverageNs"])/1000
     if c in (45,46,47,127) and "rocclr" not in r["Name"]:
         tot+=a
-        if any(k in r["Name"] for k in ("heads3_wgrad","wgrad_reduce_and","finals_tail","wgrad_mfma3")): show.append(f"{r['Name'].split('(')[0][-28:]}={a:.1f}")
+        if any(k in r["Name"] for k in ("heads3_wgrad","wgrad_reduce","finals_tail","wgrad_mfma3")): show.append(f"{r['Name'].split('(')[0][-28:]}={a:.1f}")
 print(f"{name:24s} sum {tot:7.1f}  " + "  ".join(show))
 P
 }
@@ -39,10 +39,10 @@ for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-run a NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=64
-run b NVF_WG_CAPS=256,128,32 NVF_UP1_CAP=64
-run c NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=48
-run d NVF_WG_CAPS=256,96,64 NVF_UP1_CAP=64
-run e NVF_WG_CAPS=256,64,64 NVF_UP1_CAP=64
-run f NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=64 NVF_HEADS_SLABS=256
-run a2 NVF_WG_CAPS=256,128,64 NVF_UP1_CAP=64
+run a X=1
+showk a reduce_finals
+run c NVF_SUMS_IN_TRUNK5=0
+showk c reduce
+showk c finals_tail
+run a2 X=1
+showk a2 reduce_finals
