@@ -209,6 +209,15 @@ int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, co
                              float* const* dls, const float* const* wbs, float* const* dxs,
                              const float* const* masks, const int* cs, const int* ss, int batch, void* workspace,
                              size_t workspace_bytes, NvfStepCtx* ctx, void* stream);
+/* ... and, with bias_outs (three pointers; NULL = the call above), the heads' bias gradients (autograd of the bias add,
+ * utils/network.py:741): bias_outs[h][0] = sum of dls[h], from one partial per workgroup of the values it writes anyway;
+ * the final pass is deferred like the loss terms' (or launched here). */
+int nvf_heads3_loss_bwd_data_bias(const float* const* ps, const float* const* gts, const float* const* dists,
+                                  const float* alphas, const float* betas, const int* slots, float* loss,
+                                  float* const* dls, const float* const* wbs, float* const* dxs,
+                                  const float* const* masks, const int* cs, const int* ss, int batch,
+                                  float* const* bias_outs, void* workspace, size_t workspace_bytes, NvfStepCtx* ctx,
+                                  void* stream);
 /* partial sums only: slabs[h] receives nslabs[h] (<= max_slabs) slabs of cs[h] * 27 floats, to be added by
  * nvf_wgrad_reduce_multi */
 int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs, float* const* slabs, const int* cs,

@@ -233,7 +233,26 @@ struct FinalsArgs {
   float* m_out;          // t * kLossMaxWG, summed in row order into m_out[6 t .. 6 t + 5]
   int32_t m_nwg[3], m_nterm, m_accumulate;
   int32_t f_nterm, has_f, has_s, has_r, has_g, has_m;
+  const float* hb_part;  // the heads' bias gradients (nvf_heads3_loss_bwd_data_bias): head h = the sum of its logit
+  float* hb_out[3];      // gradient, left as hb_n[h] per-workgroup partials at hb_part + h * kLossMaxWG
+  int32_t hb_n[3], has_hb;
 };
+
+// one wave per head: lanes take the partials 64 apart (ascending), then a fixed-order wave sum (as the focal terms)
+__device__ __forceinline__ int head_bias_final_body(const FinalsArgs& a, int h, int lane, const NvfAdamFuse* adam = nullptr) {
+  float s = 0.f;
+  for (int g = lane; g < a.hb_n[h]; g += 64) s += a.hb_part[h * kLossMaxWG + g];
+  s = nvf_wave_sum(s);
+  if (lane != 0) return 0;
+  *a.hb_out[h] = s;
+  return adam ? adam_fused_elem(*adam, a.hb_out[h], s) : 0;
+}
+
+// workgroups of a finals launch that run the bias sums (64 channels each); the first one also hosts the heads' sums
+__host__ __device__ inline int finals_sum_blocks(const FinalsArgs& a) {
+  const int n = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
+  return n > 0 ? n : (a.has_hb ? 1 : 0);
+}
 
 struct TailRanges { long lo[16], hi[16]; int n; };
 
@@ -282,6 +301,7 @@ __device__ __forceinline__ void finals_tail_body(const FinalsArgs& a, int sum_bl
     if (a.has_g && tid < 256) bad += stem_gdn_final_body(a.g, tid, 256, &ad);
   } else if (bid < 2 + sum_blocks) {
     if (a.has_s && tid < 64) bad += multi_channel_sum_final_body(a.s, a.s_part, (bid - 2) * 64 + tid, &ad);
+    if (a.has_hb && bid == 2 && wave >= 1 && wave <= 3) bad += head_bias_final_body(a, wave - 1, lane, &ad);
   } else {
     for (int r = 0; r < rg.n; ++r)
       for (long i = rg.lo[r] + tid; i < rg.hi[r]; i += blockDim.x) bad += adam_fused_elem(ad, t.g + i, t.g[i]);
@@ -332,6 +352,8 @@ int nvf_finals_run_stem_gdn(NvfStepCtx* ctx, const StemGdnFinal& f, void* stream
 // queue the focal final pass or, when nothing is being deferred, launch it on `stream`
 int nvf_finals_run_focal(NvfStepCtx* ctx, const FocalMulti& m, const float* part, float* loss, int nterm, void* stream);
 bool nvf_finals_push_sums(NvfStepCtx* ctx, const MultiSumDesc& d, const float* part);
+// queue the heads' bias sums or, when nothing is being deferred, launch them on `stream`
+int nvf_finals_run_head_bias(NvfStepCtx* ctx, const float* part, float* const* outs, const int* n, void* stream);
 bool nvf_finals_push_metrics(NvfStepCtx* ctx, const float* part, float* out, const int* nwg, int nterm, int accumulate);
 bool nvf_finals_push_rate(NvfStepCtx* ctx, const WeightRateBatch& b, const float* part, const float* sigma, float* bits,
                           float* dsigma, float* dmu, const float* g_dev, float g_host);

@@ -6,8 +6,9 @@ namespace {
 // workgroup 0: the focal terms (one wave each); workgroup 1: the weight-rate term (wave 0) and the stem's IGDN
 // parameter gradients (waves 1-2); workgroups 2..: 64 bias channels each; with metrics queued, one more workgroup at
 // the end: its first six lanes add the metric partials in row order (the arithmetic of finalize_partials)
-__global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a, int sum_blocks) {
+__global__ __launch_bounds__(256) void finals_kernel(FinalsArgs a, int sum_blocks) {
   const int tid = threadIdx.x;
+  if (a.has_hb && blockIdx.x == 2 && tid >= 64) head_bias_final_body(a, (tid >> 6) - 1, tid & 63);
   if ((int)blockIdx.x == 2 + sum_blocks) {
     if (a.has_m) metrics_final_body(a.m_part, a.m_out, a.m_nwg, a.m_nterm, a.m_accumulate, tid);
   } else if (blockIdx.x == 0) {
@@ -15,7 +16,7 @@ __global__ __launch_bounds__(192) void finals_kernel(FinalsArgs a, int sum_block
   } else if (blockIdx.x == 1) {
     if (a.has_r && tid < 64)
       weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost, tid);
-    if (a.has_g && tid >= 64) stem_gdn_final_body(a.g, tid - 64, 128);
+    if (a.has_g && tid >= 64 && tid < 192) stem_gdn_final_body(a.g, tid - 64, 128);
   } else if (a.has_s && tid < 64) {
     multi_channel_sum_final_body(a.s, a.s_part, ((int)blockIdx.x - 2) * 64 + tid);
   }
@@ -57,6 +58,19 @@ bool nvf_finals_push_rate(NvfStepCtx* ctx, const WeightRateBatch& b, const float
   q.r = b; q.r_part = part; q.r_sigma = sigma; q.r_bits = bits; q.r_dsigma = dsigma;
   q.r_dmu = dmu; q.r_gdev = g_dev; q.r_ghost = g_host; q.has_r = 1;
   return true;
+}
+
+__global__ void head_bias_final_kernel(FinalsArgs a) { head_bias_final_body(a, threadIdx.x >> 6, threadIdx.x & 63); }
+
+int nvf_finals_run_head_bias(NvfStepCtx* ctx, const float* part, float* const* outs, const int* n, void* stream) {
+  FinalsArgs one{};
+  FinalsArgs& q = (nvf_ctx_ok(ctx) && ctx->deferring && !ctx->args.has_hb) ? ctx->args : one;
+  q.hb_part = part; q.has_hb = 1;
+  for (int h = 0; h < 3; ++h) { q.hb_out[h] = outs[h]; q.hb_n[h] = n[h]; }
+  if (&q != &one) return NVF_OK;
+  head_bias_final_kernel<<<1, 192, 0, nvf_stream(stream)>>>(one);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
 }
 
 __global__ void stem_gdn_final_kernel(StemGdnFinal f) { stem_gdn_final_body(f, threadIdx.x, 128); }
@@ -127,7 +141,7 @@ extern "C" int nvf_finals_flush_tail(NvfStepCtx* ctx, const NvfStepTail* tail, c
   ctx->args = FinalsArgs{};
   ctx->deferring = 0;
   if (a.has_f && a.f_nterm > 3) return NVF_EINVAL;
-  const int sum_blocks = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
+  const int sum_blocks = finals_sum_blocks(a);
   finals_tail_kernel<<<2 + sum_blocks + 1, 256, 0, nvf_stream(stream)>>>(a, sum_blocks, t, rg);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -138,9 +152,9 @@ extern "C" int nvf_finals_flush(NvfStepCtx* ctx, void* stream) {
   const FinalsArgs a = ctx->args;
   ctx->args = FinalsArgs{};
   ctx->deferring = 0;
-  if (!a.has_f && !a.has_s && !a.has_r && !a.has_g && !a.has_m) return NVF_OK;
-  const int sum_blocks = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
-  finals_kernel<<<2 + sum_blocks + (a.has_m ? 1 : 0), 192, 0, nvf_stream(stream)>>>(a, sum_blocks);
+  if (!a.has_f && !a.has_s && !a.has_r && !a.has_g && !a.has_m && !a.has_hb) return NVF_OK;
+  const int sum_blocks = finals_sum_blocks(a);
+  finals_kernel<<<2 + sum_blocks + (a.has_m ? 1 : 0), 256, 0, nvf_stream(stream)>>>(a, sum_blocks);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

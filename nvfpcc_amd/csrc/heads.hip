@@ -205,6 +205,7 @@ struct HeadLoss {
   const float* dist;       // or null
   float* dl;               // [B, 1, S^3] out
   float* part;             // loss partials of this term: one per workgroup
+  float* bias_part;        // or null: the sum of the workgroup's own dl values (the head's bias gradient), one per workgroup
   float alpha, beta;
 };
 
@@ -214,7 +215,7 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
   constexpr int XG = S / 4, IZ = TZ + 2, IY = TY + 2, ITEMS = IZ * IY * XG;
   const size_t vol = (size_t)S * S * S;
   const float a1 = f.alpha, a0 = 1.f - f.alpha;
-  float s = 0.f;
+  float s = 0.f, sb = 0.f;
   constexpr int U = (ITEMS + NT - 1) / NT;                    // every load of the thread in flight before any is used
   float4 pv[U], gv[U], dv[U];
 #pragma unroll
@@ -245,6 +246,7 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
       if (zi >= 1 && zi <= TZ && yi >= 1 && yi <= TY) {       // this tile's own voxels
         *(float4*)(f.dl + off) = o;
         s += (t0 + t1) + (t2 + t3);
+        sb += (o.x + o.y) + (o.z + o.w);
       }
     }
     float* row = ds + (size_t)r * RS;
@@ -254,6 +256,10 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
   }
   const float tot = nvf_block_sum(s, red);
   if (tid == 0) f.part[wg] = tot;
+  if (f.bias_part) {
+    const float totb = nvf_block_sum(sb, red + 8);
+    if (tid == 0) f.bias_part[wg] = totb;
+  }
 }
 
 // ---- backward-data: dx[c, i] = sum_k' dl[i - 1 + k'] wb[k'][c]  (wb = w_bwd: taps flipped) ---------------------
@@ -624,7 +630,8 @@ template <class H0, class H1, class H2>
 static int heads3_loss_bwd_data_t(const float* const* ps, const float* const* gts, const float* const* dists,
                                   const float* alphas, const float* betas, const int* slots, float* loss,
                                   float* const* dls, const float* const* wbs, float* const* dxs,
-                                  const float* const* masks, int batch, void* workspace, NvfStepCtx* ctx, void* stream) {
+                                  const float* const* masks, int batch, void* workspace, NvfStepCtx* ctx, void* stream,
+                                  float* const* bias_outs) {
   static_assert(H0::NT == 256 && H1::NT == 256 && H2::NT == 256, "one workgroup size");
   Heads3 m{};
   Heads3Loss f{};
@@ -636,13 +643,41 @@ static int heads3_loss_bwd_data_t(const float* const* ps, const float* const* gt
     m.w[h] = wbs[h]; m.out[h] = dxs[h]; m.mask[h] = masks[h];
     f.h[h].p = ps[h]; f.h[h].gt = gts[h]; f.h[h].dist = dists[h]; f.h[h].dl = dls[h];
     f.h[h].part = (float*)workspace + slots[h] * kLossMaxWG;
+    f.h[h].bias_part = bias_outs ? (float*)workspace + (3 + h) * kLossMaxWG : nullptr;
     f.h[h].alpha = alphas[h]; f.h[h].beta = betas[h];
     fm.nwg[slots[h]] = m.n[h];
   }
   if (slots[0] == slots[1] || slots[0] == slots[2] || slots[1] == slots[2]) return NVF_EINVAL;
   heads3_loss_bwd_data_kernel<H0, H1, H2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, nvf_stream(stream)>>>(m, f);
   NVF_LAUNCH_CHECK();
+  if (bias_outs) {
+    const int rc = nvf_finals_run_head_bias(ctx, (const float*)workspace + 3 * kLossMaxWG, bias_outs, m.n, stream);
+    if (rc != NVF_OK) return rc;
+  }
   return nvf_finals_run_focal(ctx, fm, (const float*)workspace, loss, 3, stream);
+}
+
+// ... and, with bias_outs (three pointers), the heads' bias gradients bias_outs[h][0] = sum of dls[h]: one partial per
+// workgroup from the values it writes anyway, added by the deferred finals (or a launch of their own).
+extern "C" int nvf_heads3_loss_bwd_data_bias(const float* const* ps, const float* const* gts, const float* const* dists,
+                                             const float* alphas, const float* betas, const int* slots, float* loss,
+                                             float* const* dls, const float* const* wbs, float* const* dxs,
+                                             const float* const* masks, const int* cs, const int* ss, int batch,
+                                             float* const* bias_outs, void* workspace, size_t workspace_bytes,
+                                             NvfStepCtx* ctx, void* stream) {
+  if (!ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs || !masks || !cs || !ss ||
+      !workspace || batch <= 0)
+    return NVF_EINVAL;
+  if (bias_outs && (!bias_outs[0] || !bias_outs[1] || !bias_outs[2])) return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  const int t = heads3_tuple(cs, ss);
+  if (t == 0)
+    return heads3_loss_bwd_data_t<HCfg<16, 8, 4, 8>, HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>>(
+        ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, ctx, stream, bias_outs);
+  if (t == 1)
+    return heads3_loss_bwd_data_t<HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 4, 8>>(
+        ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, ctx, stream, bias_outs);
+  return NVF_EINVAL;
 }
 
 extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* const* gts, const float* const* dists,
@@ -650,18 +685,8 @@ extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* con
                                         float* const* dls, const float* const* wbs, float* const* dxs,
                                         const float* const* masks, const int* cs, const int* ss, int batch,
                                         void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
-  if (!ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs || !masks || !cs || !ss ||
-      !workspace || batch <= 0)
-    return NVF_EINVAL;
-  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
-  const int t = heads3_tuple(cs, ss);
-  if (t == 0)
-    return heads3_loss_bwd_data_t<HCfg<16, 8, 4, 8>, HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>>(
-        ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, ctx, stream);
-  if (t == 1)
-    return heads3_loss_bwd_data_t<HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 4, 8>>(
-        ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, ctx, stream);
-  return NVF_EINVAL;
+  return nvf_heads3_loss_bwd_data_bias(ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, cs, ss, batch,
+                                       nullptr, workspace, workspace_bytes, ctx, stream);
 }
 
 // partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)

@@ -1419,7 +1419,7 @@ extern "C" int nvf_wgrad_reduce_finals_tail(const float* const* slabs, float* co
   ctx->args = FinalsArgs{};
   ctx->deferring = 0;
   if (a.has_f && a.f_nterm > 3) return NVF_EINVAL;
-  const int sum_blocks = a.has_s ? (a.s.total_channels + 63) / 64 : 0;
+  const int sum_blocks = finals_sum_blocks(a);
   const int f_blocks = 2 + sum_blocks + 1;
   wgrad_reduce_finals_tail<<<f_blocks + base, 1024, 0, nvf_stream(stream)>>>(r, f_blocks, a, sum_blocks, t, rg);
   NVF_LAUNCH_CHECK();

@@ -32,6 +32,7 @@ _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wi
 _VAR = {k: int(os.environ.get("NVF_VAR_" + k, "0")) for k in ("UP1F", "UP2F", "UP1B", "UP2B", "C1F", "C1B")}   # tile variants
 _CONV2_FWD_VAR = int(os.environ.get("NVF_CONV2_FWD_VAR", "0"))   # tile-shape variants of conv_k4_mfma (tuning)
 _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
+_HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
 _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
 
@@ -442,6 +443,7 @@ class TrainEngine:
         main = torch.cuda.current_stream()
         self.overlap = self.allow_overlap and a["e"].shape[0] <= 64
         self._bias_jobs = []
+        self._bias_cover = []     # bias gradients some launch's own final pass writes (no channel-sum job needed)
         if self._wg is None:
             self._wg = ops.WgradBatch(self.dev, ctx=self.ctx)    # partial sums now, ONE reduction launch for all ten
         loss = torch.empty(4, device=self.dev)   # [main, head0, head1, unused]
@@ -469,7 +471,8 @@ class TrainEngine:
                 (dl0, dl1, dl2), (t0, t1, g5) = ops.heads3_loss_bwd_data(
                     [a["p0"], a["p1"], a["p2"]], [gt8, gt16, gt], [None, None, dist], [0.85, 0.85, 0.9],
                     [0.0, 0.0, 1.0], [1, 2, 0], loss, [L.w_bwd for L in hl], [L.cin for L in hl], [None, None, a["y5"]],
-                    ctx=ctx)
+                    ctx=ctx, bias_outs=[L.gb for L in hl] if (want_w and _HEAD_BIAS_IN_LOSS) else None)
+                head_bias_done = want_w and _HEAD_BIAS_IN_LOSS    # the heads' bias gradients: partials of that launch
             else:
                 t0, t1, g5 = ops.heads3_bwd_data([dl0, dl1, dl2], [L.w_bwd for L in hl], [L.cin for L in hl],
                                                  [None, None, a["y5"]])
@@ -479,7 +482,10 @@ class TrainEngine:
                 if not (self.narrow and _NAIVE_OFF() and _HEADS_IN_TRUNK5):   # else: workgroups of the five-gradient launch
                     self._wg.add_heads3(*heads_job)
                     heads_job = None
-                self._bias_jobs += [(dl2, hl[2].gb), (dl1, hl[1].gb), (dl0, hl[0].gb)]
+                if fused_loss and head_bias_done:
+                    self._bias_cover += [L.gb for L in hl]
+                else:
+                    self._bias_jobs += [(dl2, hl[2].gb), (dl1, hl[1].gb), (dl0, hl[0].gb)]
         else:
             self._fork()
             with self._on_side():
@@ -670,7 +676,7 @@ class TrainEngine:
         for j in self._wg.jobs:
             if j[2] > 0:
                 cover.append(((j[1] - base) // esz, (j[1] - base) // esz + j[3]))
-        for _, o in self._bias_jobs:
+        for o in [o for _, o in self._bias_jobs] + self._bias_cover:
             cover.append(((o.data_ptr() - base) // esz, (o.data_ptr() - base) // esz + o.numel()))
         for g1 in (gs, gm):
             cover.append(((g1.data_ptr() - base) // esz, (g1.data_ptr() - base) // esz + g1.numel()))

@@ -482,20 +482,24 @@ def heads3_bwd_data(dls, w_bwds, cs, masks):
     return dxs
 
 
-def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs, masks, ctx=None):
+def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs, masks, ctx=None, bias_outs=None):
     """focal_loss_multi (gradients w.r.t. the logits) + heads3_bwd_data in one launch: returns (dls, dxs);
-    loss[slots[h]] = focal term of head h (after finals_flush when the final passes are deferred).  batch <= 32."""
+    loss[slots[h]] = focal term of head h (after finals_flush when the final passes are deferred).  batch <= 32.
+    ``bias_outs``: three tensors that receive sum(dls[h]) (the heads' bias gradients) from the same launch."""
     import ctypes
     _f32(*ps, *gts, *[d for d in dists if d is not None], *w_bwds, *[m for m in masks if m is not None], loss)
     B = ps[0].shape[0]
     dls = [torch.empty_like(p) for p in ps]
     dxs = [torch.empty((B, c) + tuple(p.shape[2:]), device=p.device) for p, c in zip(ps, cs)]
     ws = workspace(lib().nvf_reduce_workspace(), ps[0].device, "reduce", ctx)
-    check(lib().nvf_heads3_loss_bwd_data(_parr(ps), _parr(gts), _parr(dists), (ctypes.c_float * 3)(*alphas),
-                                         (ctypes.c_float * 3)(*betas), _iarr(slots), _ptr(loss), _parr(dls),
-                                         _parr(w_bwds), _parr(dxs), _parr(masks), _iarr(cs),
-                                         _iarr([p.shape[-1] for p in ps]), B, _ptr(ws), ws.numel(), _ctx(ctx),
-                                         _stream()), "nvf_heads3_loss_bwd_data")
+    if bias_outs is not None:
+        _f32(*bias_outs)
+    check(lib().nvf_heads3_loss_bwd_data_bias(_parr(ps), _parr(gts), _parr(dists), (ctypes.c_float * 3)(*alphas),
+                                              (ctypes.c_float * 3)(*betas), _iarr(slots), _ptr(loss), _parr(dls),
+                                              _parr(w_bwds), _parr(dxs), _parr(masks), _iarr(cs),
+                                              _iarr([p.shape[-1] for p in ps]), B,
+                                              None if bias_outs is None else _parr(bias_outs), _ptr(ws), ws.numel(),
+                                              _ctx(ctx), _stream()), "nvf_heads3_loss_bwd_data_bias")
     return dls, dxs
 
 

@@ -803,6 +803,24 @@ def test_heads_loss_and_backward_data_in_one_launch(ops, which):
     for got, ref in zip(dxs, dx_ref):
         assert torch.equal(got, ref)
     np.testing.assert_allclose(loss[:3].cpu().numpy(), loss_ref[:3].cpu().numpy(), rtol=2e-6)
+    # ... and with bias_outs: the heads' bias gradients (sum of the logit gradients) from the same launch, directly and
+    # through the deferred final passes; everything else unchanged
+    for deferred in (False, True):
+        gbs = [torch.full((1,), 7.0, device="cuda") for _ in range(3)]
+        ctx = ops.StepCtx() if deferred else None
+        if deferred:
+            ctx.begin()
+        dls2, dxs2 = ops.heads3_loss_bwd_data(ps, gts, [None, None, dist], [0.85, 0.85, 0.9], [0.0, 0.0, 1.0],
+                                              [1, 2, 0], loss, wbs, cs, [None, None, mask], ctx=ctx, bias_outs=gbs)
+        if deferred:
+            assert all(float(g) == 7.0 for g in gbs)
+            ctx.flush()
+        for got, ref, gb in zip(dls2, (dl0, dl1, dl2), gbs):
+            assert torch.equal(got, ref)
+            want = float(ref.double().sum())
+            assert abs(float(gb) - want) <= 2e-6 * float(ref.double().abs().sum()) + 1e-12, (float(gb), want)
+        for got, ref in zip(dxs2, dx_ref):
+            assert torch.equal(got, ref)
     with pytest.raises(RuntimeError):          # one loss partial per workgroup: batch <= 32
         big = [torch.rand(33, 1, s, s, s, device="cuda") for c, s in shapes]
         ops.heads3_loss_bwd_data(big, big, [None, None, None], [0.85, 0.85, 0.9], [0.0, 0.0, 1.0], [1, 2, 0], loss,
