@@ -23,12 +23,14 @@
 // Per output the accumulation order is fixed (ci group, ty, tx, tz), independent of batch and tile.
 #include "nvf_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MDims {
   int din, hin, win, dout, hout, wout, pad, act, tiles_x, tiles_y, tiles_z;
   int dbg;   // tuning runs only (variant >= 100): 1 = no staging, 2 = no MFMAs; results are then meaningless
+             // (bit 2, NVF_A_GLOBAL=1: every wave fetches its A fragments from global memory itself)
   float* bias_part;   // EPI 1 only, optional: per (workgroup, wave) the 8 channel sums of the outputs it stored -- the
                       // bias gradient of the layer below (its masked output gradient is what this pass writes)
 };
@@ -329,7 +331,11 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
                                                             const float* __restrict__ mask, MDims d, int total) {
   constexpr int NC = C::NC, NT = C::NT, RS = C::RS, CS = C::CS, ZS = C::ZS, CIN = C::CIN, NG = CIN / 4, BUF = C::BUF;
   static_assert(NG % 2 == 0, "the two LDS buffers alternate per channel group");
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+  // the layer's A fragments (NA x 64 floats, the same for every wave) pass through LDS once per workgroup when they fit
+  // and eight waves would otherwise pull them through the L1 (conv2: -0.6 / -1.1 us; with four waves, conv1, the extra
+  // barrier-to-first-MFMA latency costs more than the L1 traffic saved: +0.7 us)
+  constexpr bool A_LDS = C::NW >= 8 && (2 * BUF + C::NA * 64) * 4 <= 160 * 1024;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + (A_LDS ? C::NA * 64 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // tiles of this workgroup: XCD k (workgroups k, k+8, ...) owns tiles [k per, (k+1) per)
@@ -365,16 +371,26 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
   };
   int b, oz0, oy0, ox0;
   origin(t, b, oz0, oy0, ox0);
+  const bool a_lds = A_LDS && !(d.dbg & 4);
+  if (a_lds) {                     // one copy per workgroup by LDS-DMA, in flight with the first tile's staging
+    const float* wps = nvf_uniform_ptr(wp);
+#pragma unroll 4
+    for (int i = wave; i < C::NA; i += C::NW)
+      nvf_glds_row(wps, (unsigned)(i * 64 + lane) * 4u, lds0 + (unsigned)(2 * BUF + i * 64) * 4u);
+  }
   st.issue(x + (size_t)b * CIN * vol, lds, lds0, 0, wave, lane, oz0 - d.pad, oy0 - d.pad, ox0 - d.pad, d);
   // every A fragment of the layer, resident in registers for the whole launch.  Only the first channel group's are
   // fetched before the loop: the explicit vmcnt(0) that ends a staging step waits for EVERY outstanding load, so the
   // other groups' fragments are requested right after the first barrier (the first tile's first step is peeled) and
   // arrive under group 0's MFMAs -- all NA up front was 6.5 us of the 52 us launch (s_memrealtime stamps; it is bound
-  // by the L1's throughput: 8 waves x 40 KB).
+  // by the L1's throughput: 8 waves x 40 KB).  With the LDS copy above, the L1 sees the 40 KB once and every wave takes
+  // its registers from LDS after the first barrier (160 conflict-free ds_reads).
   constexpr int NA0 = C::NA / NG;
   float A[C::NA];
+  if (!a_lds) {
 #pragma unroll
-  for (int i = 0; i < NA0; ++i) A[i] = wp[(size_t)i * 64 + lane];
+    for (int i = 0; i < NA0; ++i) A[i] = wp[(size_t)i * 64 + lane];
+  }
 
   bool more = false;
   int bn = 0, ozn = 0, oyn = 0, oxn = 0;
@@ -402,8 +418,14 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
     };
     step(std::integral_constant<int, 0>{});
     if constexpr (FIRST) {                                   // the remaining fragments are requested here
+      if (a_lds) {
+        const float* la = lds + 2 * BUF + lane;
 #pragma unroll
-      for (int i = NA0; i < C::NA; ++i) A[i] = wp[(size_t)i * 64 + lane];
+        for (int i = 0; i < C::NA; ++i) A[i] = la[i * 64];
+      } else {
+#pragma unroll
+        for (int i = NA0; i < C::NA; ++i) A[i] = wp[(size_t)i * 64 + lane];
+      }
     }
     if (!(d.dbg & 2)) mfma_step<C, 0>(lds, colbase, A, acc);
     if constexpr (NG > 1) { step(std::integral_constant<int, 1>{}); if (!(d.dbg & 2)) mfma_step<C, (NG > 1 ? 1 : 0)>(lds + BUF, colbase, A, acc); }
@@ -486,6 +508,8 @@ extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const fl
   if (bias_part && (!bias_nparts || bias || act != NVF_ACT_NONE || addend || !mask)) return NVF_EINVAL;
   MDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0, 0, bias_part};
   if (variant >= 100) { d.dbg = variant / 100; variant %= 100; }
+  static const int a_global = getenv("NVF_A_GLOBAL") ? 4 : 0;
+  d.dbg |= a_global;
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
 #define NVF_M(VAR, CI, PA, WLO, WHI, CTY, CTX, RY, RX, NWC, NWZ, NT)                                   \

@@ -40,9 +40,8 @@ for r in csv.DictReader(open(f)):
 P
 }
 run a X=1
-showk a reduce_finals
-run c NVF_SUMS_IN_TRUNK5=0
-showk c reduce
-showk c finals_tail
+showk a conv_k4
+run c NVF_A_GLOBAL=1
+showk c conv_k4
 run a2 X=1
-showk a2 reduce_finals
+showk a2 conv_k4
