@@ -717,10 +717,10 @@ extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* co
                                         void* stream) {
   if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
   const int t = heads3_tuple(cs, ss);
-  // narrow decoder: on the matrix cores (heads_wgrad_mfma.hip; NVF_HEADS_WG_VALU=1 keeps the VALU kernels: tuning)
+  // on the matrix cores (heads_wgrad_mfma.hip; NVF_HEADS_WG_VALU=1 keeps the VALU kernels: tuning)
   static const bool valu = getenv("NVF_HEADS_WG_VALU") != nullptr;
-  if (t == 0 && !valu) {
-    const int rc = nvf_heads3_wgrad_mfma_launch(dls, xs, slabs, 1, batch, max_slabs, nslabs, nvf_stream(stream));
+  if ((t == 0 || t == 1) && !valu) {
+    const int rc = nvf_heads3_wgrad_mfma_launch(dls, xs, slabs, t == 0, batch, max_slabs, nslabs, nvf_stream(stream));
     if (rc != 1) {
       if (rc != NVF_OK) return rc;
       NVF_LAUNCH_CHECK();

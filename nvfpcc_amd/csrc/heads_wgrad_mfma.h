@@ -54,7 +54,9 @@ struct HMCfg {
 template <class H>
 __device__ __forceinline__ void head_wgrad_mfma_body(const float* __restrict__ dl, const float* __restrict__ x,
                                                      float* __restrict__ slabs, int items, int items_per_wg, int bx,
-                                                     float* lds) {
+                                                     float* lds, int ct = H::C) {
+  // ct: channels of the tensor x / rows of a slab (> C when this call handles one group of C channels of a wider head:
+  // x and slabs then point at the group's first channel / row)
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, ACS = H::ACS, BRS = H::BRS, BPS = H::BPS, UA = H::UA,
                 UB = H::UB, SEG4 = H::SEG4;
   float* la = lds;
@@ -103,7 +105,7 @@ __device__ __forceinline__ void head_wgrad_mfma_body(const float* __restrict__ d
   auto load = [&](int item) {
     const int tile = item % TILES, b = item / TILES;
     const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * C * S * S * S), 0,
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * ct * S * S * S), 0,
                                                                         C * S * S * S * 4, 0x00020000);
     const int xs = ((z0 * S + y0) * S) * 4;
 #pragma unroll
@@ -171,7 +173,7 @@ __device__ __forceinline__ void head_wgrad_mfma_body(const float* __restrict__ d
 #pragma unroll
     for (int r = 0; r < 4; ++r) lds[(wave * 2 + tt) * 256 + (4 * k + r) * 16 + i16] = acc[tt][r];
   __syncthreads();
-  float* slab = slabs + (size_t)bx * (C * 27);
+  float* slab = slabs + (size_t)bx * (ct * 27);
   for (int o = tid; o < C * 27; o += 256) {
     const int c = o / 27, t = o % 27, tt = t >> 4, col = t & 15;
     const int w = tt * 256 + c * 16 + col;
@@ -185,21 +187,25 @@ struct HeadsW3 {
   const float* dl[3];
   const float* x[3];
   float* slabs[3];
-  int32_t n[3], items[3], per[3];
+  int32_t n[3], items[3], per[3];     // n[h]: workgroups of head h (slabs x channel groups)
 };
 constexpr int hmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
-template <class H0, class H1, class H2>
+// G0: channel groups of head 0 (the wide decoder's first head has 32 channels = two row tiles of H0::C = 16)
+template <class H0, class H1, class H2, int G0 = 1>
 __device__ __forceinline__ void heads3_wgrad_mfma_dispatch(const HeadsW3& m, int bid, float* lds) {
   if (bid < m.n[2]) { head_wgrad_mfma_body<H2>(m.dl[2], m.x[2], m.slabs[2], m.items[2], m.per[2], bid, lds); return; }
   bid -= m.n[2];
   if (bid < m.n[1]) { head_wgrad_mfma_body<H1>(m.dl[1], m.x[1], m.slabs[1], m.items[1], m.per[1], bid, lds); return; }
   bid -= m.n[1];
-  head_wgrad_mfma_body<H0>(m.dl[0], m.x[0], m.slabs[0], m.items[0], m.per[0], bid, lds);
+  constexpr int S3 = H0::S * H0::S * H0::S;
+  const int per_group = m.n[0] / G0, g = bid / per_group;
+  head_wgrad_mfma_body<H0>(m.dl[0], m.x[0] + (size_t)g * H0::C * S3, m.slabs[0] + g * H0::C * 27, m.items[0], m.per[0],
+                           bid - g * per_group, lds, H0::C * G0);
 }
 
-// geometry of the three jobs (nslabs[h] = workgroups = slabs of head h)
-template <class H0, class H1, class H2>
+// geometry of the three jobs (nslabs[h] = slabs of head h; head 0 runs G0 workgroups per slab)
+template <class H0, class H1, class H2, int G0 = 1>
 static inline int heads3_wgrad_mfma_fill(HeadsW3& m, const float* const* dls, const float* const* xs,
                                          float* const* slabs, int batch, int max_slabs, int* nslabs) {
   const int items[3] = {batch * (H0::S / H0::TZ) * (H0::S / H0::TY), batch * (H1::S / H1::TZ) * (H1::S / H1::TY),
@@ -210,7 +216,7 @@ static inline int heads3_wgrad_mfma_fill(HeadsW3& m, const float* const* dls, co
     int n = items[h] < max_slabs ? items[h] : max_slabs;
     const int per = (items[h] + n - 1) / n;
     n = (items[h] + per - 1) / per;
-    m.n[h] = n; m.items[h] = items[h]; m.per[h] = per;
+    m.n[h] = h == 0 ? n * G0 : n; m.items[h] = items[h]; m.per[h] = per;
     nslabs[h] = n;
   }
   return NVF_OK;
@@ -220,3 +226,7 @@ static inline int heads3_wgrad_mfma_fill(HeadsW3& m, const float* const* dls, co
 using HeadW0 = HMCfg<16, 8, 4, 8>;
 using HeadW1 = HMCfg<8, 16, 4, 8>;
 using HeadW2 = HMCfg<8, 32, 2, 8>;
+// the wide decoder's: conv0_cls [32, 8^3] (two groups of 16 channels), conv1_cls [16, 16^3], conv2_cls [16, 32^3]
+using HeadWw0 = HMCfg<16, 8, 4, 8>;
+using HeadWw1 = HMCfg<16, 16, 4, 8>;
+using HeadWw2 = HMCfg<16, 32, 2, 8>;

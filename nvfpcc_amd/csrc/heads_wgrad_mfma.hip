@@ -18,25 +18,33 @@
 // in registers (buffer loads: scalar descriptor + scalar offsets + one per-thread voffset) while this item's MFMAs issue.
 // Its four waves split an item's K groups; their partial D tiles are added in wave order through LDS at the end and
 // leave as ONE slab of C * 27 floats per workgroup (added in a fixed order by nvf_wgrad_reduce_multi): no atomics.
+// A head with 32 channels (the wide decoder's first) is two groups of 16 rows: two workgroups per slab.
 #include "heads_wgrad_mfma.h"
 
 namespace {
 
-template <class H0, class H1, class H2>
+template <class H0, class H1, class H2, int G0>
 __global__ __launch_bounds__(256) void heads3_wgrad_mfma_kernel(HeadsW3 m) {
   __shared__ __attribute__((aligned(16))) float lds[hmax3(H0::SMEM, H1::SMEM, H2::SMEM)];
-  heads3_wgrad_mfma_dispatch<H0, H1, H2>(m, blockIdx.x, lds);
+  heads3_wgrad_mfma_dispatch<H0, H1, H2, G0>(m, blockIdx.x, lds);
+}
+
+template <class H0, class H1, class H2, int G0>
+int launch_heads3(const float* const* dls, const float* const* xs, float* const* slabs, int batch, int max_slabs,
+                  int* nslabs, hipStream_t s) {
+  HeadsW3 m{};
+  const int rc = heads3_wgrad_mfma_fill<H0, H1, H2, G0>(m, dls, xs, slabs, batch, max_slabs, nslabs);
+  if (rc != NVF_OK) return rc;
+  heads3_wgrad_mfma_kernel<H0, H1, H2, G0><<<m.n[0] + m.n[1] + m.n[2], 256, 0, s>>>(m);
+  return NVF_OK;
 }
 
 }  // namespace
 
-// matrix-core form of nvf_heads3_wgrad_partial (same contract); 1 = no instantiation for these heads
+// matrix-core form of nvf_heads3_wgrad_partial (same contract: slabs of cs[h] * 27 floats); narrow: the (16, 8, 8)-
+// channel heads, otherwise the wide decoder's (32, 16, 16)
 int nvf_heads3_wgrad_mfma_launch(const float* const* dls, const float* const* xs, float* const* slabs, int narrow,
                                  int batch, int max_slabs, int* nslabs, hipStream_t s) {
-  if (!narrow) return 1;      // the wide decoder's first head has 32 channels: two row tiles, not instantiated
-  HeadsW3 m{};
-  const int rc = heads3_wgrad_mfma_fill<HeadW0, HeadW1, HeadW2>(m, dls, xs, slabs, batch, max_slabs, nslabs);
-  if (rc != NVF_OK) return rc;
-  heads3_wgrad_mfma_kernel<HeadW0, HeadW1, HeadW2><<<m.n[0] + m.n[1] + m.n[2], 256, 0, s>>>(m);
-  return NVF_OK;
+  if (narrow) return launch_heads3<HeadW0, HeadW1, HeadW2, 1>(dls, xs, slabs, batch, max_slabs, nslabs, s);
+  return launch_heads3<HeadWw0, HeadWw1, HeadWw2, 2>(dls, xs, slabs, batch, max_slabs, nslabs, s);
 }

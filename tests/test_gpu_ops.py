@@ -132,9 +132,9 @@ HEAD_TUPLES = {"narrow": [(16, 8), (8, 16), (8, 32)], "wide": [(32, 8), (16, 16)
 @pytest.mark.parametrize("which", ["narrow", "wide"])
 def test_three_head_launches_equal_the_single_head_kernels(ops, which):
     """nvf_heads3_* run the same kernel bodies as the per-head calls: forward and backward-data must agree bit for bit
-    -- for the heads of both decoders (chanstr 8,16,8,8 and 16,32,16,16) -- and so must the wide decoder's weight
-    gradients; the narrow decoder's run on the matrix cores (heads_wgrad_mfma.hip: positions are the K index, another
-    summation order) and are held to the fp64 sum and to the VALU kernels to rounding."""
+    -- for the heads of both decoders (chanstr 8,16,8,8 and 16,32,16,16).  The weight gradients run on the matrix cores
+    (heads_wgrad_mfma.hip: positions are the K index, another summation order; the wide decoder's 32-channel head as
+    two groups of 16 rows) and are held to the fp64 sum and to the VALU kernels to rounding."""
     g = gen(7000)
     B = 3
     shapes = HEAD_TUPLES[which]
@@ -156,9 +156,7 @@ def test_three_head_launches_equal_the_single_head_kernels(ops, which):
     wg.finish()
     for dl, x, o, (c, s) in zip(dls, xs, outs, shapes):
         ref = ops.wgrad(dl, x, 3, 1, 1, out_mode=0)
-        if which == "wide":
-            assert torch.equal(o, ref)
-        else:
+        if True:
             xp = torch.nn.functional.pad(x.double().cpu(), (1, 1, 1, 1, 1, 1))
             d64 = dl.double().cpu()
             want = torch.stack([(xp[:, :, kz:kz + s, ky:ky + s, kx:kx + s] * d64).sum(dim=(0, 2, 3, 4))
