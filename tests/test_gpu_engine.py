@@ -632,3 +632,27 @@ def test_engine_eval_forward_is_bit_identical_to_batch_1(tag, gpu):
             assert torch.equal(one[k][0], p_all[k][b]), (tag, b, k)
     chunk = eng.eval_forward(lo=5, hi=21, q=2)["p2"]
     assert torch.equal(chunk, p_all["p2"][5:21])
+
+
+def test_one_launch_tail_equals_the_separate_launches(gpu, monkeypatch):
+    """The single-GPU step ends in ONE launch (nvf_wgrad_reduce_finals_tail: slab reduction + fused Adam + final passes
+    + epoch statistics + schedule hand-over; bias partials from the loss launch and the five-gradient launch).  Switching
+    those groupings off (the slab reduction with its own bias sums, then nvf_finals_flush_tail) must train the same network:
+    same kernels for every weight gradient, bias sums in another summation order -- parameters agree to rounding after
+    six graph-replayed steps across the phase change, the log sums likewise."""
+    from nvfpcc_amd import engine as E
+    from nvfpcc_amd.engine import EpochDriver
+    got = {}
+    for merged in (True, False):
+        monkeypatch.setattr(E, "_SUMS_IN_TRUNK5", merged)
+        monkeypatch.setattr(E, "_HEAD_BIAS_IN_LOSS", merged)
+        net, eng, gt, dist, emb = make("S", gpu, nblk=12)
+        drv = EpochDriver(eng, 4, use_graph=True)
+        drv.run(np.arange(12), 1)
+        drv.run(np.arange(12)[::-1].copy(), 2)
+        torch.cuda.synchronize()
+        got[merged] = (eng.flat_p.clone(), eng.read_epoch_stats().copy())
+    (p1, s1), (p0, s0) = got[True], got[False]
+    d = (p1 - p0).abs()
+    assert float(d.max()) <= 2e-5 and float((d <= 2e-6).float().mean()) >= 0.99, (float(d.max()),)
+    np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)

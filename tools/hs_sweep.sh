@@ -39,9 +39,6 @@ for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
-run a X=1
-showk a conv_k4
-run c NVF_A_GLOBAL=1
-showk c conv_k4
-run a2 X=1
-showk a2 conv_k4
+run base X=1
+for m in 1 6 8 16 32 15; do run skip$m NVF_LIB=$GRAFT_REPO_ROOT/nvfpcc_amd/ab/lib_skip$m.so; done
+run base2 X=1
