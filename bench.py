@@ -308,6 +308,7 @@ def run(args):
     graphed = None
     if not args.no_graph and args.mode == "step":
         graphed = GraphedTrainStep(eng, B, args.q)
+        graphed.prime()      # setup, like the capture itself: every graph launched once before the W warm-up steps
 
     def shares(i):
         ids, whole = nd.shard_minibatch(order, i, B * world, rank, world)
@@ -456,8 +457,8 @@ def run(args):
     launch_desc = "host" if (graphed is None and args.mode == "step") else (
         "hip-graph replay (step head .. backward), then all-reduce + Adam from the host"
         if (graphed is not None and graphed.collective == "host") else
-        "hip-graph replay (step head .. Adam in one graph, %d steps per replay; per-step scalars from a "
-        "device-resident schedule)" % (graphed.unroll if graphed is not None and graphed.graph_u is not None else 1))
+        "hip-graph replay (step head .. Adam in one graph, %s steps per replay, largest that fits first; per-step scalars from a "
+        "device-resident schedule)" % ("/".join(str(u) for u in graphed.unrolls if u in graphed.graphs_u) if graphed is not None and graphed.graphs_u else "1"))
     collective_desc = None if eng.grad_hook is None else (
         "all-reduce captured in the step graph" if (graphed is not None and graphed.collective == "graph")
         else "all-reduce launched from the host")

@@ -562,6 +562,11 @@ int nvf_finals_flush_tail(NvfStepCtx* ctx, const NvfStepTail* tail, const int64_
 int nvf_wgrad_reduce_finals_tail(const float* const* slabs, float* const* dws, const int* nslabs, const int* jtotals,
                                  int n, const float* const* addends, const NvfAdamFuse* adam, NvfStepCtx* ctx,
                                  const NvfStepTail* tail, const int64_t* ranges, int nranges, void* stream);
+/* The same pairing without the optimiser, for steps whose gradients are not final yet (data parallelism: the all-reduce
+ * and nvf_step_tail follow): nvf_wgrad_reduce_multi with addends + nvf_finals_flush in ONE launch.  Same condition: no
+ * queued final pass may read what the reduction writes. */
+int nvf_wgrad_reduce_finals(const float* const* slabs, float* const* dws, const int* nslabs, const int* jtotals, int n,
+                            const float* const* addends, NvfStepCtx* ctx, void* stream);
 int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
 
 /* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose

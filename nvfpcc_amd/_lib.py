@@ -68,6 +68,7 @@ PROTOTYPES = {
     "nvf_wgrad_trunk5_heads_partial": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
     "nvf_wgrad_trunk5_heads_sums_partial": (I, [P, P, P, P, P, P, P, I, P, P, P, P, I, P, Z, P, P, I, P, P, P, P]),
     "nvf_wgrad_reduce_finals_tail": (I, [P, P, P, P, I, P, P, P, P, P, I, P]),
+    "nvf_wgrad_reduce_finals": (I, [P, P, P, P, I, P, P, P]),
     "nvf_channel_sum_workspace": (Z, [I]),
     "nvf_channel_sum": (I, [P, P, P, Z, I, I, I, I, P]),
     "nvf_multi_channel_sum_workspace": (Z, [I]),

@@ -254,6 +254,27 @@ __host__ __device__ inline int finals_sum_blocks(const FinalsArgs& a) {
   return n > 0 ? n : (a.has_hb ? 1 : 0);
 }
 
+// The queued final passes without the optimiser (nvf_finals_flush; data-parallel steps, whose gradients are not final
+// before the all-reduce).  Workgroup 0: the focal terms (one wave each); workgroup 1: the weight-rate term (wave 0) and the
+// stem's IGDN parameter gradients (waves 1-2); workgroups 2 .. 2 + sum_blocks - 1: 64 bias channels each (the first one also
+// the heads' bias sums, waves 1-3); with metrics queued, one more workgroup: the metric partials in row order.  Workgroups
+// of >= 256 threads.
+__device__ __forceinline__ void finals_plain_body(const FinalsArgs& a, int sum_blocks, int bid) {
+  const int tid = threadIdx.x;
+  if (a.has_hb && bid == 2 && tid >= 64 && tid < 256) head_bias_final_body(a, (tid >> 6) - 1, tid & 63);
+  if (bid == 2 + sum_blocks) {
+    if (a.has_m) metrics_final_body(a.m_part, a.m_out, a.m_nwg, a.m_nterm, a.m_accumulate, tid);
+  } else if (bid == 0) {
+    if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
+  } else if (bid == 1) {
+    if (a.has_r && tid < 64)
+      weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost, tid);
+    if (a.has_g && tid >= 64 && tid < 192) stem_gdn_final_body(a.g, tid - 64, 128);
+  } else if (a.has_s && tid < 64) {
+    multi_channel_sum_final_body(a.s, a.s_part, (bid - 2) * 64 + tid);
+  }
+}
+
 struct TailRanges { long lo[16], hi[16]; int n; };
 
 // finals + the tail of a single-GPU training step (nvf_finals_flush_tail).  Workgroup 0 runs the passes the epoch

@@ -3,23 +3,8 @@
 
 namespace {
 
-// workgroup 0: the focal terms (one wave each); workgroup 1: the weight-rate term (wave 0) and the stem's IGDN
-// parameter gradients (waves 1-2); workgroups 2..: 64 bias channels each; with metrics queued, one more workgroup at
-// the end: its first six lanes add the metric partials in row order (the arithmetic of finalize_partials)
 __global__ __launch_bounds__(256) void finals_kernel(FinalsArgs a, int sum_blocks) {
-  const int tid = threadIdx.x;
-  if (a.has_hb && blockIdx.x == 2 && tid >= 64) head_bias_final_body(a, (tid >> 6) - 1, tid & 63);
-  if ((int)blockIdx.x == 2 + sum_blocks) {
-    if (a.has_m) metrics_final_body(a.m_part, a.m_out, a.m_nwg, a.m_nterm, a.m_accumulate, tid);
-  } else if (blockIdx.x == 0) {
-    if (a.has_f) focal_multi_final_body(a.f, a.f_part, a.f_loss, a.f_nterm, tid);
-  } else if (blockIdx.x == 1) {
-    if (a.has_r && tid < 64)
-      weight_rate_batch_final_body(a.r, a.r_part, a.r_sigma, a.r_bits, a.r_dsigma, a.r_dmu, a.r_gdev, a.r_ghost, tid);
-    if (a.has_g && tid >= 64 && tid < 192) stem_gdn_final_body(a.g, tid - 64, 128);
-  } else if (a.has_s && tid < 64) {
-    multi_channel_sum_final_body(a.s, a.s_part, ((int)blockIdx.x - 2) * 64 + tid);
-  }
+  finals_plain_body(a, sum_blocks, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void finals_tail_kernel(FinalsArgs a, int sum_blocks, NvfStepTail t, TailRanges rg) {

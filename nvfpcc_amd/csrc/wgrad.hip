@@ -1378,6 +1378,42 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_finals_tail(WgReduceMulti r
   else wgrad_reduce_multi_body(r, bid - f_blocks, sm);
 }
 
+// ... and without the optimiser (data-parallel steps): the slab reduction with its addends + nvf_finals_flush in one launch
+__global__ __launch_bounds__(1024) void wgrad_reduce_finals(WgReduceMulti r, int f_blocks, FinalsArgs a, int sum_blocks) {
+  __shared__ float sm[16][64];
+  const int bid = blockIdx.x;
+  if (bid < f_blocks) finals_plain_body(a, sum_blocks, bid);
+  else wgrad_reduce_multi_body(r, bid - f_blocks, sm);
+}
+
+extern "C" int nvf_wgrad_reduce_finals(const float* const* slabs, float* const* dws, const int* nslabs,
+                                       const int* jtotals, int n, const float* const* addends, NvfStepCtx* ctx,
+                                       void* stream) {
+  if (!slabs || !dws || !nslabs || !jtotals || n <= 0 || n > 16 || !nvf_ctx_ok(ctx)) return NVF_EINVAL;
+  WgReduceMulti r{};
+  int base = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (nslabs[i] == 0) continue;
+    if (!slabs[i] || !dws[i] || nslabs[i] < 0 || jtotals[i] <= 0) return NVF_EINVAL;
+    r.slabs[m] = slabs[i]; r.dw[m] = dws[i]; r.nslab[m] = nslabs[i]; r.jtotal[m] = jtotals[i];
+    r.add[m] = addends ? addends[i] : nullptr;
+    r.blk_base[m] = base;
+    base += (jtotals[i] + 63) / 64;
+    ++m;
+  }
+  r.blk_base[m] = base;
+  r.n = m;
+  const FinalsArgs a = ctx->args;
+  ctx->args = FinalsArgs{};
+  ctx->deferring = 0;
+  if (a.has_f && a.f_nterm > 3) return NVF_EINVAL;
+  const int sum_blocks = finals_sum_blocks(a);
+  const int f_blocks = 2 + sum_blocks + (a.has_m ? 1 : 0);
+  wgrad_reduce_finals<<<f_blocks + base, 1024, 0, nvf_stream(stream)>>>(r, f_blocks, a, sum_blocks);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 extern "C" int nvf_wgrad_reduce_finals_tail(const float* const* slabs, float* const* dws, const int* nslabs,
                                             const int* jtotals, int n, const float* const* addends,
                                             const NvfAdamFuse* adam, NvfStepCtx* ctx, const NvfStepTail* tail,

@@ -602,7 +602,7 @@ class TrainEngine:
                                 [Ls["conv2"].gk, Ls["up2"].gk, Ls["conv1"].gk, Ls["up1"].gk, Ls["conv0"].gk],
                                 bias_outs=(Ls["conv2"].gb, Ls["conv1"].gb), heads=heads_job if self.heads3 else None,
                                 sums=(([t for t, _ in self._bias_jobs], [o for _, o in self._bias_jobs])
-                                      if (self.heads3 and heads_job is not None and defer and fuse is not None and self._rate_ready
+                                      if (self.heads3 and heads_job is not None and defer and self._rate_ready
                                           and want_w and _SUMS_IN_TRUNK5) else None),
                                 coef=((fuse["coef_dev"], self._coef_live)
                                       if (fuse is not None and fuse.get("coef_dev") is not None) else None))
@@ -635,6 +635,11 @@ class TrainEngine:
                     if fuse.get("coef_dev") is not None:     # the copy add_trunk5 staged: not the step buffer's words
                         adam.coef_dev = self._coef_live.data_ptr()
                     self._wg.finish_and_flush_tail(addends, adam, fused[0], fused[2])
+                elif sums_done and rate_head and fused is None:
+                    # data parallelism (the all-reduce and the step tail follow): the same pairing without the optimiser
+                    one_launch = True
+                    ops.weight_rate_final(job, nbits, gs, gm, ctx=ctx)
+                    self._wg.finish_and_flush(addends)
                 else:
                     if sums_done:
                         self._wg.finish_with_sums([], [], addends=addends, adam=None if fused is None else fused[1])
@@ -856,21 +861,27 @@ class GraphedTrainStep:
     the host.  dist.attach picks "graph" for RCCL and falls back to "host" in-process if the capture fails."""
 
     CAP = 4096       # rows of the device-resident schedule (longer schedules are loaded in pieces)
-    UNROLL = int(os.environ.get("NVF_GRAPH_UNROLL", "8"))   # steps per replay of the unrolled graph
+    # steps per replay of the unrolled graphs, largest first (a run of n loaded steps is replayed greedily: 57 = 3 x 16 + 8
+    # + 1 is five graph launches; 20 = 16 + 4 two)
+    UNROLL = tuple(sorted({max(int(v), 1) for v in os.environ.get("NVF_GRAPH_UNROLL", "16,8,4,2").split(",") if v.strip()},
+                          reverse=True))
 
     def __init__(self, eng, batch, q, ring=2, collective=None, unroll=None):
         self.eng, self.batch, self.q = eng, batch, q
-        self.unroll = max(int(self.UNROLL if unroll is None else unroll), 1)
+        un = self.UNROLL if unroll is None else ((unroll,) if isinstance(unroll, int) else tuple(unroll))
+        self.unrolls = tuple(u for u in sorted({max(int(v), 1) for v in un}, reverse=True) if u > 1)
+        self.unroll = self.unrolls[0] if self.unrolls else 1
         dev = eng.dev
         if collective is None:
             collective = getattr(eng, "collective_mode", None) or os.environ.get("NVF_GRAPH_COLLECTIVE", "host")
         self.collective = collective if eng.grad_hook is not None else "none"
         # the buffer the step's kernels read: [idx (B x i64) | noise step (u64) | lambda*w1/n_pts, 1/n_pts (2 x f32) |
         # Adam coefficients (2 x f32)]; sched = [cursor | unused | CAP + 1 rows of the same layout]
+        # -- one allocation [step buffer | cursor | unused | rows], so that loading a schedule is ONE host-to-device copy
         nw = self.nw = batch + 3
-        self.buf = torch.zeros(nw, dtype=torch.int64, device=dev)
-        self.sched = torch.zeros(2 + (self.CAP + 1) * nw, dtype=torch.int64, device=dev)
-        self.cursor, self.rows = self.sched[0:1], self.sched[2:]
+        self.sched = torch.zeros(nw + 2 + (self.CAP + 1) * nw, dtype=torch.int64, device=dev)
+        self.buf = self.sched[:nw]
+        self.cursor, self.rows = self.sched[nw:nw + 1], self.sched[nw + 2:]
         # staging ring: the host may load the next schedule while the copy of the previous one has not executed yet
         self.pins = [torch.zeros(self.sched.numel(), dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
         self.pin_events = [None] * len(self.pins)
@@ -911,21 +922,22 @@ class GraphedTrainStep:
             eng._step_dev, eng._g_lat_dev = None, None
 
     def _capture(self, tail):
-        """graph: one step.  graph_u: ``unroll`` steps back to back -- every step's last kernel hands the step buffer
+        """graph: one step.  graphs_u[u]: u steps back to back -- every step's last kernel hands the step buffer
         over to the next schedule row, so the bodies are identical; a graph launch costs ~9 us of idle GPU between two
-        replays (measured: 461 us period against 452 us of kernels), which the unrolled graph pays once per
-        ``unroll`` steps.  Only when the optimiser is inside the graph (not with a host-launched all-reduce)."""
+        replays (measured: 461 us period against 452 us of kernels), which an unrolled graph pays once per u steps.
+        Only when the optimiser is inside the graph (not with a host-launched all-reduce)."""
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._body(tail=tail)
         self.out1, self.last1 = self.out, self.last          # each graph writes tensors of its own
-        self.graph_u = None
-        if tail and self.unroll > 1:
-            self.graph_u = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_u):
-                for _ in range(self.unroll):
+        self.graphs_u = {}
+        for u in (self.unrolls if tail else ()):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(u):
                     self._body(tail=tail)
-            self.out_u, self.last_u = self.out, self.last     # ... the unrolled one: those of its last step
+            self.graphs_u[u] = (g, self.out, self.last)       # ... an unrolled one: those of its last step
+        self.graph_u = self.graphs_u[self.unroll][0] if self.graphs_u else None
 
     def _body(self, tail):
         eng = self.eng
@@ -963,7 +975,7 @@ class GraphedTrainStep:
         if self.pin_events[slot] is not None:
             self.pin_events[slot].synchronize()
         pin = self.pins[slot]
-        rows = pin[2:2 + (n + 1) * nw].view(n + 1, nw)
+        rows = pin[nw + 2:nw + 2 + (n + 1) * nw].view(n + 1, nw)
         f32 = rows.view(torch.float32)            # [n + 1, 2 nw]
         for k, (ids, n_pts) in enumerate(steps):
             ids = np.asarray(ids, np.int64)
@@ -977,10 +989,10 @@ class GraphedTrainStep:
             f32[k, 2 * (B + 2)], f32[k, 2 * (B + 2) + 1] = ops.adam_coefficients(eng.lr, eng.opt_step + 1 + k)
             self.pending.append(float(n_pts))
         rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
-        pin[0], pin[1] = 1, 0                     # cursor: the tail of the first step fetches row 1
-        m = 2 + (n + 1) * nw
+        pin[:nw] = rows[0]                        # the step buffer starts as row 0 ...
+        pin[nw], pin[nw + 1] = 1, 0               # ... and the cursor at 1: the tail of the first step fetches row 1
+        m = nw + 2 + (n + 1) * nw
         self.sched[:m].copy_(pin[:m], non_blocking=True)
-        self.buf.copy_(pin[2:2 + nw], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pin_events[slot] = ev
@@ -1000,20 +1012,34 @@ class GraphedTrainStep:
         return self.out
 
     def replay_all(self):
-        """Run every loaded step: ``unroll`` at a time through the unrolled graph, the rest one by one."""
-        eng, U = self.eng, self.unroll
-        while self.graph_u is not None and len(self.pending) >= U:
-            n_pts = self.pending[U - 1]
-            del self.pending[:U]
-            eng.noise_step += U
-            eng.opt_step += U
-            self.graph_u.replay()
-            self.out, self.last = self.out_u, self.last_u
-            eng.last = dict(self.last)
-            eng.last["n_pts"] = n_pts
+        """Run every loaded step: through the largest unrolled graphs that fit, the rest one by one."""
+        eng = self.eng
+        for U in self.unrolls:
+            if U not in self.graphs_u:
+                continue
+            g, out, last = self.graphs_u[U]
+            while len(self.pending) >= U:
+                n_pts = self.pending[U - 1]
+                del self.pending[:U]
+                eng.noise_step += U
+                eng.opt_step += U
+                g.replay()
+                self.out, self.last = out, last
+                eng.last = dict(self.last)
+                eng.last["n_pts"] = n_pts
         while self.pending:
             self.replay()
         return self.out
+
+    def prime(self):
+        """Replay every captured graph once (real training steps on block ids 0..): the first launch of a graph pays a
+        one-off upload that a measurement should not hold.  For benchmarks; training does not need it."""
+        B, N = self.batch, self.eng.N_leaf
+        sizes = [u for u in self.unrolls if u in self.graphs_u] + [1]
+        for u in sizes:
+            self.load_schedule([((np.arange(B) + k * B) % N, None) for k in range(u)])
+            self.replay_all()
+        torch.cuda.synchronize()
 
     def __call__(self, idx_host, n_pts=None):
         """One step with its own one-row schedule (tests; the training loop loads an epoch at a time)."""

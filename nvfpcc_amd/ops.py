@@ -739,6 +739,24 @@ class WgradBatch:
             ctypes.byref(adam), _ctx(self.ctx), ctypes.byref(tail), arr, len(ranges), _stream()),
             "nvf_wgrad_reduce_finals_tail")
 
+    def finish_and_flush(self, addends):
+        """The slab reduction (with addends) and the context's queued final passes in ONE launch, no optimiser
+        (nvf_wgrad_reduce_finals): data-parallel steps, whose all-reduce and step tail follow."""
+        import ctypes
+        jobs = self.jobs
+        n = len(jobs)
+        if not (0 < n <= 16) or self.ctx is None:
+            raise RuntimeError("finish_and_flush: 1..16 reduction jobs and a step context are required")
+        self.jobs, self.offset = [], 0
+        adds = None
+        if addends:
+            adds = (ctypes.c_void_p * n)(*[(addends[j[1]].data_ptr() if (j[1] in addends and j[2] > 0) else None)
+                                           for j in jobs])
+        check(lib().nvf_wgrad_reduce_finals(
+            (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
+            (ctypes.c_int * n)(*[j[2] for j in jobs]), (ctypes.c_int * n)(*[j[3] for j in jobs]), n, adds,
+            _ctx(self.ctx), _stream()), "nvf_wgrad_reduce_finals")
+
     def finish(self):
         import ctypes
         jobs, self.jobs, self.offset = self.jobs, [], 0
