@@ -275,6 +275,11 @@ def measure_traffic(args, label):
 
 
 def run(args):
+    # stdout carries ONE line, the JSON: libraries that print there (RCCL writes a version banner to stdout when its
+    # communicator is built) go to stderr for the life of the process; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
     from nvfpcc_amd import dist as nd, ops
@@ -579,7 +584,7 @@ def run(args):
             out["sweep"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     return 0
