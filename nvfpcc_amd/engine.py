@@ -975,22 +975,26 @@ class GraphedTrainStep:
         if self.pin_events[slot] is not None:
             self.pin_events[slot].synchronize()
         pin = self.pins[slot]
-        rows = pin[nw + 2:nw + 2 + (n + 1) * nw].view(n + 1, nw)
-        f32 = rows.view(torch.float32)            # [n + 1, 2 nw]
-        for k, (ids, n_pts) in enumerate(steps):
-            ids = np.asarray(ids, np.int64)
-            assert ids.shape[0] == B
-            if n_pts is None:
-                n_pts = float(eng.counts[ids].sum())
-            rows[k, :B] = torch.from_numpy(ids)
-            rows[k, B] = eng.noise_step + 1 + k
-            f32[k, 2 * (B + 1)] = eng.lmbda * eng.w1 / n_pts
-            f32[k, 2 * (B + 1) + 1] = 1.0 / n_pts
+        # the rows are filled as ONE NumPy array (per-element writes into a torch tensor cost ~10 us each: milliseconds per
+        # epoch of host time that a short timed region would see)
+        ids_all = np.stack([np.asarray(ids, np.int64) for ids, _ in steps])
+        assert ids_all.shape == (n, B)
+        npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
+                         for k, (_, p) in enumerate(steps)], np.float64)
+        rows = np.zeros((n + 1, nw), np.int64)
+        f32 = rows.view(np.float32)               # [n + 1, 2 nw]
+        rows[:n, :B] = ids_all
+        rows[:n, B] = eng.noise_step + 1 + np.arange(n)
+        f32[:n, 2 * (B + 1)] = (eng.lmbda * eng.w1 / npts).astype(np.float32)
+        f32[:n, 2 * (B + 1) + 1] = (1.0 / npts).astype(np.float32)
+        for k in range(n):
             f32[k, 2 * (B + 2)], f32[k, 2 * (B + 2) + 1] = ops.adam_coefficients(eng.lr, eng.opt_step + 1 + k)
-            self.pending.append(float(n_pts))
         rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
-        pin[:nw] = rows[0]                        # the step buffer starts as row 0 ...
-        pin[nw], pin[nw + 1] = 1, 0               # ... and the cursor at 1: the tail of the first step fetches row 1
+        host = pin.numpy()
+        host[nw + 2:nw + 2 + (n + 1) * nw] = rows.reshape(-1)
+        host[:nw] = rows[0]                       # the step buffer starts as row 0 ...
+        host[nw], host[nw + 1] = 1, 0             # ... and the cursor at 1: the tail of the first step fetches row 1
+        self.pending.extend(float(v) for v in npts)
         m = nw + 2 + (n + 1) * nw
         self.sched[:m].copy_(pin[:m], non_blocking=True)
         ev = torch.cuda.Event()
