@@ -12,7 +12,7 @@ f=glob.glob(f"gpurun_out/ab_{name}/**/*kernel_stats.csv",recursive=True)[0]
 tot=0; show=[]
 for r in csv.DictReader(open(f)):
     c=int(r["Calls"]); a=float(r["AverageNs"])/1000
-    if c in (45,46,47,127) and "rocclr" not in r["Name"]:
+    if c >= 70 and "rocclr" not in r["Name"] and not ("wgrad_mfma3_kernel" in r["Name"] and c >= 80):
         tot+=a
         if any(k in r["Name"] for k in ("heads3_wgrad","wgrad_reduce","finals_tail","wgrad_mfma3")): show.append(f"{r['Name'].split('(')[0][-28:]}={a:.1f}")
 print(f"{name:24s} sum {tot:7.1f}  " + "  ".join(show))
