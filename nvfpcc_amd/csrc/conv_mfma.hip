@@ -30,7 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct MDims {
   int din, hin, win, dout, hout, wout, pad, act, tiles_x, tiles_y, tiles_z;
   int dbg;   // tuning runs only (variant >= 100): 1 = no staging, 2 = no MFMAs; results are then meaningless
-             // (bit 2, NVF_A_GLOBAL=1: every wave fetches its A fragments from global memory itself)
+             // (bit 2, NVF_A_GLOBAL=1: every wave fetches its A fragments from global memory itself; bit 3: every tile
+             //  is staged as if it lay inside the tensor -- reads around it, the caller owns that memory)
   float* bias_part;   // EPI 1 only, optional: per (workgroup, wave) the 8 channel sums of the outputs it stored -- the
                       // bias gradient of the layer below (its masked output gradient is what this pass writes)
 };
@@ -201,8 +202,8 @@ struct MStage {
   __device__ __forceinline__ void issue(const float* __restrict__ xg, float* lds, unsigned lds0, int buf, int wave,
                                         int lane, int gz0, int gy0, int gx0, const MDims& d) const {
     const long plane = (long)d.hin * d.win;
-    const bool interior = gz0 >= 0 && gz0 + C::IZ <= d.din && gy0 >= 0 && gy0 + C::IY <= d.hin && gx0 >= 0 &&
-                          gx0 + C::IXW <= d.win;          // wave-uniform
+    const bool interior = (d.dbg & 8) || (gz0 >= 0 && gz0 + C::IZ <= d.din && gy0 >= 0 && gy0 + C::IY <= d.hin && gx0 >= 0 &&
+                          gx0 + C::IXW <= d.win);          // wave-uniform (dbg 8: tuning runs, see MDims)
     const float* x0 = xg + ((long)gz0 * d.hin + gy0) * d.win + gx0;   // may lie outside the tensor; only in-range
 #pragma unroll 1                                                      // elements are ever dereferenced
     for (int c = 0; c < 4; ++c) {
