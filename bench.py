@@ -335,9 +335,11 @@ def run(args):
                 step(i)
             return
         i = lo
+        W = B * world
         while i < hi:
             e = min(hi, i + graphed.CAP)
-            graphed.load_schedule([shares(k) for k in range(i, e)])
+            whole = np.asarray(order[i * W:e * W], np.int64).reshape(e - i, W)        # the steps' mini-batches
+            graphed.load_schedule((whole[:, rank::world], counts[whole].sum(axis=1).astype(np.float64)))
             graphed.replay_all()
             i = e
 

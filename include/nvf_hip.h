@@ -568,6 +568,8 @@ int nvf_wgrad_reduce_finals_tail(const float* const* slabs, float* const* dws, c
 int nvf_wgrad_reduce_finals(const float* const* slabs, float* const* dws, const int* nslabs, const int* jtotals, int n,
                             const float* const* addends, NvfStepCtx* ctx, void* stream);
 int nvf_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
+/* ... of n consecutive steps step0, step0 + 1, ...: coef_host[2 k], coef_host[2 k + 1] (the rows of a schedule) */
+int nvf_adam_coefficients_n(float lr, float beta1, float beta2, int step0, int n, float* coef_host);
 
 /* rows: dst[r,:] = src[idx[r],:]  (emb[indices], NVFPCC.py:158) and its transpose
  * dst[idx[r],:] += src[r,:] (indices unique within a call) */

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "nvf_adam_step": (I, [P, P, P, P, L, F, F, F, F, I, P]),
     "nvf_step_tail": (I, [P, P]),
     "nvf_adam_coefficients": (I, [F, F, F, I, P]),
+    "nvf_adam_coefficients_n": (I, [F, F, F, I, I, P]),
     "nvf_gather_rows": (I, [P, P, P, I, I, P]),
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
     "nvf_gather_rows_multi": (I, [P, P, P, I, P, I, P]),

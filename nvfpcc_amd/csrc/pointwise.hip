@@ -941,6 +941,16 @@ extern "C" int nvf_adam_coefficients(float lr, float beta1, float beta2, int ste
   return NVF_OK;
 }
 
+// ... for n consecutive steps step0, step0 + 1, ...: coef_host[2 k], coef_host[2 k + 1] (a schedule's rows in one call)
+extern "C" int nvf_adam_coefficients_n(float lr, float beta1, float beta2, int step0, int n, float* coef_host) {
+  if (!coef_host || step0 < 1 || n < 0) return NVF_EINVAL;
+  for (int k = 0; k < n; ++k) {
+    const int rc = nvf_adam_coefficients(lr, beta1, beta2, step0 + k, coef_host + 2 * k);
+    if (rc != NVF_OK) return rc;
+  }
+  return NVF_OK;
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
                                    float* __restrict__ dst, int rows, int width) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

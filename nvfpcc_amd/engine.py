@@ -966,9 +966,11 @@ class GraphedTrainStep:
 
     def load_schedule(self, steps):
         """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
-        CAP).  One host-to-device copy for all of them; Adam / noise counters continue from the engine's."""
+        CAP) -- or the same as two arrays (ids [n, batch] int64, n_pts [n]).  One host-to-device copy for all of them;
+        Adam / noise counters continue from the engine's."""
         eng, B, nw = self.eng, self.batch, self.nw
-        n = len(steps)
+        arrays = isinstance(steps, tuple)
+        n = len(steps[0]) if arrays else len(steps)
         assert 0 < n <= self.CAP and not self.pending
         slot = self.loads % len(self.pins)
         self.loads += 1
@@ -977,18 +979,20 @@ class GraphedTrainStep:
         pin = self.pins[slot]
         # the rows are filled as ONE NumPy array (per-element writes into a torch tensor cost ~10 us each: milliseconds per
         # epoch of host time that a short timed region would see)
-        ids_all = np.stack([np.asarray(ids, np.int64) for ids, _ in steps])
-        assert ids_all.shape == (n, B)
-        npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
-                         for k, (_, p) in enumerate(steps)], np.float64)
+        if arrays:
+            ids_all, npts = np.asarray(steps[0], np.int64), np.asarray(steps[1], np.float64)
+        else:
+            ids_all = np.stack([np.asarray(ids, np.int64) for ids, _ in steps])
+            npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
+                             for k, (_, p) in enumerate(steps)], np.float64)
+        assert ids_all.shape == (n, B) and npts.shape == (n,)
         rows = np.zeros((n + 1, nw), np.int64)
         f32 = rows.view(np.float32)               # [n + 1, 2 nw]
         rows[:n, :B] = ids_all
         rows[:n, B] = eng.noise_step + 1 + np.arange(n)
         f32[:n, 2 * (B + 1)] = (eng.lmbda * eng.w1 / npts).astype(np.float32)
         f32[:n, 2 * (B + 1) + 1] = (1.0 / npts).astype(np.float32)
-        for k in range(n):
-            f32[k, 2 * (B + 2)], f32[k, 2 * (B + 2) + 1] = ops.adam_coefficients(eng.lr, eng.opt_step + 1 + k)
+        f32[:n, 2 * (B + 2):2 * (B + 2) + 2] = ops.adam_coefficients_n(eng.lr, eng.opt_step + 1, n)
         rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
         host = pin.numpy()
         host[nw + 2:nw + 2 + (n + 1) * nw] = rows.reshape(-1)
@@ -1068,26 +1072,26 @@ class EpochDriver:
         eng, B = self.eng, self.batch
         n = len(order)
         nsteps = (n + B - 1) // B
-        plan = []
-        for s in range(nsteps):
-            ids, whole = self.nd.shard_minibatch(order, s, B, self.rank, self.world)
-            n_pts = float(eng.counts[whole].sum())
-            plan.append((ids, n_pts, self.use_graph and len(whole) == B and len(ids) > 0))
+        order = np.asarray(order, np.int64)
+        nfull = n // B
+        share = len(range(self.rank, B, self.world))     # this rank's blocks of a full mini-batch
         s = 0
-        while s < nsteps:
-            ids, n_pts, graphed = plan[s]
-            if not graphed:
-                eng.train_step(ids, q, n_pts=n_pts)
-                s += 1
-                continue
-            key = (len(ids), q)
+        if self.use_graph and nfull > 0 and share > 0:
+            # every full-size mini-batch in one go: the rows of the schedule as arrays (a Python loop over the steps costs
+            # the host ~8 us each, with the GPU idle behind the epoch's read-back)
+            whole = order[:nfull * B].reshape(nfull, B)
+            ids_all, npts = whole[:, self.rank::self.world], eng.counts[whole].sum(axis=1).astype(np.float64)
+            key = (share, q)
             g = self.graphs.get(key)
             if g is None:
-                g = self.graphs[key] = GraphedTrainStep(eng, len(ids), q)
-            e = s                                       # the run of graph-replayed steps starting here: one upload
-            while e < nsteps and plan[e][2] and len(plan[e][0]) == len(ids) and e - s < g.CAP:
-                e += 1
-            g.load_schedule([(plan[k][0], plan[k][1]) for k in range(s, e)])
-            g.replay_all()
-            s = e
+                g = self.graphs[key] = GraphedTrainStep(eng, share, q)
+            while s < nfull:
+                e = min(nfull, s + g.CAP)
+                g.load_schedule((ids_all[s:e], npts[s:e]))
+                g.replay_all()
+                s = e
+        while s < nsteps:                                # the short last batch, empty shares, or no graph at all
+            ids, whole = self.nd.shard_minibatch(order, s, B, self.rank, self.world)
+            eng.train_step(ids, q, n_pts=float(eng.counts[whole].sum()))
+            s += 1
         return nsteps

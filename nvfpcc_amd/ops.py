@@ -1002,6 +1002,15 @@ def adam_coefficients(lr, step, beta1=0.9, beta2=0.999):
     return float(c[0]), float(c[1])
 
 
+def adam_coefficients_n(lr, step0, n, beta1=0.9, beta2=0.999):
+    """adam_coefficients of steps step0 .. step0 + n - 1 as a float32 array [n, 2] (one call)."""
+    import numpy as np
+    out = np.empty((n, 2), np.float32)
+    check(lib().nvf_adam_coefficients_n(float(lr), float(beta1), float(beta2), int(step0), int(n),
+                                        out.ctypes.data), "nvf_adam_coefficients_n")
+    return out
+
+
 def step_tail(p, g, m, v, coef_dev=None, coef_host=(0.0, 0.0), loss_terms=None, lbits=None, nbits=None,
               inv_npts_dev=None, inv_npts_host=1.0, nbits_scale=1.0, counts=None, acc=None, done=None, sched=None,
               beta1=0.9, beta2=0.999, eps=1e-8):
