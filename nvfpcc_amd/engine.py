@@ -884,6 +884,7 @@ class GraphedTrainStep:
         self.cursor, self.rows = self.sched[nw:nw + 1], self.sched[nw + 2:]
         # staging ring: the host may load the next schedule while the copy of the previous one has not executed yet
         self.pins = [torch.zeros(self.sched.numel(), dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
+        self.pin_np = [p.numpy() for p in self.pins]                    # the same memory, for the NumPy row fill
         self.pin_events = [None] * len(self.pins)
         self.loads = 0
         self.pending = []            # (n_pts) of the loaded steps not replayed yet
@@ -976,7 +977,7 @@ class GraphedTrainStep:
         self.loads += 1
         if self.pin_events[slot] is not None:
             self.pin_events[slot].synchronize()
-        pin = self.pins[slot]
+        pin, host = self.pins[slot], self.pin_np[slot]
         # the rows are filled as ONE NumPy array (per-element writes into a torch tensor cost ~10 us each: milliseconds per
         # epoch of host time that a short timed region would see)
         if arrays:
@@ -986,7 +987,7 @@ class GraphedTrainStep:
             npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
                              for k, (_, p) in enumerate(steps)], np.float64)
         assert ids_all.shape == (n, B) and npts.shape == (n,)
-        rows = np.zeros((n + 1, nw), np.int64)
+        rows = host[nw + 2:nw + 2 + (n + 1) * nw].reshape(n + 1, nw)      # written in place (pinned memory)
         f32 = rows.view(np.float32)               # [n + 1, 2 nw]
         rows[:n, :B] = ids_all
         rows[:n, B] = eng.noise_step + 1 + np.arange(n)
@@ -994,16 +995,15 @@ class GraphedTrainStep:
         f32[:n, 2 * (B + 1) + 1] = (1.0 / npts).astype(np.float32)
         f32[:n, 2 * (B + 2):2 * (B + 2) + 2] = ops.adam_coefficients_n(eng.lr, eng.opt_step + 1, n)
         rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
-        host = pin.numpy()
-        host[nw + 2:nw + 2 + (n + 1) * nw] = rows.reshape(-1)
         host[:nw] = rows[0]                       # the step buffer starts as row 0 ...
         host[nw], host[nw + 1] = 1, 0             # ... and the cursor at 1: the tail of the first step fetches row 1
-        self.pending.extend(float(v) for v in npts)
+        self.pending.extend(npts.tolist())
         m = nw + 2 + (n + 1) * nw
         self.sched[:m].copy_(pin[:m], non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = self.pin_events[slot]
+        if ev is None:
+            ev = self.pin_events[slot] = torch.cuda.Event()
         ev.record()
-        self.pin_events[slot] = ev
 
     def replay(self):
         """Run the next loaded step."""
