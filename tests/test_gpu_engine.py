@@ -444,7 +444,7 @@ def test_epoch_driver_graph_and_host_paths_agree_and_nan_guard_raises(gpu):
             eng.latent_step(q)
             stats.append(eng.read_epoch_stats())
         torch.cuda.synchronize()
-        assert (not use_graph) or sorted(drv.graphs) == [(8, 1), (8, 2)]
+        assert (not use_graph) or sorted(drv.graphs) == [(5, 1), (5, 2), (8, 1), (8, 2)]
         results.append((eng.flat_p.clone(), eng.emb.clone(), np.stack(stats), eng.opt_step, eng.noise_step))
     (p_g, e_g, s_g, o_g, n_g), (p_h, e_h, s_h, o_h, n_h) = results
     assert o_g == o_h == 9 and n_g == n_h == 12
@@ -603,7 +603,7 @@ def test_engine_reproduces_the_reference_training_trajectory(use_graph, gpu, gol
         errs = np.concatenate(errs)
         print(f"epoch {epoch}: parameters max err {errs.max():.2e}, {(errs > 2e-5).sum()} of {errs.size} > 2e-5")
         assert (errs <= 2e-5).mean() >= 0.99 and errs.max() <= 2 * 4 * 1e-3, (np.sort(errs)[-5:], (errs > 2e-5).sum())
-    assert (not use_graph) or sorted(drv.graphs) == [(4, 1), (4, 2)]
+    assert (not use_graph) or sorted(drv.graphs) == [(2, 1), (2, 2), (4, 1), (4, 2)]     # 14 blocks = 3 x 4 + 2
 
 
 def test_lambda_zero_trains_and_logs(gpu):
