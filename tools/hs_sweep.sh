@@ -39,6 +39,10 @@ for r in csv.DictReader(open(f)):
     if sys.argv[2] in r["Name"] and int(r["Calls"])>=45: print("   ", r["Name"].split("(")[0][-46:], r["Calls"], round(float(r["AverageNs"])/1000,1))
 P
 }
+# edit below: one line per setting, e.g.
+#   run base X=1
+#   run caps NVF_WG_CAPS=256,128,32
+#   showk caps wgrad_mfma3
+#   run lib NVF_LIB=$GRAFT_REPO_ROOT/nvfpcc_amd/ab/lib_variant.so      (a second build: tools/ab_build.py)
 run base X=1
-for m in 1 6 8 16 32 15; do run skip$m NVF_LIB=$GRAFT_REPO_ROOT/nvfpcc_amd/ab/lib_skip$m.so; done
 run base2 X=1
