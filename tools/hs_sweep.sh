@@ -41,8 +41,4 @@ P
 }
 # edit below: one line per setting, e.g.
 #   run base X=1
-#   run caps NVF_WG_CAPS=256,128,32
-#   showk caps wgrad_mfma3
-#   run lib NVF_LIB=$GRAFT_REPO_ROOT/nvfpcc_amd/ab/lib_variant.so      (a second build: tools/ab_build.py)
-run base X=1
 run base2 X=1
