@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
   // its multiply-adds (measured by skipping it); the stride-2 body with two row blocks of eight input channels
   if (bid < m.n[3]) { if (!(NVF_WG_SKIP & 8)) wgrad_s2k5_mfma_body<WgUp1>(m.p[3], m.q[3], m.slabs[3], m.d[3], bid, lds); return; }
   bid -= m.n[3];
-  if (NVF_WG_SKIP & 8) { if (bid < u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return; }
+  if (NVF_WG_SKIP & (8 | 64)) { if (bid < u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return; }     // 64: the tile jobs only
   if ((NVF_WG_SKIP & 16) && bid >= u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return;
   // the two small transposed convolutions' gradients (VALU kernels, latency-bound on their own) fill the slots the
   // short matrix-core workgroups leave while conv2's are still running
