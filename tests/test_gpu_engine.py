@@ -656,3 +656,28 @@ def test_one_launch_tail_equals_the_separate_launches(gpu, monkeypatch):
     d = (p1 - p0).abs()
     assert float(d.max()) <= 2e-5 and float((d <= 2e-6).float().mean()) >= 0.99, (float(d.max()),)
     np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)
+
+
+def test_schedule_rows_are_the_same_from_a_list_and_from_arrays(gpu):
+    """GraphedTrainStep.load_schedule takes the steps as a list of (ids, n_pts) or as two arrays (EpochDriver / bench.py):
+    the uploaded rows -- block ids, noise step, (lambda w1 / n_pts, 1 / n_pts), Adam coefficients -- must be the same
+    words, and n_pts = None must mean "the sum of the blocks' point counts"."""
+    from nvfpcc_amd.engine import GraphedTrainStep
+    net, eng, gt, dist, emb = make("S", gpu, nblk=12)
+    g = GraphedTrainStep(eng, 4, 1, unroll=1)
+    ids = np.stack([np.arange(4) + 4 * k for k in range(3)]).astype(np.int64)
+    npts = eng.counts[ids].sum(axis=1)
+    g.load_schedule([(ids[k], None if k == 1 else float(npts[k])) for k in range(3)])
+    torch.cuda.synchronize()
+    a = g.sched[:g.nw + 2 + 4 * g.nw].cpu().clone()
+    g.pending.clear()
+    g.load_schedule((ids, npts))
+    torch.cuda.synchronize()
+    b = g.sched[:g.nw + 2 + 4 * g.nw].cpu()
+    g.pending.clear()
+    assert torch.equal(a, b)
+    rows = b[g.nw + 2:].view(4, g.nw)
+    assert torch.equal(rows[:3, :4], torch.from_numpy(ids)) and int(b[g.nw]) == 1 and torch.equal(b[:g.nw], rows[0])
+    f = rows.view(torch.float32)
+    np.testing.assert_allclose(f[:3, 2 * 5].numpy(), eng.lmbda * eng.w1 / npts, rtol=1e-7)
+    np.testing.assert_allclose(f[:3, 2 * 5 + 1].numpy(), 1.0 / npts, rtol=1e-7)
