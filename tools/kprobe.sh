@@ -26,7 +26,7 @@ for tag in ("s", "w"):
         # under the same name -- same kernel, the average stands -- and the five-gradient launch without its tail
         # workgroup as a row of its own, which is left out)
         c = int(r["Calls"])
-        probe_row = "wgrad_mfma3_kernel" in n and abs(c - nstep) > 2
+        probe_row = "wgrad_mfma3_kernel" in n and c != nstep
         if c >= nstep - 2 and "rocclr" not in n and not probe_row:
             tot += float(r["AverageNs"]) / 1000
     print(f"-- sum of the step's kernels: {tot:.1f} us")
