@@ -912,6 +912,9 @@ __global__ void step_tail_kernel(NvfStepTail a) {
     }
   }
   if (a.sched_rows) {
+    // thread 0's statistics read 1/n_pts from the step buffer (word batch + 1); the copy below overwrites that word from
+    // another wave once the per-rank batch exceeds 62: order them (is_last is uniform over the workgroup)
+    __syncthreads();
     const unsigned long long c = a.sched_cursor[0];
     const int64_t* row = a.sched_rows + c * (unsigned long long)a.sched_words;
     for (int w = threadIdx.x; w < a.sched_words; w += blockDim.x) a.sched_buf[w] = row[w];

@@ -14,9 +14,10 @@ Leaf blocks are independent given the shared decoder and every loss term is a SU
   * weight noise (q = 1) is keyed by (seed, step, layer) and so identical on all ranks; latent noise is
     keyed by (block id, step), so results do not depend on W; the step counter advances once per mini-batch and
     once per latent phase on every rank, idle or not;
-  * the all-reduce is a node of the captured step graph (engine.GraphedTrainStep); NVF_GRAPH_COLLECTIVE=host ends
-    the graph before it and launches it from the host (torch.distributed runs RCCL on a stream of its own: two event
-    waits per step), which is also the in-process fallback when the capture fails;
+  * the all-reduce is launched from the host behind the captured step graph (engine.GraphedTrainStep;
+    torch.distributed runs RCCL on a stream of its own: two event waits per step).  NVF_GRAPH_COLLECTIVE=graph opts in
+    to capturing it as a node of the step graph (and of the unrolled 16/8/4/2-step graphs): measured with a one-rank
+    group only, so it stays opt-in until a >= 2-rank RCCL run has passed with it;
   * latent phase / eval: contiguous block shards, no collective inside the step; one all-gather of the
     updated latent rows per epoch.
 """
@@ -99,13 +100,13 @@ def attach(engine, world, force=False):
     """Wire an engine for data parallelism.  ``force``: install the all-reduce hook even for one rank (exercises the
     RCCL plumbing -- communicator, capture inside the step graph -- on a single GPU).
 
-    Where the all-reduce sits (engine.GraphedTrainStep): with RCCL it is captured as a node of the step graph
-    ("graph": the hand-over between the compute stream and RCCL's stream is a graph edge; measured 0.5113 vs 0.522 ms
-    per step against the host launch, one-rank group on one MI355X); NVF_GRAPH_COLLECTIVE=host forces the host launch,
-    which is also what a failed capture falls back to, in-process.  RCCL builds its communicator on the FIRST
-    collective and doing that inside a capture invalidates it, so one eager all-reduce is issued here -- by every
-    rank, once, whether or not a rank will ever build a graph (a rank whose share of every full mini-batch is
-    empty never does)."""
+    Where the all-reduce sits (engine.GraphedTrainStep): "host" (default) ends the graph after the backward pass and
+    launches the all-reduce and the optimiser node from the host; NVF_GRAPH_COLLECTIVE=graph captures it as a node of
+    the step graph (the hand-over between the compute stream and RCCL's stream is then a graph edge; measured 0.5113 vs
+    0.522 ms per step, ONE-rank group on one MI355X -- never run with peers, hence opt-in).  RCCL builds its communicator
+    on the FIRST collective and doing that inside a capture invalidates it, so one eager all-reduce is issued here --
+    by every rank, once, whether or not a rank will ever build a graph (a rank whose share of every full mini-batch
+    is empty never does)."""
     if world > 1 or (force and dist.is_initialized()):
         engine.rate_grad_scale = 1.0 / world
         engine.grad_hook = _allreduce_any_world if force and world == 1 else allreduce_sum_
@@ -113,7 +114,7 @@ def attach(engine, world, force=False):
         if dist.get_backend() == "gloo":
             engine.collective_mode = "host"
         else:
-            engine.collective_mode = os.environ.get("NVF_GRAPH_COLLECTIVE", "graph")
+            engine.collective_mode = os.environ.get("NVF_GRAPH_COLLECTIVE", "host")
             warm = torch.zeros(8, device=engine.flat_g.device)
             dist.all_reduce(warm, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()

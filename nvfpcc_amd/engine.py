@@ -120,6 +120,8 @@ class TrainEngine:
         self._coef_live = torch.zeros(2, device=self.dev)   # the step's Adam coefficients, staged outside the step buffer
         self._rate = None         # (NvfRateJob, {gk data_ptr: its weight-rate gradient}, rate_grad_scale) of the step head
         self._rate_ready = False  # the step head of the step in flight carried the weight-rate partial pass
+        self._rate_retired = []   # outgrown weight-rate buffers stay referenced (kernels in flight)
+        self._graphs_captured = 0  # GraphedTrainStep instances that baked this engine's buffers into a graph
         self.tail_done = False    # the last backward pass applied the optimiser itself (fused tail)
         self._stem_gdn_in_finals = False
         self._tail_ranges = {}    # gradient index ranges no fused launch covers, per set of covered intervals
@@ -241,6 +243,13 @@ class TrainEngine:
         """The weight-rate term's partial pass as a job of the step head: it reads parameters only.  g is a host
         constant (lambda w2 / N, times 1 / world under data parallelism)."""
         key = (self.rate_grad_scale, self.lmbda, self.w2, self.n_points_total)
+        if self._rate is not None and self._rate[2] != key:
+            # captured step graphs hold the old buffers' addresses and the old g: a graph replayed after this point would
+            # add stale addends into retired memory -- refuse instead (dist.attach runs before any capture)
+            if self._graphs_captured:
+                raise RuntimeError("weight-rate coefficients changed after a step graph was captured "
+                                   "(attach data parallelism / set lambda before building GraphedTrainStep)")
+            self._rate_retired.append(self._rate)       # a kernel in flight may still read them
         if self._rate is None or self._rate[2] != key:
             lm = self.net.reconstructor.likelihood_model
             ks = [self.layers[n].mod.kernel for n in TRUNK]
@@ -931,6 +940,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._body(tail=tail)
+        self.eng._graphs_captured += 1
         self.out1, self.last1 = self.out, self.last          # each graph writes tensors of its own
         self.graphs_u = {}
         for u in (self.unrolls if tail else ()):
@@ -968,12 +978,25 @@ class GraphedTrainStep:
 
     def load_schedule(self, steps):
         """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
-        CAP) -- or the same as two arrays (ids [n, batch] int64, n_pts [n]).  One host-to-device copy for all of them;
-        Adam / noise counters continue from the engine's."""
+        CAP) -- or the same as two arrays (ids [n, batch] int64 ndarray, n_pts [n] ndarray).  One host-to-device copy
+        for all of them; Adam / noise counters continue from the engine's.  Nothing is touched before the input has been
+        validated."""
         eng, B, nw = self.eng, self.batch, self.nw
-        arrays = isinstance(steps, tuple)
-        n = len(steps[0]) if arrays else len(steps)
-        assert 0 < n <= self.CAP and not self.pending
+        # the arrays form is recognised by its first member being a 2-D ndarray (a tuple of two (ids, n_pts) pairs is a
+        # two-step list, not the arrays form)
+        arrays = (len(steps) == 2 and isinstance(steps[0], np.ndarray) and steps[0].ndim == 2
+                  and isinstance(steps[1], np.ndarray))
+        if arrays:
+            ids_all, npts = np.asarray(steps[0], np.int64), np.asarray(steps[1], np.float64)
+        else:
+            ids_all = np.stack([np.asarray(ids, np.int64).reshape(-1) for ids, _ in steps]) if len(steps) else np.zeros((0, B), np.int64)
+            npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
+                             for k, (_, p) in enumerate(steps)], np.float64)
+        n = ids_all.shape[0]
+        if not (0 < n <= self.CAP) or self.pending:
+            raise ValueError("load_schedule: 1..%d steps, and only after every loaded step has been replayed" % self.CAP)
+        if ids_all.shape != (n, B) or npts.shape != (n,):
+            raise ValueError("load_schedule: ids must be [n, %d] and n_pts [n]; got %s, %s" % (B, ids_all.shape, npts.shape))
         slot = self.loads % len(self.pins)
         self.loads += 1
         if self.pin_events[slot] is not None:
@@ -981,13 +1004,6 @@ class GraphedTrainStep:
         pin, host = self.pins[slot], self.pin_np[slot]
         # the rows are filled as ONE NumPy array (per-element writes into a torch tensor cost ~10 us each: milliseconds per
         # epoch of host time that a short timed region would see)
-        if arrays:
-            ids_all, npts = np.asarray(steps[0], np.int64), np.asarray(steps[1], np.float64)
-        else:
-            ids_all = np.stack([np.asarray(ids, np.int64) for ids, _ in steps])
-            npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
-                             for k, (_, p) in enumerate(steps)], np.float64)
-        assert ids_all.shape == (n, B) and npts.shape == (n,)
         rows = host[nw + 2:nw + 2 + (n + 1) * nw].reshape(n + 1, nw)      # written in place (pinned memory)
         f32 = rows.view(np.float32)               # [n + 1, 2 nw]
         rows[:n, :B] = ids_all
