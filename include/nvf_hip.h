@@ -138,6 +138,20 @@ int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const float* bias, 
                             int win, int dout, int hout, int wout, int act, int variant, float* bias_part,
                             int* bias_nparts, void* stream);
 
+/* ---- reduced-multiplication backward-data of the valid 4^3 convolutions with 8 -> 8 channels (conv2 of chanstr
+ * 8,16,8,8: the autograd backward of F.conv3d, network.py:687, NVFPCC.py:197): Winograd F(2x2, 4x4) over (y, x), direct
+ * over z on the matrix cores (conv_wino.hip) -- 2.56 x fewer multiplications than nvf_conv3d_k4_mfma's gather form.
+ * BACKWARD PASSES ONLY: fp32 error 1e-6 of max |dx| against 6e-7 for the direct form, but not a fixed fmaf chain per
+ * output, so the forward (bit-exact batch invariance) never uses it.
+ * dy [batch, 8, din^3]; dx, mask [batch, 8, (din + 3)^3]: dx = mask > 0 ? conv_full(dy, w) : 0 (the ReLU of the layer
+ * below).  wp = nvf_pack_mfma_all kind 40 (c0 = c1 = 8) of the layer's gather-form backward weights w_bwd,
+ * nvf_pack_wino_k4_floats() floats.  ppc = pairs of output planes per work unit (0: default).  bias_part (optional):
+ * *bias_nparts slabs of 8 floats, the channel sums of dx per work unit (the bias gradient of the layer below, a
+ * jtotal = 8 job of nvf_wgrad_reduce_multi).  NVF_EINVAL = no instantiation (din must be 32). */
+size_t nvf_pack_wino_k4_floats(void);
+int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
+                           float* bias_part, int* bias_nparts, void* stream);
+
 /* ---- matrix-core form of the transposed convolutions k5 s2 with 8 output channels and padding 0 (up1, up2 of
  * chanstr 8,16,8,8; F.conv_transpose3d network.py:621).  Same contract as nvf_convT3d_k5s2_fwd; the weights are
  * MFMA A-fragments: nvf_pack_convT_mfma(w_fwd [cin][125][8], cin, 8, wp), nvf_pack_convT_mfma_floats(cin) floats.

@@ -1,0 +1,324 @@
+// Backward-data of the 4x4x4 convolutions (conv2: 32^3 -> 35^3, conv1: 16^3 -> 19^3; 8 -> 8 channels) with a
+// reduced-multiplication form: Winograd F(2x2, 4x4) over (y, x), direct over z with the pair trick of conv_mfma.hip.
+// Reference site: the autograd backward of F.conv3d, utils/network.py:687 (NVFPCC.py:197).  Backward passes only:
+// the forward keeps the direct fixed-order form (bit-exact batch invariance, the 2e-6 occupancy contract).
+//
+//   out[ci, z, y, x] = sum_co sum_{tz,ty,tx} g[co, z + tz, y + ty, x + tx] w'[co][tz,ty,tx][ci]        (gather form: g is
+//   the zero-padded output gradient, w' = w_bwd, the flipped kernel).  For the 2 x 2 outputs of tile (R, X) on plane z:
+//
+//   out_tile = A^T [ sum_co sum_tz U[f][tz][co][ci] * V[f][z + tz][co][tile] ] A,     f = (fy, fx) in 5 x 5
+//   V = B^T g_tile B  (5 x 5 window at (2R, 2X)),   U = G w'_{tz} G^T  (packed once per step: nvf_pack kind 40)
+//
+// with the Cook-Toom matrices on {0, 1, -1, 2, inf}, the rational factors moved into G so that B^T is small integers:
+// 25 products per 2 x 2 outputs and tz instead of 64 -- 2.56 x fewer multiplications.  fp32 error against fp64:
+// 1.0e-6 of max |out| (direct form 6.0e-7; tools/winograd_probe.py, /tmp-probe in DESIGN section 12).
+//
+// Matrix-core mapping (v_mfma_f32_16x16x4_f32): rows (ci, s) = two output planes z = 2q + s of a PAIR q, columns = 16
+// tiles, K = four gradient channels; a plane p = 2q + zw (zw = 0..4) feeds pair q with A[(ci,s)][co] = U[f][zw - s][co][ci]
+// (zero where zw - s is no tap: 4/5 of every MFMA useful).  The B operand of lane (tile j, co kq) is V[f] of ITS tile
+// and channel, so the transformed data never leaves the registers of the lane that computed it: raw 5 x 5 windows are
+// read from the wave's own LDS image of the plane (flattened tiles: 16 consecutive tiles of the 18 x 18 tile plane; row
+// stride 50 = 18 (mod 32) makes the window reads of 16 tiles x 2 channels conflict-free 8-byte reads), transformed by
+// 90 VALU operations per (plane, channel group) and multiplied into up to three live pairs (75 MFMAs).  A wave walks a
+// chunk of pairs down z with three rotating accumulator sets (25 frequencies x 4 registers each); a finished pair goes
+// through the inverse transform in registers and leaves as 8-byte stores behind the ReLU mask.  Planes are fetched one
+// ahead with 16-byte buffer loads (8 rows per instruction) held in registers and committed to LDS after the current
+// plane's reads; no barrier after the prologue -- waves share only the A fragments (64 KB of LDS per workgroup).
+#include "nvf_common.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wn_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWinoAFloats = 2 * 5 * 25 * 64;     // [g][zw][f][lane]
+
+extern "C" size_t nvf_pack_wino_k4_floats(void) { return (size_t)kWinoAFloats; }
+
+struct WDims {
+  int batch, units, ppc;        // work units = (block, z chunk, column group); ppc pairs per chunk
+  int dbg;                      // tuning runs only (ppc >> 8): 1 no MFMAs, 2 no emit, 4 no transform, 8 no staging; results meaningless
+  float* bias_part;             // optional: per unit the 8 channel sums of what it stored
+};
+
+template <int DIN_>
+struct WCfg {
+  static constexpr int DIN = DIN_, DOUT = DIN_ + 3, TPR = (DOUT + 1) / 2, NTILE = TPR * TPR, NCG = (NTILE + 15) / 16;
+  static constexpr int NPAIR = TPR;
+  static constexpr int SPAN = TPR >= 16 ? 2 : 3;          // tile rows a group of 16 flattened tiles can touch
+  static constexpr int NR = 2 * SPAN + 3;                 // raw rows staged per plane and channel
+  static constexpr int rs_for() { int r = 2 * TPR + 4; while (r % 32 != TPR % 32) ++r; return r; }
+  static constexpr int RS = rs_for();                     // 2 RS = 2 TPR (mod 64): window address linear in the tile index
+  static constexpr int cs_for() { int c = NR * RS; while (c % 64 != 32) ++c; return c; }
+  static constexpr int CS = cs_for();                     // the second channel of a 32-lane read group: banks + 32
+  static constexpr int BUF = 8 * CS;
+  static constexpr int SEGS = DIN / 4, RPI = 64 / SEGS, NROW = 8 * NR, NLD = (NROW + RPI - 1) / RPI;
+  static_assert(RS % 2 == 0 && CS % 2 == 0, "8-byte window reads");
+  static_assert((kWinoAFloats + 4 * BUF) * 4 <= 160 * 1024, "LDS");
+};
+
+// B^T d for one axis: (2, -1, -2, 1, 0 | 0, 2, 1, -1, 0 | 0, -2, 3, -1, 0 | 0, 1, 0, -1, 0 | 0, 2, -1, -2, 1)
+__device__ __forceinline__ void wino_bt(float d0, float d1, float d2, float d3, float d4, float& v0, float& v1, float& v2,
+                                        float& v3, float& v4) {
+  const float t13 = d1 - d3, t02 = d0 - d2, t24 = d2 - d4, t23 = d2 - d3;
+  v0 = fmaf(2.f, t02, -t13);
+  v1 = fmaf(2.f, d1, t23);
+  v2 = fmaf(3.f, d2, fmaf(-2.f, d1, -d3));
+  v3 = t13;
+  v4 = fmaf(2.f, t13, -t24);
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict__ g, const float* __restrict__ wp,
+                                                        float* __restrict__ y, const float* __restrict__ mask, WDims d) {
+  constexpr int DIN = C::DIN, DOUT = C::DOUT, TPR = C::TPR, RS = C::RS, CS = C::CS, NLD = C::NLD;
+  __shared__ __attribute__((aligned(16))) float lds[kWinoAFloats + 4 * C::BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {                                             // the A fragments: every load of a thread in flight before its first store
+    constexpr int NV = kWinoAFloats / 4, NI = (NV + 255) / 256;
+    float4 tmp[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) tmp[i] = (i * 256 + tid < NV) ? ((const float4*)wp)[i * 256 + tid] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i * 256 + tid < NV) ((float4*)lds)[i * 256 + tid] = tmp[i];
+  }
+  float* raw = lds + kWinoAFloats + wave * C::BUF;
+  for (int i = lane; i < C::BUF; i += 64) raw[i] = 0.f;          // the margins stay zero for the whole launch
+  __syncthreads();
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  const int j = lane & 15, kq = lane >> 4;
+  if (unit >= d.units) {
+    if (d.bias_part && j == 0) { d.bias_part[(size_t)unit * 8 + 2 * kq] = 0.f; d.bias_part[(size_t)unit * 8 + 2 * kq + 1] = 0.f; }
+    return;
+  }
+  const int nchunk = (C::NPAIR + d.ppc - 1) / d.ppc;
+  const int cg = unit % C::NCG, zc = (unit / C::NCG) % nchunk, b = unit / (C::NCG * nchunk);
+  const int q0 = zc * d.ppc, q1 = min(q0 + d.ppc, C::NPAIR);
+  const int tl = 16 * cg + j;
+  const bool tvalid = tl < C::NTILE;
+  const int t = tvalid ? tl : C::NTILE - 1;
+  const int R = t / TPR, X = t % TPR, R0 = (16 * cg) / TPR;
+  const float* win = raw + 2 * (R - R0) * RS + 2 * X + kq * CS;
+  const float* abase = lds + lane;
+
+  // staging descriptors: load k covers rows (k RPI + lane / SEGS) of the (channel, row) list, 16 bytes per lane
+  int voff[NLD], ldst[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int ri = k * C::RPI + lane / C::SEGS, seg = lane % C::SEGS;
+    const int co = ri / C::NR, row = ri % C::NR, yd = 2 * R0 + row - 3;
+    const bool ok = ri < C::NROW && yd >= 0 && yd < DIN;
+    voff[k] = ok ? ((co * DIN * DIN + yd) * DIN + 4 * seg) * 4 : 0x7ffffff0;      // beyond the descriptor: reads 0
+    ldst[k] = ri < C::NROW ? co * CS + row * RS + 3 + 4 * seg : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(g + (size_t)b * 8 * DIN * DIN * DIN), 0, 8 * DIN * DIN * DIN * 4, 0x00020000);
+  wn_u4 st[NLD];
+  auto fetch = [&](int p) {
+    const int pz = p - 3;
+    if (d.dbg & 8) return;
+    if (pz >= 0 && pz < DIN) {
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) st[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], pz * DIN * DIN * 4, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) st[k] = wn_u4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto commit = [&]() {
+    if (d.dbg & 8) return;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      if (ldst[k] < 0) continue;
+      float* o = raw + ldst[k];                                   // odd word: 4 + 8 + 4 bytes
+      o[0] = __uint_as_float(st[k].x);
+      *(float2*)(o + 1) = float2{__uint_as_float(st[k].y), __uint_as_float(st[k].z)};
+      o[3] = __uint_as_float(st[k].w);
+    }
+  };
+
+  // two accumulator sets: pair q lives in set q & 1 (25 frequencies x 4 registers); the matrix cores' accumulators are
+  // the AGPR half of the register file, which 3 x 100 would overflow -- so the plane that completes pair s - 2 (tap 4)
+  // is multiplied into that set FIRST, the pair is emitted, and the same set then starts pair s with the same V
+  f32x4 acc[2][25];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 25; ++f) acc[s][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+
+  // V = B^T (5 x 5 window of channel 4 gi + kq) B
+  auto transform = [&](auto gi, float (&V)[25]) {
+    constexpr int G = decltype(gi)::value;
+    const float* p = win + G * 4 * CS;
+    if (d.dbg & 4) {
+#pragma unroll
+      for (int f = 0; f < 25; ++f) V[f] = 1.f + f;
+      return;
+    }
+    float e[5][5];
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+      const float2 a = *(const float2*)(p + dy * RS), bb = *(const float2*)(p + dy * RS + 2);
+      const float c = p[dy * RS + 4];
+      wino_bt(a.x, a.y, bb.x, bb.y, c, e[dy][0], e[dy][1], e[dy][2], e[dy][3], e[dy][4]);
+    }
+#pragma unroll
+    for (int fx = 0; fx < 5; ++fx)
+      wino_bt(e[0][fx], e[1][fx], e[2][fx], e[3][fx], e[4][fx], V[fx], V[5 + fx], V[10 + fx], V[15 + fx], V[20 + fx]);
+  };
+  auto mfma25 = [&](auto slot, auto zwc, auto gi, const float (&V)[25]) {
+    constexpr int S = decltype(slot)::value, ZW = decltype(zwc)::value, G = decltype(gi)::value;
+    constexpr bool FIRST = ZW == 0 && G == 0;       // the first block of a pair starts from zero: no clearing pass
+    const float* ap = abase + (G * 5 + ZW) * 25 * 64;
+    if (d.dbg & 1) return;
+    __builtin_amdgcn_sched_barrier(0);        // keeps the A reads of other (slot, tap) blocks out of this one: registers
+#pragma unroll
+    for (int f = 0; f < 25; ++f)
+      acc[S][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[f * 64], V[f], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[S][f], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- a finished pair: mask / output addressing through buffer descriptors (out-of-range lanes read 0 and store nothing:
+  // no divergent branches).  Lane part of the offset per output row yo; the (channel half, plane) part is scalar.
+  const size_t cstride = (size_t)DOUT * DOUT * DOUT;
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)(mask + (size_t)b * 8 * cstride), 0,
+                                                                         (int)(8 * cstride * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)b * 8 * cstride), 0,
+                                                                         (int)(8 * cstride * 4), 0x00020000);
+  constexpr int kOob = 0x7ffffff0;
+  const bool full = 2 * X + 1 < DOUT;                     // the tile's second x output exists
+  int vo[2], vs64[2], vs32[2];
+#pragma unroll
+  for (int yo = 0; yo < 2; ++yo) {
+    const bool ok = tvalid && 2 * R + yo < DOUT;
+    const int o = (int)(((size_t)(2 * kq) * cstride + (size_t)(2 * R + yo) * DOUT + 2 * X) * 4);
+    vo[yo] = ok ? o : kOob;
+    vs64[yo] = ok && full ? o : kOob;
+    vs32[yo] = ok && !full ? o : kOob;
+  }
+  wn_u2 mk[8];                                            // the ReLU mask of the pair being finished, fetched a plane ahead
+  auto mask_fetch = [&](int q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int so = (int)(((size_t)(r >> 1) * cstride + (size_t)(2 * q + (r & 1)) * DOUT * DOUT) * 4);
+      const bool zin = 2 * q + (r & 1) < DOUT;            // wave-uniform
+#pragma unroll
+      for (int yo = 0; yo < 2; ++yo)
+        mk[2 * r + yo] = zin ? __builtin_amdgcn_raw_buffer_load_b64(rs_m, vo[yo], so, 0) : wn_u2{0u, 0u};
+    }
+  };
+  // A^T M A per row, ReLU mask, stores, channel sums (a masked-out or out-of-range output is 0 and adds nothing)
+  auto emit = [&](auto slot, int q) {
+    constexpr int S = decltype(slot)::value;
+    if (d.dbg & 2) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float c[2][5];
+#pragma unroll
+      for (int fx = 0; fx < 5; ++fx) {
+        const float m0 = acc[S][fx][r], m1 = acc[S][5 + fx][r], m2 = acc[S][10 + fx][r], m3 = acc[S][15 + fx][r],
+                    m4 = acc[S][20 + fx][r];
+        c[0][fx] = (m0 + m1) + (m2 + m3);
+        c[1][fx] = (m1 - m2) + fmaf(2.f, m3, m4);
+      }
+      const int so = (int)(((size_t)(r >> 1) * cstride + (size_t)(2 * q + (r & 1)) * DOUT * DOUT) * 4);
+      const bool zin = 2 * q + (r & 1) < DOUT;            // wave-uniform
+#pragma unroll
+      for (int yo = 0; yo < 2; ++yo) {
+        float o0 = (c[yo][0] + c[yo][1]) + (c[yo][2] + c[yo][3]);
+        float o1 = (c[yo][1] - c[yo][2]) + fmaf(2.f, c[yo][3], c[yo][4]);
+        const wn_u2 m = mk[2 * r + yo];
+        o0 = __uint_as_float(m.x) > 0.f ? o0 : 0.f;
+        o1 = (full && __uint_as_float(m.y) > 0.f) ? o1 : 0.f;
+        if (zin) {
+          __builtin_amdgcn_raw_buffer_store_b64(wn_u2{__float_as_uint(o0), __float_as_uint(o1)}, rs_y, vs64[yo], so, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rs_y, vs32[yo], so, 0);
+          bsum[r >> 1] += o0 + o1;
+        }
+      }
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  // one pair step: planes 2s (taps 4 / 0 / 2 of pairs s-2, s, s-1) and 2s + 1 (taps 1 / 3 of pairs s, s-1); SA = set of s
+  auto step = [&](auto sa, int s) -> bool {
+    constexpr int SA = decltype(sa)::value;
+    using A = std::integral_constant<int, SA>;
+    using B = std::integral_constant<int, 1 - SA>;
+    const bool hA = s < q1, hB = s - 1 >= q0 && s - 1 < q1, hC = s - 2 >= q0;
+    const bool last = s == q1 + 1;
+    if (hC) mask_fetch(s - 2);
+    if (!last) fetch(2 * s + 1);
+    const bool pin = 2 * s - 3 >= 0 && 2 * s - 3 < DIN;
+    float V0[25], V1[25];
+    if (pin) {
+      transform(I0{}, V0);
+      transform(I1{}, V1);
+      if (hC) { mfma25(A{}, I4{}, I0{}, V0); mfma25(A{}, I4{}, I1{}, V1); }
+    }
+    if (hC) emit(A{}, s - 2);
+    if (pin) {
+      if (hA) { mfma25(A{}, I0{}, I0{}, V0); mfma25(A{}, I0{}, I1{}, V1); }
+      if (hB) { mfma25(B{}, I2{}, I0{}, V0); mfma25(B{}, I2{}, I1{}, V1); }
+    }
+    if (last) return false;
+    commit();
+    fetch(2 * s + 2);
+    if (2 * s + 1 - 3 >= 0 && 2 * s + 1 - 3 < DIN) {
+      transform(I0{}, V0);
+      if (hA) mfma25(A{}, I1{}, I0{}, V0);
+      if (hB) mfma25(B{}, I3{}, I0{}, V0);
+      transform(I1{}, V1);
+      if (hA) mfma25(A{}, I1{}, I1{}, V1);
+      if (hB) mfma25(B{}, I3{}, I1{}, V1);
+    }
+    commit();
+    return true;
+  };
+  fetch(2 * q0);
+  commit();
+  int s = q0;                                         // q0 is even (ppc is): the set of pair q is q & 1
+#pragma unroll 1
+  for (;;) {
+    if (!step(I0{}, s++)) break;
+    if (!step(I1{}, s++)) break;
+  }
+  if (d.bias_part) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v = bsum[h];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (j == 0) d.bias_part[(size_t)unit * 8 + 2 * kq + h] = v;
+    }
+  }
+}
+
+// dx[b, ci, :] = relu-mask( sum_co conv_full(dy[b, co], w) ): backward-data of a valid 4^3 convolution with 8 -> 8 channels
+// through the ReLU of the layer below.  dy [batch, 8, din^3] (din = 32 or 16), dx / mask [batch, 8, (din + 3)^3];
+// wp = nvf_pack_mfma_all kind 40 of the layer's w_bwd (nvf_pack_wino_k4_floats() floats).  bias_part (optional):
+// *bias_nparts slabs of 8 channel sums of dx (the bias gradient of the layer below).  ppc: pairs of output planes per
+// work unit (0 = default).  NVF_EINVAL for shapes without an instantiation.
+extern "C" int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din,
+                                      int ppc, float* bias_part, int* bias_nparts, void* stream) {
+  if (!dy || !wp || !dx || !mask || batch <= 0 || (bias_part && !bias_nparts)) return NVF_EINVAL;
+  if (din != 32) return NVF_EINVAL;
+  using C = WCfg<32>;
+  const int dbg = ppc >> 8;
+  ppc &= 255;
+  if (ppc <= 0) ppc = 6;
+  if (ppc & 1) return NVF_EINVAL;       // chunks start at even pairs (two alternating accumulator sets)
+  const int nchunk = (C::NPAIR + ppc - 1) / ppc;
+  WDims d{batch, batch * nchunk * C::NCG, ppc, dbg, bias_part};
+  const int grid = (d.units + 3) / 4;
+  if (bias_nparts) *bias_nparts = grid * 4;
+  conv_k4_wino_bwd<C><<<grid, 256, 0, nvf_stream(stream)>>>(dy, wp, dx, mask, d);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}

@@ -51,6 +51,24 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       const int jx = f % (3 - ex), jy = (f / (3 - ex)) % (3 - ey), jz = f / ((3 - ex) * (3 - ey));
       const int cout = m.c1[job], g4 = g % (m.c0[job] / 4), cg = g / (m.c0[job] / 4);
       v = src(job, ((4 * g4 + k) * 125 + ((ez + 2 * jz) * 5 + ey + 2 * jy) * 5 + ex + 2 * jx) * cout + cg * 16 + i);
+    } else if (kind == 40) {                         // Winograd (y, x) backward-data of a 4^3 conv: [g][zw][f][lane]
+      // U = G w' G^T of the gather-form kernel slice kz = zw - s, G = Cook-Toom F(2, 4) on {0, 1, -1, 2, inf} with the
+      // rational factors of B^T folded in (rows / 2, / 2, / 6, / -6, 1): conv_wino.hip
+      const int f = r % 25; r /= 25;
+      const int zw = r % 5, g = r / 5;
+      const int cog = i >> 1, s = i & 1, ci = 4 * g + k, kz = zw - s, fy = f / 5, fx = f % 5;
+      if (kz >= 0 && kz < 4) {
+        const float G[5][4] = {{0.5f, 0.f, 0.f, 0.f},
+                               {0.5f, 0.5f, 0.5f, 0.5f},
+                               {1.f / 6.f, -1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
+                               {-1.f / 6.f, -2.f / 6.f, -4.f / 6.f, -8.f / 6.f},
+                               {0.f, 0.f, 0.f, 1.f}};
+        for (int ky = 0; ky < 4; ++ky) {
+          float row = 0.f;
+          for (int kx = 0; kx < 4; ++kx) row = fmaf(G[fx][kx], src(job, (ci * 64 + (kz * 4 + ky) * 4 + kx) * 8 + cog), row);
+          v = fmaf(G[fy][ky], row, v);
+        }
+      }
     } else if (kind == 30 || kind == 31) {           // 16-row gather convolution (conv16_mfma.hip): [cog][g][tap][lane]
       const int k3 = kind == 30 ? 64 : 125, cin = m.c0[job], cout = m.c1[job];
       const int tap = r % k3; r /= k3;
@@ -70,7 +88,7 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
 }
 
 // kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
-// 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout).
+// 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout); 40 = Winograd backward-data of a 4^3 conv (c0 = c1 = 8; conv_wino.hip).
 // Fills m (sources optional: the step head derives them).
 static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
                                  const int* c1s, int n, PackJobs& m) {
@@ -80,6 +98,7 @@ static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, c
     m.src[j] = srcs ? srcs[j] : nullptr; m.dst[j] = dsts[j]; m.kind[j] = kinds[j]; m.c0[j] = c0s[j]; m.c1[j] = c1s[j];
     if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
     else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
+    else if (kinds[j] == 40 && c0s[j] == 8 && c1s[j] == 8) m.total[j] = 2 * 5 * 25 * 64;
     else if (kinds[j] == 11 && c1s[j] > 0 && c1s[j] % 16 == 0) m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * 125 * 64;
     else if (kinds[j] == 20 && (c1s[j] == 8 || c1s[j] == 16)) m.total[j] = (c0s[j] / 4) * 25 * (c1s[j] == 8 ? 7 : 5) * 64;
     else if ((kinds[j] == 30 || kinds[j] == 31) && c1s[j] > 0 && (c1s[j] % 16 == 0 || c1s[j] == 8))

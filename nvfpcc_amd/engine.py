@@ -96,6 +96,13 @@ class TrainEngine:
                     else emb.detach().to(self.dev).float().contiguous().clone())
         self.emb_m = torch.zeros_like(self.emb)
         self.emb_v = torch.zeros_like(self.emb)
+        # Decoder classes ("Decoder configurations"): the two of BASELINE.json have matrix-core / fused
+        # launches instantiated for their shapes; ANY other --chanstr runs every layer on the shape-generic kernels
+        # (conv3d_gather, convT3d_k5s2_fwd, wgrad_tiled; per-layer stem, heads and gradients) -- same results, not tuned
+        chans = tuple(net.reconstructor.channels)
+        self.narrow = chans == (8, 16, 8, 8)
+        self.wide = chans == (16, 32, 16, 16)
+        self.generic = not (self.narrow or self.wide)
         self._flatten_parameters()
         self._build_layers()
         self.last = {}
@@ -108,8 +115,7 @@ class TrainEngine:
         # shortens the step (0.828 ms either way) -- every kernel fills the chip on its own -- so the default is
         # one stream; NVF_OVERLAP=1 turns the two-stream schedule back on.
         self.allow_overlap = os.environ.get("NVF_OVERLAP", "0") == "1"
-        self.fused_stem = (tuple(net.reconstructor.channels[:2]) in ((8, 16), (16, 32))
-                           and net.entropy_coder.sigma.shape[1] <= 8 and _STEM)
+        self.fused_stem = ((self.narrow or self.wide) and net.entropy_coder.sigma.shape[1] <= 8 and _STEM)
         self.fused_latent_stem = True      # latent generator + quantiser ride in the stem's forward launch
         self.overlap = True
         self._g_lat_dev = None    # lambda * w1 / n_pts
@@ -128,8 +134,7 @@ class TrainEngine:
         self.collective_mode = None   # "graph" / "host": where GraphedTrainStep puts the all-reduce (dist.attach)
         # the three classifier heads go through the one-launch kernels (instantiated for the two decoders of BASELINE.json);
         # the one-launch trunk weight gradients exist for the narrow decoder only
-        self.narrow = tuple(net.reconstructor.channels) == (8, 16, 8, 8)
-        self.heads3 = self.narrow or tuple(net.reconstructor.channels) == (16, 32, 16, 16)
+        self.heads3 = self.narrow or self.wide
 
     # ------------------------------------------------------------------ parameters
     def _flatten_parameters(self):
@@ -177,13 +182,13 @@ class TrainEngine:
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
             L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = None
             L.bwd_pair, L.bwd_max_batch = 2, 0
-            if L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
+            if self.narrow and L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
                 # stride-2 gather convolution with cin output channels)
                 L.wp_t = torch.empty(int(lib().nvf_pack_convT_mfma_floats(L.cin)), device=self.dev)
                 if L.cin in (8, 16):
                     L.wp_s = torch.empty(int(lib().nvf_pack_s2k5_mfma_floats(L.cout, L.cin)), device=self.dev)
-            if L.k == 4 and L.cin % 4 == 0 and L.cout == 8 and L.cin == 8 and L.pad == 0:
+            if self.narrow and L.k == 4 and L.cin % 4 == 0 and L.cout == 8 and L.cin == 8 and L.pad == 0:
                 # matrix-core form of the 4^3 convolutions: MFMA A-fragments, re-packed after every weight preparation
                 L.wp_f = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cin, 0)), device=self.dev)
                 if name in MFMA_BWD:
@@ -193,17 +198,17 @@ class TrainEngine:
                     L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, L.bwd_pair)), device=self.dev)
             # wide decoder (16 / 32 channels): the output channels are the MFMA rows (conv16_mfma.hip) -- conv1 / conv2
             # forward and backward-data, and the backward-data of up2 / up1 (stride-2 gather with cin output channels)
-            if _G16 and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0 and name in ("conv1", "conv2"):
+            if _G16 and self.wide and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0 and name in ("conv1", "conv2"):
                 L.wp_gf = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
-            if _G16 and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
+            if _G16 and self.wide and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
-            if _G16 and L.k == 5 and (name, L.cin, L.cout, L.pad) in (("up1", 32, 16, 0), ("up2", 16, 16, 0),
+            if _G16 and self.wide and L.k == 5 and (name, L.cin, L.cout, L.pad) in (("up1", 32, 16, 0), ("up2", 16, 16, 0),
                                                                       ("conv0", 16, 32, 2), ("up0", 8, 16, 2)):
                 L.wp_t16 = torch.empty(int(lib().nvf_pack_convT16_mfma_floats(L.cin, L.cout)), device=self.dev)
-            if _G16 and name == "up0" and L.cin == 8 and L.cout == 16 and L.pad == 2:     # 16 -> 8 channels, rows 8..15 zero
+            if _G16 and self.wide and name == "up0" and L.cin == 8 and L.cout == 16 and L.pad == 2:     # 16 -> 8 channels, rows 8..15 zero
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 8, 5)), device=self.dev)
-            if _G16 and name == "conv0" and L.cin == 16 and L.cout == 32 and L.pad == 2:
+            if _G16 and self.wide and name == "conv0" and L.cin == 16 and L.cout == 32 and L.pad == 2:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(32, 16, 5)), device=self.dev)
             self.layers[name] = L
             t = table[i]

@@ -230,6 +230,32 @@ def conv3d_k4_mfma(x, wp, bias, pad, pair_axis, act=ACT_NONE, addend=None, mask=
     return y
 
 
+def pack_wino_k4(w_bwd):
+    """A fragments of nvf_conv3d_k4_wino_bwd from a gather-form backward weight [8][64][8] (one pack_mfma_all job)."""
+    wp = torch.empty(int(lib().nvf_pack_wino_k4_floats()), device=w_bwd.device)
+    pack_mfma_all([(w_bwd, wp, 40, 8, 8)])
+    return wp
+
+
+def conv3d_k4_wino_bwd(dy, wp, mask, out=None, bias_part=None, ppc=0):
+    """Backward-data of a valid 4^3 convolution (8 -> 8 channels) through the ReLU mask of the layer below, in the
+    Winograd (y, x) form: dx = mask > 0 ? conv_full(dy, w) : 0.  ``bias_part``: device address of the slabs that receive
+    the channel sums of dx per work unit; returns (dx, number of 8-float slabs) then."""
+    import ctypes
+    _f32(dy, wp, mask)
+    B, c, di = dy.shape[0], dy.shape[1], dy.shape[2]
+    shape = (B, 8, di + 3, di + 3, di + 3)
+    if c != 8 or tuple(mask.shape) != shape:
+        raise RuntimeError("conv3d_k4_wino_bwd: dy [B,8,n^3], mask [B,8,(n+3)^3]")
+    dx = out if out is not None else torch.empty(shape, device=dy.device)
+    nparts = ctypes.c_int(0)
+    check(lib().nvf_conv3d_k4_wino_bwd(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(mask), B, di, int(ppc),
+                                       None if bias_part is None else int(bias_part),
+                                       ctypes.byref(nparts) if bias_part is not None else None, _stream()),
+          "nvf_conv3d_k4_wino_bwd")
+    return dx if bias_part is None else (dx, nparts.value)
+
+
 _MFMA_VARIANT = int(os.environ.get("NVF_MFMA_VARIANT", "0"))
 # slabs (= workgroups) of the big head's weight gradient: 512 (matrix-core kernel inside the five-gradient launch:
 # 447.7 us of step kernels against 449.6 with 256 and 450.4 with 1024); the VALU kernels did best with 256

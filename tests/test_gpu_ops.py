@@ -953,3 +953,37 @@ def test_threshold_points_match_nonzero(ops):
         ref = nz[:, 1:] + origins[nz[:, 0]].long()
         assert torch.equal(pts.cpu().long(), ref)
         assert torch.equal(counts.cpu().long(), (p[:, 0] > thh).flatten(1).sum(1))
+
+
+@pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (2, 2), (3, 18)])
+def test_conv3d_k4_wino_backward_data(ops, B, ppc):
+    """conv2's backward-data in the reduced-multiplication form (conv_wino.hip: Winograd F(2x2, 4x4) over (y, x), direct
+    over z on the matrix cores) against torch's autograd of F.conv3d on the CPU, through the ReLU mask of the layer below,
+    at batches 1, 5 and 16 and with other chunkings of the z pairs; the channel sums it leaves (up2's bias gradient)
+    against the sums of what it wrote.  Tolerance: 1e-5 of max |dx| (measured 1e-6; the direct MFMA form is held to the
+    same figure above)."""
+    g = gen(4400 + B)
+    x = torch.randn(B, 8, 35, 35, 35, generator=g)
+    w = torch.round(torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08 * 16) / 16 + 0.02 * torch.randn(8, 8, 4, 4, 4, generator=g)
+    x.requires_grad_(True)
+    y_ref = F.conv3d(x, w)
+    gy = torch.randn(y_ref.shape, generator=g) * (torch.rand(y_ref.shape, generator=g) < 0.6)
+    y_ref.backward(gy)
+    mask = torch.randn(x.shape, generator=g)
+    _, wb = ops.pack_conv_weight(dev(w))
+    wp = ops.pack_wino_k4(wb)
+    dx = ops.conv3d_k4_wino_bwd(dev(gy), wp, dev(mask), ppc=ppc)
+    ref = x.grad * (mask > 0)
+    assert rel_err(dx, ref) < 1e-5, rel_err(dx, ref)
+    assert torch.equal(dx.cpu() == 0, (ref == 0) | (dx.cpu() == 0)) and bool(((dx.cpu() == 0) >= (mask <= 0)).all())
+    # channel sums per work unit: slabs of 8 floats
+    slabs = torch.full((4096 * 8,), float("nan"), device=dx.device)
+    dx2, n = ops.conv3d_k4_wino_bwd(dev(gy), wp, dev(mask), ppc=ppc, bias_part=slabs.data_ptr())
+    assert torch.equal(dx2, dx) and 0 < n <= 4096
+    sums = slabs[:8 * n].view(n, 8).double().sum(0).cpu()
+    want = dx.double().sum(dim=(0, 2, 3, 4)).cpu()
+    assert float((sums - want).abs().max()) < 1e-4 * float(want.abs().max() + dx.abs().max().cpu() * 100)
+    # the direct matrix-core form agrees (same contract, different arithmetic)
+    wpbx = ops.pack_mfma_k4(wb, 8, 0)
+    dx_direct = ops.conv3d_k4_mfma(dev(gy), wpbx, None, 3, 0, ops.ACT_NONE, mask=dev(mask))
+    assert rel_err(dx, dx_direct.cpu()) < 1e-5

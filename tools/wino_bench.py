@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""A/B of conv2's backward-data at the bench batch: the direct matrix-core form (conv_k4_mfma, flattened x-pair) against
+the Winograd (y, x) form (conv_wino.hip).  HIP events around `reps` back-to-back launches, L2-cold-ish inputs rotated.
+
+    python tools/wino_bench.py --batch 16 --ppc 6,2,18
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nvfpcc_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--ppc", default="6")
+    a = ap.parse_args()
+    B = a.batch
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(1)
+    w = (torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08).to(dev)
+    gy = (torch.randn(B, 8, 32, 32, 32, generator=g) * (torch.rand(B, 8, 32, 32, 32, generator=g) < 0.6)).to(dev)
+    mask = torch.randn(B, 8, 35, 35, 35, generator=g).to(dev)
+    _, wb = ops.pack_conv_weight(w)
+    wp_d, wp_w = ops.pack_mfma_k4(wb, 8, 0), ops.pack_wino_k4(wb)
+    slabs = torch.zeros(4096 * 8, device=dev)
+    out = torch.empty(B, 8, 35, 35, 35, device=dev)
+    macs = B * 8 * 8 * 64 * 32 ** 3
+    d = ops.conv3d_k4_mfma(gy, wp_d, None, 3, 0, ops.ACT_NONE, mask=mask)
+    us = timeit(lambda: ops.conv3d_k4_mfma(gy, wp_d, None, 3, 0, ops.ACT_NONE, mask=mask, out=out, bias_part=slabs.data_ptr()), a.reps)
+    print(f"direct  (conv_k4_mfma flat x-pair): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic")
+    for ppc in [int(v) for v in a.ppc.split(",")]:
+        wv = ops.conv3d_k4_wino_bwd(gy, wp_w, mask, ppc=ppc)
+        err = float((wv - d).abs().max() / d.abs().max()) if ppc < 256 else float("nan")
+        us = timeit(lambda: ops.conv3d_k4_wino_bwd(gy, wp_w, mask, out=out, bias_part=slabs.data_ptr(), ppc=ppc), a.reps)
+        print(f"winograd (conv_k4_wino_bwd, ppc {ppc & 255:2d} dbg {ppc >> 8:2d}): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic   max|d| / max = {err:.2e}")
+
+
+if __name__ == "__main__":
+    main()
