@@ -116,16 +116,16 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(g + (size_t)b * 8 * DIN * DIN * DIN), 0, 8 * DIN * DIN * DIN * 4, 0x00020000);
   wn_u4 st[NLD];
+  // (unconditional loads: a plane outside the tensor takes the out-of-range offset in every lane and reads zeros -- a
+  // branch here makes the loaded registers a phi, which the compiler resolves with a wait right behind the loads; the
+  // plane offset is forced into an SGPR or every load becomes a waterfall loop)
   auto fetch = [&](int p) {
     const int pz = p - 3;
     if (d.dbg & 8) return;
-    if (pz >= 0 && pz < DIN) {
+    const bool pin = pz >= 0 && pz < DIN;
+    const int so = __builtin_amdgcn_readfirstlane(pin ? pz * DIN * DIN * 4 : 0);
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) st[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], pz * DIN * DIN * 4, 0);
-    } else {
-#pragma unroll
-      for (int k = 0; k < NLD; ++k) st[k] = wn_u4{0u, 0u, 0u, 0u};
-    }
+    for (int k = 0; k < NLD; ++k) st[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pin ? voff[k] : 0x7ffffff0, so, 0);
   };
   auto commit = [&]() {
     if (d.dbg & 8) return;
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   auto mask_fetch = [&](int q) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int so = (int)(((size_t)(r >> 1) * cstride + (size_t)(2 * q + (r & 1)) * DOUT * DOUT) * 4);
       const bool zin = 2 * q + (r & 1) < DOUT;            // wave-uniform
+      const int so = __builtin_amdgcn_readfirstlane(
+          zin ? (int)(((size_t)(r >> 1) * cstride + (size_t)(2 * q + (r & 1)) * DOUT * DOUT) * 4) : 0);
 #pragma unroll
-      for (int yo = 0; yo < 2; ++yo)
-        mk[2 * r + yo] = zin ? __builtin_amdgcn_raw_buffer_load_b64(rs_m, vo[yo], so, 0) : wn_u2{0u, 0u};
+      for (int yo = 0; yo < 2; ++yo) mk[2 * r + yo] = __builtin_amdgcn_raw_buffer_load_b64(rs_m, zin ? vo[yo] : kOob, so, 0);
     }
   };
   // A^T M A per row, ReLU mask, stores, channel sums (a masked-out or out-of-range output is 0 and adds nothing)
@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
         c[0][fx] = (m0 + m1) + (m2 + m3);
         c[1][fx] = (m1 - m2) + fmaf(2.f, m3, m4);
       }
-      const int so = (int)(((size_t)(r >> 1) * cstride + (size_t)(2 * q + (r & 1)) * DOUT * DOUT) * 4);
       const bool zin = 2 * q + (r & 1) < DOUT;            // wave-uniform
+      const int so = __builtin_amdgcn_readfirstlane(
+          zin ? (int)(((size_t)(r >> 1) * cstride + (size_t)(2 * q + (r & 1)) * DOUT * DOUT) * 4) : 0);
 #pragma unroll
       for (int yo = 0; yo < 2; ++yo) {
         float o0 = (c[yo][0] + c[yo][1]) + (c[yo][2] + c[yo][3]);
@@ -232,11 +233,10 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
         const wn_u2 m = mk[2 * r + yo];
         o0 = __uint_as_float(m.x) > 0.f ? o0 : 0.f;
         o1 = (full && __uint_as_float(m.y) > 0.f) ? o1 : 0.f;
-        if (zin) {
-          __builtin_amdgcn_raw_buffer_store_b64(wn_u2{__float_as_uint(o0), __float_as_uint(o1)}, rs_y, vs64[yo], so, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rs_y, vs32[yo], so, 0);
-          bsum[r >> 1] += o0 + o1;
-        }
+        // (a plane beyond the tensor: its mask was read as zeros, so o0 = o1 = 0; the stores take the out-of-range offset)
+        __builtin_amdgcn_raw_buffer_store_b64(wn_u2{__float_as_uint(o0), __float_as_uint(o1)}, rs_y, zin ? vs64[yo] : kOob, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rs_y, zin ? vs32[yo] : kOob, so, 0);
+        bsum[r >> 1] += o0 + o1;
       }
     }
   };
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   int s = q0;                                         // q0 is even (ppc is): the set of pair q is q & 1
 #pragma unroll 1
   for (;;) {
+    s = __builtin_amdgcn_readfirstlane(s);
     if (!step(I0{}, s++)) break;
     if (!step(I1{}, s++)) break;
   }

@@ -32,6 +32,7 @@ _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wi
 _VAR = {k: int(os.environ.get("NVF_VAR_" + k, "0")) for k in ("UP1F", "UP2F", "UP1B", "UP2B", "C1F", "C1B")}   # tile variants
 _CONV2_FWD_VAR = int(os.environ.get("NVF_CONV2_FWD_VAR", "0"))   # tile-shape variants of conv_k4_mfma (tuning)
 _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
+_WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's backward-data in the Winograd (y, x) form (conv_wino.hip)
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
@@ -62,7 +63,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "wp_t16", "bwd_pair", "bwd_max_batch")
+                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "wp_t16", "wp_w", "bwd_pair", "bwd_max_batch")
 
 
 class TrainEngine:
@@ -180,7 +181,7 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = None
+            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = L.wp_w = None
             L.bwd_pair, L.bwd_max_batch = 2, 0
             if self.narrow and L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
@@ -196,6 +197,10 @@ class TrainEngine:
                     # flattened 18-cell rows (conv2; faster than the VALU kernel only while the batch is small)
                     L.bwd_pair, L.bwd_max_batch = MFMA_BWD[name]
                     L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, L.bwd_pair)), device=self.dev)
+                if name == "conv2" and _WINO:
+                    # backward-data in the reduced-multiplication form (Winograd over (y, x), z pairs on the matrix
+                    # cores: 52 us against 85 for the direct form at batch 16); backward passes only
+                    L.wp_w = torch.empty(int(lib().nvf_pack_wino_k4_floats()), device=self.dev)
             # wide decoder (16 / 32 channels): the output channels are the MFMA rows (conv16_mfma.hip) -- conv1 / conv2
             # forward and backward-data, and the backward-data of up2 / up1 (stride-2 gather with cin output channels)
             if _G16 and self.wide and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0 and name in ("conv1", "conv2"):
@@ -226,6 +231,8 @@ class TrainEngine:
         meta = [(row[nm], 0) for nm, L in named if L.wp_f is not None]
         jobs += [(L.w_bwd, L.wp_b, L.bwd_pair, L.cout, 8) for _, L in named if L.wp_b is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_b is not None]
+        jobs += [(L.w_bwd, L.wp_w, 40, L.cout, 8) for _, L in named if L.wp_w is not None]
+        meta += [(row[nm], 1) for nm, L in named if L.wp_w is not None]
         jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for _, L in named if L.wp_t is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_t is not None]
         jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for _, L in named if L.wp_s is not None]
@@ -411,6 +418,15 @@ class TrainEngine:
             dx = ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 4, 1, 3, tuple(x_in.shape[2:]), addend=addend,
                                      mask=mask)
             return dx if bias_out is None else (dx, False)
+        if L.wp_w is not None and mask is not None and addend is None and g_out.shape[-1] == 32:
+            if bias_out is not None:
+                base = self._wg.reserve(4096 * 8 * 4) if g_out.shape[0] <= 64 else None
+                if base is not None:
+                    dx, nparts = ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask, bias_part=base)
+                    self._wg.add_job(base, bias_out, nparts, 8)
+                    return dx, True
+                return ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask), False
+            return ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask)
         if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
             var = _CONV2_BWD_VAR if (g_out.shape[-1] == 32 and _CONV2_BWD_VAR) else None
             if g_out.shape[-1] == 16 and _VAR["C1B"]:

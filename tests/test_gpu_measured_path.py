@@ -169,10 +169,21 @@ def test_other_channel_strings_match_the_oracle_or_refuse(ch, channels, gpu):
     # tensor's maximum (the primary criterion, 2e-4, holds with a factor 10 to spare) is 1.3 % of the small ones
     for q in (2, 1):
         _check_against_oracle(eng, net, P, gt, dist, emb, [4, 1, 3, 0], q, rtol=5e-2)
+    # latent gradient: against the oracle in FLOAT64.  The rate term's gradient is a ratio of differences of Gaussian CDFs
+    # (network.py:145-161); where a latent sits in a tail, one ulp of erf is a %-level change of it, and with these
+    # perturbed parameters the fp32 ORACLE itself is off by 4e-5 (ch = 8) to 2e-3 (chanstr 8,8,8,8) of the largest entry
+    # (measured: profiles/r04_latent_grad_conditioning.md).  Allowance: 2e-4 of the largest entry, or ten times the fp32
+    # oracle's own distance from float64 where that is larger
     a, de = eng.latent_step(2, update=False)
-    _, _, _, _, de_ref = _oracle_step(P, emb, gt, dist, np.arange(6), 2, float(eng.counts.sum()), eng.noise_step,
-                                      layer_ids=_layer_ids(net))
-    grad_close(de.cpu().numpy(), de_ref.numpy(), rtol=5e-2)
+    args = (np.arange(6), 2, float(eng.counts.sum()), eng.noise_step)
+    de32 = _oracle_step(P, emb, gt, dist, *args, layer_ids=_layer_ids(net))[4].double()
+    de64 = _oracle_step({k: v.double() for k, v in P.items()}, emb.double(), gt.double(), dist.double(), *args,
+                        layer_ids=_layer_ids(net))[4]
+    scale = float(de64.abs().max())
+    cond = float((de32 - de64).abs().max()) / scale
+    err = float((de.cpu().double() - de64).abs().max()) / scale
+    print(f"latent gradient ch={ch} {channels}: HIP vs fp64 {err:.2e}, fp32 oracle vs fp64 {cond:.2e}")
+    assert err < max(2e-4, 10 * cond), (err, cond)
     # eval forward is batch-invariant bit for bit here as well (rc_enc.ply == rc_dec.ply)
     p_all = eng.eval_forward(q=2)["p2"]
     one = eng.eval_forward(lo=3, hi=4, q=2)["p2"]
