@@ -152,6 +152,16 @@ size_t nvf_pack_wino_k4_floats(void);
 int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
                            float* bias_part, int* bias_nparts, void* stream);
 
+/* ... and conv2's WEIGHT gradient in the corresponding form (wgrad_wino.h: Winograd F(4x4, 2x2) over (y, x) -- the taps
+ * are the output, 2 x 2 tiles of dy the filter -- direct over z on the matrix cores, every MFMA lane useful): the weight
+ * half of the autograd backward of F.conv3d, network.py:687.  dy [batch, 8, 32^3], x [batch, 8, 35^3] -> dw [8][8][4][4][4]
+ * (and db [8] = channel sums of dy when db is not NULL).  One launch of per-workgroup slabs + the fixed-order reduction
+ * (deterministic; fp32 error 4e-6 of max |dw| against 1e-6 for the direct form).  workspace: 512 * (4096 + 8) floats.
+ * zsplit: the z steps of a (block, tile group) are split over this many work items (1..8).  In the training step the same
+ * body runs as job 0 of nvf_wgrad_trunk5_* (NVF_WGRAD_WINO=0 selects the direct form there). */
+int nvf_wgrad_k4_wino(const float* dy, const float* x, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                      int batch, int zsplit, void* stream);
+
 /* ---- matrix-core form of the transposed convolutions k5 s2 with 8 output channels and padding 0 (up1, up2 of
  * chanstr 8,16,8,8; F.conv_transpose3d network.py:621).  Same contract as nvf_convT3d_k5s2_fwd; the weights are
  * MFMA A-fragments: nvf_pack_convT_mfma(w_fwd [cin][125][8], cin, 8, wp), nvf_pack_convT_mfma_floats(cin) floats.

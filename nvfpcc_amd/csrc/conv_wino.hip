@@ -24,7 +24,7 @@
 // through the inverse transform in registers and leaves as 8-byte stores behind the ReLU mask.  Planes are fetched one
 // ahead with 16-byte buffer loads (8 rows per instruction) held in registers and committed to LDS after the current
 // plane's reads; no barrier after the prologue -- waves share only the A fragments (64 KB of LDS per workgroup).
-#include "nvf_common.h"
+#include "wino_common.h"
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,17 +56,6 @@ struct WCfg {
   static_assert(RS % 2 == 0 && CS % 2 == 0, "8-byte window reads");
   static_assert((kWinoAFloats + 4 * BUF) * 4 <= 160 * 1024, "LDS");
 };
-
-// B^T d for one axis: (2, -1, -2, 1, 0 | 0, 2, 1, -1, 0 | 0, -2, 3, -1, 0 | 0, 1, 0, -1, 0 | 0, 2, -1, -2, 1)
-__device__ __forceinline__ void wino_bt(float d0, float d1, float d2, float d3, float d4, float& v0, float& v1, float& v2,
-                                        float& v3, float& v4) {
-  const float t13 = d1 - d3, t02 = d0 - d2, t24 = d2 - d4, t23 = d2 - d3;
-  v0 = fmaf(2.f, t02, -t13);
-  v1 = fmaf(2.f, d1, t23);
-  v2 = fmaf(3.f, d2, fmaf(-2.f, d1, -d3));
-  v3 = t13;
-  v4 = fmaf(2.f, t13, -t24);
-}
 
 template <class C>
 __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict__ g, const float* __restrict__ wp,

@@ -497,6 +497,44 @@ static int launch_wgrad_mfma(const float* g, const float* x, float* dw, float* s
   return NVF_OK;
 }
 
+// ---- the same gradient in the Winograd (y, x) form (wgrad_wino.h): 2.56 x fewer multiplications ----
+#include "wgrad_wino.h"
+using WgWino2 = WWCfg<32>;
+__global__ __launch_bounds__(256) void wgrad_k4_wino(const float* __restrict__ g, const float* __restrict__ x,
+                                                     float* __restrict__ slabs, WgDims d) {
+  __shared__ __attribute__((aligned(16))) float lds[WgWino2::LDSF > kWgEpiFloats ? WgWino2::LDSF : kWgEpiFloats];
+  wgrad_k4_wino_body<WgWino2>(g, x, slabs, d, blockIdx.x, lds, kWgRegion);
+}
+
+// walkers of the Winograd gradient: (block, group of four tiles, z split); fills d.items / items_per_wg / tiles_z
+static int wino_items(WgDims& d, int batch, int zsplit, int cap) {
+  d.tiles_z = zsplit < 1 ? 1 : zsplit;
+  d.items = batch * WgWino2::NGRP * d.tiles_z;
+  const int quads = (d.items + 3) / 4;                         // a workgroup's four waves take one walker each per round
+  int n = quads < cap ? quads : cap;
+  d.items_per_wg = (quads + n - 1) / n * 4;
+  return (d.items + d.items_per_wg - 1) / d.items_per_wg;
+}
+
+// dW [8][8][4][4][4] (and, optional, db [8] = channel sums of dy) of conv2 from dy [batch, 8, 32^3] and x [batch, 8, 35^3]
+// in the Winograd form: one launch of partial slabs + the fixed-order reduction.  workspace: 512 slabs of 4096 + 8 floats.
+extern "C" int nvf_wgrad_k4_wino(const float* dy, const float* x, float* dw, float* db, void* workspace,
+                                 size_t workspace_bytes, int batch, int zsplit, void* stream) {
+  if (!dy || !x || !dw || !workspace || batch <= 0) return NVF_EINVAL;
+  if (workspace_bytes < (size_t)kMaxSlabs * (4096 + 8) * sizeof(float)) return NVF_EWORKSPACE;
+  WgDims d{};
+  d.batch = batch; d.bc = 8;
+  const int nslab = wino_items(d, batch, zsplit, kMaxSlabs);
+  float* slabs = (float*)workspace;
+  d.bias_slab = db ? slabs + (size_t)kMaxSlabs * 4096 : nullptr;
+  hipStream_t s = nvf_stream(stream);
+  wgrad_k4_wino<<<nslab, 256, 0, s>>>(dy, x, slabs, d);
+  wgrad_reduce<<<(4096 + 63) / 64, 1024, 0, s>>>(slabs, dw, nslab, 4096, 0);
+  if (db) wgrad_reduce<<<1, 1024, 0, s>>>(d.bias_slab, db, nslab, 8, 0);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // MFMA weight gradient of the stride-2, 5^3 transposed convolution with 8 -> 8 channels (up2):
 //   dW[ci][co][kz][ky][kx] = sum_{n,i} x[ci, i] g[co, 2 i + k]

@@ -256,6 +256,21 @@ def conv3d_k4_wino_bwd(dy, wp, mask, out=None, bias_part=None, ppc=0):
     return dx if bias_part is None else (dx, nparts.value)
 
 
+def wgrad_k4_wino(dy, x, zsplit=1, want_bias=False):
+    """conv2's weight gradient [8,8,4,4,4] (and the bias gradient [8]) in the Winograd (y, x) form: one launch of slabs +
+    the fixed-order reduction."""
+    _f32(dy, x)
+    B = dy.shape[0]
+    if tuple(dy.shape[1:]) != (8, 32, 32, 32) or tuple(x.shape) != (B, 8, 35, 35, 35):
+        raise RuntimeError("wgrad_k4_wino: dy [B,8,32^3], x [B,8,35^3]")
+    dw = torch.empty(8, 8, 4, 4, 4, device=dy.device)
+    db = torch.empty(8, device=dy.device) if want_bias else None
+    ws = workspace(512 * (4096 + 8) * 4, dy.device, tag="wgrad_wino")
+    check(lib().nvf_wgrad_k4_wino(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), ws.data_ptr(), ws.numel(), B,
+                                  int(zsplit), _stream()), "nvf_wgrad_k4_wino")
+    return (dw, db) if want_bias else dw
+
+
 _MFMA_VARIANT = int(os.environ.get("NVF_MFMA_VARIANT", "0"))
 # slabs (= workgroups) of the big head's weight gradient: 512 (matrix-core kernel inside the five-gradient launch:
 # 447.7 us of step kernels against 449.6 with 256 and 450.4 with 1024); the VALU kernels did best with 256

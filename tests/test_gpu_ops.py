@@ -987,3 +987,24 @@ def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     wpbx = ops.pack_mfma_k4(wb, 8, 0)
     dx_direct = ops.conv3d_k4_mfma(dev(gy), wpbx, None, 3, 0, ops.ACT_NONE, mask=dev(mask))
     assert rel_err(dx, dx_direct.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("B,zsplit", [(1, 1), (5, 1), (16, 1), (3, 2), (2, 5)])
+def test_wgrad_k4_wino(ops, B, zsplit):
+    """conv2's weight gradient in the Winograd (y, x) form (wgrad_wino.h) against torch's autograd of F.conv3d on the CPU
+    (float64 reference), at batches 1, 5, 16 and with the z steps split over several work items; the bias gradient it leaves
+    (channel sums of dy).  Tolerance 2e-5 of max |dW| (measured 4e-6; the gradient goldens are held to 2e-4)."""
+    g = gen(4700 + B)
+    x = torch.relu(torch.randn(B, 8, 35, 35, 35, generator=g) * 0.7)
+    gy = torch.randn(B, 8, 32, 32, 32, generator=g) * (torch.rand(B, 8, 32, 32, 32, generator=g) < 0.6)
+    w = torch.zeros(8, 8, 4, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), w).backward(gy.double())
+    dw, db = ops.wgrad_k4_wino(dev(gy), dev(x), zsplit=zsplit, want_bias=True)
+    assert rel_err(dw, w.grad) < 2e-5, rel_err(dw, w.grad)
+    assert rel_err(db, gy.double().sum(dim=(0, 2, 3, 4))) < 2e-5
+    # deterministic: the same bits on a second run
+    dw2 = ops.wgrad_k4_wino(dev(gy), dev(x), zsplit=zsplit)
+    assert torch.equal(dw, dw2)
+    # the direct matrix-core form agrees
+    dw_direct = ops.wgrad(dev(gy), dev(x), 4, 1, 0, out_mode=0)
+    assert rel_err(dw, dw_direct.cpu().reshape(8, 8, 4, 4, 4)) < 2e-5

@@ -55,5 +55,29 @@ def main():
         print(f"winograd (conv_k4_wino_bwd, ppc {ppc & 255:2d} dbg {ppc >> 8:2d}): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic   max|d| / max = {err:.2e}")
 
 
+def wgrad_main(B, reps):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = torch.relu(torch.randn(B, 8, 35, 35, 35, generator=g) * 0.7).to(dev)
+    gy = (torch.randn(B, 8, 32, 32, 32, generator=g) * (torch.rand(B, 8, 32, 32, 32, generator=g) < 0.6)).to(dev)
+    macs = B * 8 * 8 * 64 * 32 ** 3
+    d = ops.wgrad(gy, x, 4, 1, 0, out_mode=0).reshape(-1)
+    us = timeit(lambda: ops.wgrad(gy, x, 4, 1, 0, out_mode=0), reps)
+    print(f"wgrad direct  (wgrad_k4_mfma + reduce): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic")
+    for zs in (1, 2, 3):
+        w = ops.wgrad_k4_wino(gy, x, zsplit=zs).reshape(-1)
+        err = float((w - d).abs().max() / d.abs().max())
+        us = timeit(lambda: ops.wgrad_k4_wino(gy, x, zsplit=zs), reps)
+        print(f"wgrad winograd (zsplit {zs}, + reduce):     {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic   max|d| / max = {err:.2e}")
+
+
 if __name__ == "__main__":
+    if "--wgrad" in sys.argv:
+        sys.argv.remove("--wgrad")
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--batch", type=int, default=16)
+        ap.add_argument("--reps", type=int, default=50)
+        a = ap.parse_args()
+        wgrad_main(a.batch, a.reps)
+        sys.exit(0)
     main()
