@@ -811,7 +811,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
     if (bid == 0) { if (!(NVF_WG_SKIP & 32)) latent_tail_body(tail, lds); return; }
     --bid;
   }
-  if (bid < m.n[0]) { if (!(NVF_WG_SKIP & 1)) wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds); return; }
+  if (bid < m.n[0]) {                  // conv2: the Winograd (y, x) form when the job says so (tiles_z = its z split)
+    if (NVF_WG_SKIP & 1) return;
+    if (m.d[0].tiles_z > 0) wgrad_k4_wino_body<WgWino2>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds, kWgRegion);
+    else wgrad_k4_mfma_body<C0>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds);
+    return;
+  }
   bid -= m.n[0];
   if (bid < m.n[1]) { if (!(NVF_WG_SKIP & 2)) wgrad_s2k5_mfma_body<T1>(m.p[1], m.q[1], m.slabs[1], m.d[1], bid, lds); return; }
   bid -= m.n[1];
@@ -911,6 +916,15 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     int n = items[j] < cap ? items[j] : cap;
     d.items_per_wg = (items[j] + n - 1) / n;
     n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
+    // conv2 in the Winograd (y, x) form (wgrad_wino.h): NVF_WGRAD_WINO=0 keeps the direct form; =z: z steps split over z
+    // work items (default 1 = 256 workgroups at batch 16: step 0.375 ms against 0.3825 with 2 and 0.3886 for the direct form)
+    static int wino = -1;
+    if (wino < 0) { const char* e = getenv("NVF_WGRAD_WINO"); wino = e ? atoi(e) : 1; if (wino > 8) wino = 8; }
+    if (j == 0 && wino > 0) {
+      static int wcap = 0;
+      if (!wcap) { const char* e = getenv("NVF_WGRAD_WINO_CAP"); wcap = e ? atoi(e) : 512; if (wcap < 1 || wcap > 512) wcap = 512; }
+      n = wino_items(d, batch, wino, wcap);
+    }
     if (bias_slabs && j != 1) d.bias_slab = bias_slabs[j];     // conv2 (job 0) and conv1 (job 2): p = dY
     m.d[j] = d; m.n[j] = n; nslabs[j] = n;
   }

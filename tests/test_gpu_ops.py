@@ -178,7 +178,10 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     wg = ops.WgradBatch(g5.device, nbytes=128 << 20)
     wg.add_mfma3([g5, y3, g3], [y4, g4, y2], outs)
     wg.finish()
-    assert torch.equal(outs[0], ops.wgrad(g5, y4, 4, 1, 0, out_mode=0))
+    # conv2's gradient runs in the Winograd (y, x) form inside the merged launches (wgrad_wino.h): another arithmetic,
+    # agreement to rounding (NVF_WGRAD_WINO=0 restores the direct form and bit-equality)
+    ref0 = ops.wgrad(g5, y4, 4, 1, 0, out_mode=0)
+    assert (outs[0] - ref0).abs().max().item() < 2e-5 * ref0.abs().max().item()
     assert torch.equal(outs[1], ops.wgrad(y3, g4, 5, 2, 0, out_mode=0))
     assert torch.equal(outs[2], ops.wgrad(g3, y2, 4, 1, 0, out_mode=0))
     # ... and so do up1 + conv0
@@ -194,7 +197,8 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     wg.add_trunk5([g5, y3, g3, y1, h0], [y4, g4, y2, g2, g1], outs5)
     wg.finish()
     for i, (got, ref) in enumerate(zip(outs5, outs + outs2)):
-        if i == 3:     # up1 runs on the matrix cores inside the five-gradient launch (another summation order)
+        if i in (0, 3):     # conv2 (Winograd form: the same arithmetic in both launches, but other work items per
+            # workgroup) and up1 (on the matrix cores inside the five-gradient launch): another summation order
             assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
         else:
             assert torch.equal(got, ref)
