@@ -147,10 +147,16 @@ int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const float* bias, 
  * below).  wp = nvf_pack_mfma_all kind 40 (c0 = c1 = 8) of the layer's gather-form backward weights w_bwd,
  * nvf_pack_wino_k4_floats() floats.  ppc = pairs of output planes per work unit (0: default).  bias_part (optional):
  * *bias_nparts slabs of 8 floats, the channel sums of dx per work unit (the bias gradient of the layer below, a
- * jtotal = 8 job of nvf_wgrad_reduce_multi).  NVF_EINVAL = no instantiation (din must be 32). */
+ * jtotal = 8 job of nvf_wgrad_reduce_multi).  NVF_EINVAL = no instantiation (din 32: conv2, 16: conv1; ppc even). */
 size_t nvf_pack_wino_k4_floats(void);
 int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
                            float* bias_part, int* bias_nparts, void* stream);
+/* The FORWARD of the same layers in the same form, y = relu(conv3d(x, w) + bias), for TRAINING steps only (NVFPCC.py:160,
+ * 234): x [batch, 8, din^3] (din 35: conv2, 19: conv1), y [batch, 8, (din - 3)^3], wp = kind 40 of the layer's w_fwd.  Its
+ * outputs differ from nvf_conv3d_k4_mfma's by fp32 rounding (1e-6 of max |y|) and are not a fixed fmaf chain per output:
+ * eval / encode / decode (NVFPCC.py:316, 516, 628), whose occupancy must be batch-invariant bit for bit, never use it. */
+int nvf_conv3d_k4_wino_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int din, int ppc,
+                           void* stream);
 
 /* ... and conv2's WEIGHT gradient in the corresponding form (wgrad_wino.h: Winograd F(4x4, 2x2) over (y, x) -- the taps
  * are the output, 2 x 2 tiles of dy the filter -- direct over z on the matrix cores, every MFMA lane useful): the weight

@@ -1,5 +1,5 @@
-// Backward-data of the 4x4x4 convolutions (conv2: 32^3 -> 35^3, conv1: 16^3 -> 19^3; 8 -> 8 channels) with a
-// reduced-multiplication form: Winograd F(2x2, 4x4) over (y, x), direct over z with the pair trick of conv_mfma.hip.
+// Backward-data (and the training-step forward) of the 4x4x4 convolutions (conv2: 32^3 <-> 35^3, conv1: 16^3 <-> 19^3;
+// 8 -> 8 channels) in a reduced-multiplication form: Winograd F(2x2, 4x4) over (y, x), direct over z with the pair trick of conv_mfma.hip.
 // Reference site: the autograd backward of F.conv3d, utils/network.py:687 (NVFPCC.py:197).  Backward passes only:
 // the forward keeps the direct fixed-order form (bit-exact batch invariance, the 2e-6 occupancy contract).
 //
@@ -41,26 +41,35 @@ struct WDims {
   float* bias_part;             // optional: per unit the 8 channel sums of what it stored
 };
 
-template <int DIN_>
+// DIN: input extent; PAD: zero padding of the gather (3: backward-data = full correlation of the output gradient, 0: the
+// forward pass); output extent DIN + 2 PAD - 3.  The kernel works in PADDED input coordinates p = input index + PAD.
+template <int DIN_, int PAD_>
 struct WCfg {
-  static constexpr int DIN = DIN_, DOUT = DIN_ + 3, TPR = (DOUT + 1) / 2, NTILE = TPR * TPR, NCG = (NTILE + 15) / 16;
-  static constexpr int NPAIR = TPR;
-  static constexpr int SPAN = TPR >= 16 ? 2 : 3;          // tile rows a group of 16 flattened tiles can touch
+  static constexpr int DIN = DIN_, PAD = PAD_, DOUT = DIN_ + 2 * PAD_ - 3, TPR = (DOUT + 1) / 2, NTILE = TPR * TPR;
+  static constexpr int NCG = (NTILE + 15) / 16, NPAIR = TPR;
+  // tile rows a group of 16 consecutive flattened tiles can touch: 16 | 16 tiles per row: 1; 8: 2; 18: 2; 10: 3
+  static constexpr int SPAN = TPR % 16 == 0 ? 1 : (16 % TPR == 0 ? 16 / TPR : (14 + TPR) / TPR + 1);
   static constexpr int NR = 2 * SPAN + 3;                 // raw rows staged per plane and channel
-  static constexpr int rs_for() { int r = 2 * TPR + 4; while (r % 32 != TPR % 32) ++r; return r; }
+  static constexpr int SEGS = (DIN + 3) / 4, RPI = 64 / SEGS, NROW = 8 * NR, NLD = (NROW + RPI - 1) / RPI;
+  static constexpr int rs_for() {
+    int r = 2 * TPR + 4 > PAD + 4 * SEGS ? 2 * TPR + 4 : PAD + 4 * SEGS;
+    while (r % 32 != TPR % 32) ++r;
+    return r;
+  }
   static constexpr int RS = rs_for();                     // 2 RS = 2 TPR (mod 64): window address linear in the tile index
   static constexpr int cs_for() { int c = NR * RS; while (c % 64 != 32) ++c; return c; }
   static constexpr int CS = cs_for();                     // the second channel of a 32-lane read group: banks + 32
   static constexpr int BUF = 8 * CS;
-  static constexpr int SEGS = DIN / 4, RPI = 64 / SEGS, NROW = 8 * NR, NLD = (NROW + RPI - 1) / RPI;
   static_assert(RS % 2 == 0 && CS % 2 == 0, "8-byte window reads");
   static_assert((kWinoAFloats + 4 * BUF) * 4 <= 160 * 1024, "LDS");
 };
 
-template <class C>
-__global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict__ g, const float* __restrict__ wp,
-                                                        float* __restrict__ y, const float* __restrict__ mask, WDims d) {
-  constexpr int DIN = C::DIN, DOUT = C::DOUT, TPR = C::TPR, RS = C::RS, CS = C::CS, NLD = C::NLD;
+// EPI 1: y = mask > 0 ? acc : 0 (backward-data through the ReLU of the layer below; `mask` = that layer's output)
+// EPI 0: y = relu(acc + bias[channel])  (forward; `mask` = the 8 biases)
+template <class C, int EPI>
+__global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g, const float* __restrict__ wp,
+                                                    float* __restrict__ y, const float* __restrict__ mask, WDims d) {
+  constexpr int DIN = C::DIN, PAD = C::PAD, DOUT = C::DOUT, TPR = C::TPR, RS = C::RS, CS = C::CS, NLD = C::NLD;
   __shared__ __attribute__((aligned(16))) float lds[kWinoAFloats + 4 * C::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,10 +106,11 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < NLD; ++k) {
     const int ri = k * C::RPI + lane / C::SEGS, seg = lane % C::SEGS;
-    const int co = ri / C::NR, row = ri % C::NR, yd = 2 * R0 + row - 3;
-    const bool ok = ri < C::NROW && yd >= 0 && yd < DIN;
+    const int co = ri / C::NR, row = ri % C::NR, yd = 2 * R0 + row - PAD;
+    const bool live = ri < C::NROW && lane < C::RPI * C::SEGS;
+    const bool ok = live && yd >= 0 && yd < DIN;
     voff[k] = ok ? ((co * DIN * DIN + yd) * DIN + 4 * seg) * 4 : 0x7ffffff0;      // beyond the descriptor: reads 0
-    ldst[k] = ri < C::NROW ? co * CS + row * RS + 3 + 4 * seg : -1;
+    ldst[k] = live ? co * CS + row * RS + PAD + 4 * seg : -1;
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(g + (size_t)b * 8 * DIN * DIN * DIN), 0, 8 * DIN * DIN * DIN * 4, 0x00020000);
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   // branch here makes the loaded registers a phi, which the compiler resolves with a wait right behind the loads; the
   // plane offset is forced into an SGPR or every load becomes a waterfall loop)
   auto fetch = [&](int p) {
-    const int pz = p - 3;
+    const int pz = p - PAD;
     if (d.dbg & 8) return;
     const bool pin = pz >= 0 && pz < DIN;
     const int so = __builtin_amdgcn_readfirstlane(pin ? pz * DIN * DIN * 4 : 0);
@@ -121,10 +131,15 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       if (ldst[k] < 0) continue;
-      float* o = raw + ldst[k];                                   // odd word: 4 + 8 + 4 bytes
-      o[0] = __uint_as_float(st[k].x);
-      *(float2*)(o + 1) = float2{__uint_as_float(st[k].y), __uint_as_float(st[k].z)};
-      o[3] = __uint_as_float(st[k].w);
+      float* o = raw + ldst[k];
+      if constexpr (PAD & 1) {                                    // odd word: 4 + 8 + 4 bytes
+        o[0] = __uint_as_float(st[k].x);
+        *(float2*)(o + 1) = float2{__uint_as_float(st[k].y), __uint_as_float(st[k].z)};
+        o[3] = __uint_as_float(st[k].w);
+      } else {                                                    // (a row's last segment may run one word past the
+        *(float2*)o = float2{__uint_as_float(st[k].x), __uint_as_float(st[k].y)};       // row: no window reads it)
+        *(float2*)(o + 2) = float2{__uint_as_float(st[k].z), __uint_as_float(st[k].w)};
+      }
     }
   };
 
@@ -172,8 +187,10 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   // ---- a finished pair: mask / output addressing through buffer descriptors (out-of-range lanes read 0 and store nothing:
   // no divergent branches).  Lane part of the offset per output row yo; the (channel half, plane) part is scalar.
   const size_t cstride = (size_t)DOUT * DOUT * DOUT;
-  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)(mask + (size_t)b * 8 * cstride), 0,
-                                                                         (int)(8 * cstride * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(EPI == 1 ? mask + (size_t)b * 8 * cstride : mask), 0, EPI == 1 ? (int)(8 * cstride * 4) : 32, 0x00020000);
+  float bias2[2] = {0.f, 0.f};                            // EPI 0: the biases of this lane's two channels
+  if constexpr (EPI == 0) { bias2[0] = mask[2 * kq]; bias2[1] = mask[2 * kq + 1]; }
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)b * 8 * cstride), 0,
                                                                          (int)(8 * cstride * 4), 0x00020000);
   constexpr int kOob = 0x7ffffff0;
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   }
   wn_u2 mk[8];                                            // the ReLU mask of the pair being finished, fetched a plane ahead
   auto mask_fetch = [&](int q) {
+    if constexpr (EPI != 1) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool zin = 2 * q + (r & 1) < DOUT;            // wave-uniform
@@ -219,9 +237,14 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
       for (int yo = 0; yo < 2; ++yo) {
         float o0 = (c[yo][0] + c[yo][1]) + (c[yo][2] + c[yo][3]);
         float o1 = (c[yo][1] - c[yo][2]) + fmaf(2.f, c[yo][3], c[yo][4]);
-        const wn_u2 m = mk[2 * r + yo];
-        o0 = __uint_as_float(m.x) > 0.f ? o0 : 0.f;
-        o1 = (full && __uint_as_float(m.y) > 0.f) ? o1 : 0.f;
+        if constexpr (EPI == 1) {
+          const wn_u2 m = mk[2 * r + yo];
+          o0 = __uint_as_float(m.x) > 0.f ? o0 : 0.f;
+          o1 = (full && __uint_as_float(m.y) > 0.f) ? o1 : 0.f;
+        } else {
+          o0 = fmaxf(o0 + bias2[r >> 1], 0.f);
+          o1 = fmaxf(o1 + bias2[r >> 1], 0.f);
+        }
         // (a plane beyond the tensor: its mask was read as zeros, so o0 = o1 = 0; the stores take the out-of-range offset)
         __builtin_amdgcn_raw_buffer_store_b64(wn_u2{__float_as_uint(o0), __float_as_uint(o1)}, rs_y, zin ? vs64[yo] : kOob, so, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rs_y, zin ? vs32[yo] : kOob, so, 0);
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
     const bool last = s == q1 + 1;
     if (hC) mask_fetch(s - 2);
     if (!last) fetch(2 * s + 1);
-    const bool pin = 2 * s - 3 >= 0 && 2 * s - 3 < DIN;
+    const bool pin = 2 * s - PAD >= 0 && 2 * s - PAD < DIN;
     float V0[25], V1[25];
     if (pin) {
       transform(I0{}, V0);
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
     if (last) return false;
     commit();
     fetch(2 * s + 2);
-    if (2 * s + 1 - 3 >= 0 && 2 * s + 1 - 3 < DIN) {
+    if (2 * s + 1 - PAD >= 0 && 2 * s + 1 - PAD < DIN) {
       transform(I0{}, V0);
       if (hA) mfma25(A{}, I1{}, I0{}, V0);
       if (hB) mfma25(B{}, I3{}, I0{}, V0);
@@ -290,25 +313,49 @@ __global__ __launch_bounds__(256) void conv_k4_wino_bwd(const float* __restrict_
   }
 }
 
-// dx[b, ci, :] = relu-mask( sum_co conv_full(dy[b, co], w) ): backward-data of a valid 4^3 convolution with 8 -> 8 channels
-// through the ReLU of the layer below.  dy [batch, 8, din^3] (din = 32 or 16), dx / mask [batch, 8, (din + 3)^3];
-// wp = nvf_pack_mfma_all kind 40 of the layer's w_bwd (nvf_pack_wino_k4_floats() floats).  bias_part (optional):
-// *bias_nparts slabs of 8 channel sums of dx (the bias gradient of the layer below).  ppc: pairs of output planes per
-// work unit (0 = default).  NVF_EINVAL for shapes without an instantiation.
-extern "C" int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din,
-                                      int ppc, float* bias_part, int* bias_nparts, void* stream) {
-  if (!dy || !wp || !dx || !mask || batch <= 0 || (bias_part && !bias_nparts)) return NVF_EINVAL;
-  if (din != 32) return NVF_EINVAL;
-  using C = WCfg<32>;
+template <class C, int EPI>
+static int launch_wino(const float* x, const float* wp, float* y, const float* aux, int batch, int ppc, float* bias_part,
+                       int* bias_nparts, hipStream_t s) {
   const int dbg = ppc >> 8;
   ppc &= 255;
-  if (ppc <= 0) ppc = 6;
   if (ppc & 1) return NVF_EINVAL;       // chunks start at even pairs (two alternating accumulator sets)
   const int nchunk = (C::NPAIR + ppc - 1) / ppc;
   WDims d{batch, batch * nchunk * C::NCG, ppc, dbg, bias_part};
   const int grid = (d.units + 3) / 4;
   if (bias_nparts) *bias_nparts = grid * 4;
-  conv_k4_wino_bwd<C><<<grid, 256, 0, nvf_stream(stream)>>>(dy, wp, dx, mask, d);
+  conv_k4_wino<C, EPI><<<grid, 256, 0, s>>>(x, wp, y, aux, d);
+  return NVF_OK;
+}
+
+// dx[b, ci, :] = relu-mask( sum_co conv_full(dy[b, co], w) ): backward-data of a valid 4^3 convolution with 8 -> 8 channels
+// through the ReLU of the layer below.  dy [batch, 8, din^3] (din = 32: conv2, 16: conv1), dx / mask [batch, 8, (din + 3)^3];
+// wp = nvf_pack_mfma_all kind 40 of the layer's w_bwd (nvf_pack_wino_k4_floats() floats).  bias_part (optional):
+// *bias_nparts slabs of 8 channel sums of dx (the bias gradient of the layer below).  ppc: pairs of output planes per
+// work unit (0 = default; even).  NVF_EINVAL for shapes without an instantiation.
+extern "C" int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din,
+                                      int ppc, float* bias_part, int* bias_nparts, void* stream) {
+  if (!dy || !wp || !dx || !mask || batch <= 0 || (bias_part && !bias_nparts)) return NVF_EINVAL;
+  int rc;
+  if (din == 32) rc = launch_wino<WCfg<32, 3>, 1>(dy, wp, dx, mask, batch, (ppc & 255) ? ppc : (ppc | 6), bias_part, bias_nparts, nvf_stream(stream));
+  else if (din == 16) rc = launch_wino<WCfg<16, 3>, 1>(dy, wp, dx, mask, batch, (ppc & 255) ? ppc : (ppc | 2), bias_part, bias_nparts, nvf_stream(stream));
+  else return NVF_EINVAL;
+  if (rc != NVF_OK) return rc;
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// y = relu(conv3d(x, w) + bias): the FORWARD pass of the same layers in the Winograd form -- for training steps only (its
+// results differ from the direct fixed-order kernel by fp32 rounding, 1e-6 of max |y|: the eval / encode / decode forward,
+// whose occupancy must be batch-invariant bit for bit, never uses it).  x [batch, 8, din^3] (din = 35: conv2, 19: conv1),
+// y [batch, 8, (din - 3)^3]; wp = kind 40 of the layer's w_fwd.
+extern "C" int nvf_conv3d_k4_wino_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int din,
+                                      int ppc, void* stream) {
+  if (!x || !wp || !bias || !y || batch <= 0) return NVF_EINVAL;
+  int rc;
+  if (din == 35) rc = launch_wino<WCfg<35, 0>, 0>(x, wp, y, bias, batch, (ppc & 255) ? ppc : (ppc | 4), nullptr, nullptr, nvf_stream(stream));
+  else if (din == 19) rc = launch_wino<WCfg<19, 0>, 0>(x, wp, y, bias, batch, (ppc & 255) ? ppc : (ppc | 2), nullptr, nullptr, nvf_stream(stream));
+  else return NVF_EINVAL;
+  if (rc != NVF_OK) return rc;
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

@@ -15,6 +15,48 @@ template <class Src>
 __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int bx, int nbx, Src src) {
   float* __restrict__ wp = m.dst[job];
   const int kind = m.kind[job], total = m.total[job];
+  if (kind == 40) {
+    // Winograd (y, x) backward-data of a 4^3 conv (conv_wino.hip): [g][zw][f][lane], lane = (co, s) + 16 k, value
+    // U = G w' G^T of the gather-form kernel slice kz = zw - s, G = Cook-Toom F(2, 4) on {0, 1, -1, 2, inf} with the
+    // rational factors of B^T folded in (rows / 2, / 2, / 6, / -6, 1).  One thread per (slice (ci, kz, co), fy): the 16
+    // weights of a slice are fetched once per thread (src may draw counter-RNG noise per element), five outputs each go
+    // to (zw = kz, s = 0) and (zw = kz + 1, s = 1); the entries without a tap (zw = 0, s = 1 and zw = 4, s = 0) are zeroed
+    const float G[5][4] = {{0.5f, 0.f, 0.f, 0.f},
+                           {0.5f, 0.5f, 0.5f, 0.5f},
+                           {1.f / 6.f, -1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
+                           {-1.f / 6.f, -2.f / 6.f, -4.f / 6.f, -8.f / 6.f},
+                           {0.f, 0.f, 0.f, 1.f}};
+    for (int t = bx * blockDim.x + threadIdx.x; t < 256 * 5 + 3200; t += nbx * blockDim.x) {
+      if (t < 256 * 5) {
+        const int fy = t % 5, sl = t / 5, cog = sl % 8, kz = (sl / 8) % 4, ci = sl / 32, g = ci / 4, k = ci % 4;
+        float row[4][5];
+        for (int ky = 0; ky < 4; ++ky) {
+          float w4[4];
+          for (int kx = 0; kx < 4; ++kx) w4[kx] = src(job, (ci * 64 + (kz * 4 + ky) * 4 + kx) * 8 + cog);
+          for (int fx = 0; fx < 5; ++fx) {
+            float r = 0.f;
+            for (int kx = 0; kx < 4; ++kx) r = fmaf(G[fx][kx], w4[kx], r);
+            row[ky][fx] = r;
+          }
+        }
+        for (int fx = 0; fx < 5; ++fx) {
+          float v = 0.f;
+          for (int ky = 0; ky < 4; ++ky) v = fmaf(G[fy][ky], row[ky][fx], v);
+          const int f = fy * 5 + fx;
+          wp[((g * 5 + kz) * 25 + f) * 64 + 16 * k + 2 * cog] = v;
+          wp[((g * 5 + kz + 1) * 25 + f) * 64 + 16 * k + 2 * cog + 1] = v;
+        }
+      } else {
+        int r = t - 256 * 5;
+        const int cog = r % 8; r /= 8;
+        const int k = r % 4; r /= 4;
+        const int f = r % 25; r /= 25;
+        const int g = r % 2, s1 = r / 2;                      // s1 = 1: (zw 0, s 1); 0: (zw 4, s 0)
+        wp[((g * 5 + (s1 ? 0 : 4)) * 25 + f) * 64 + 16 * k + 2 * cog + s1] = 0.f;
+      }
+    }
+    return;
+  }
   for (int idx = bx * blockDim.x + threadIdx.x; idx < total; idx += nbx * blockDim.x) {
     int r = idx;
     const int lane = r % 64; r /= 64;
@@ -51,24 +93,6 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       const int jx = f % (3 - ex), jy = (f / (3 - ex)) % (3 - ey), jz = f / ((3 - ex) * (3 - ey));
       const int cout = m.c1[job], g4 = g % (m.c0[job] / 4), cg = g / (m.c0[job] / 4);
       v = src(job, ((4 * g4 + k) * 125 + ((ez + 2 * jz) * 5 + ey + 2 * jy) * 5 + ex + 2 * jx) * cout + cg * 16 + i);
-    } else if (kind == 40) {                         // Winograd (y, x) backward-data of a 4^3 conv: [g][zw][f][lane]
-      // U = G w' G^T of the gather-form kernel slice kz = zw - s, G = Cook-Toom F(2, 4) on {0, 1, -1, 2, inf} with the
-      // rational factors of B^T folded in (rows / 2, / 2, / 6, / -6, 1): conv_wino.hip
-      const int f = r % 25; r /= 25;
-      const int zw = r % 5, g = r / 5;
-      const int cog = i >> 1, s = i & 1, ci = 4 * g + k, kz = zw - s, fy = f / 5, fx = f % 5;
-      if (kz >= 0 && kz < 4) {
-        const float G[5][4] = {{0.5f, 0.f, 0.f, 0.f},
-                               {0.5f, 0.5f, 0.5f, 0.5f},
-                               {1.f / 6.f, -1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
-                               {-1.f / 6.f, -2.f / 6.f, -4.f / 6.f, -8.f / 6.f},
-                               {0.f, 0.f, 0.f, 1.f}};
-        for (int ky = 0; ky < 4; ++ky) {
-          float row = 0.f;
-          for (int kx = 0; kx < 4; ++kx) row = fmaf(G[fx][kx], src(job, (ci * 64 + (kz * 4 + ky) * 4 + kx) * 8 + cog), row);
-          v = fmaf(G[fy][ky], row, v);
-        }
-      }
     } else if (kind == 30 || kind == 31) {           // 16-row gather convolution (conv16_mfma.hip): [cog][g][tap][lane]
       const int k3 = kind == 30 ? 64 : 125, cin = m.c0[job], cout = m.c1[job];
       const int tap = r % k3; r /= k3;

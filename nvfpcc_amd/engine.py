@@ -32,7 +32,9 @@ _G16 = os.environ.get("NVF_G16", "1") != "0"     # matrix-core kernels of the wi
 _VAR = {k: int(os.environ.get("NVF_VAR_" + k, "0")) for k in ("UP1F", "UP2F", "UP1B", "UP2B", "C1F", "C1B")}   # tile variants
 _CONV2_FWD_VAR = int(os.environ.get("NVF_CONV2_FWD_VAR", "0"))   # tile-shape variants of conv_k4_mfma (tuning)
 _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
-_WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's backward-data in the Winograd (y, x) form (conv_wino.hip)
+_WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's / conv1's backward-data in the Winograd (y, x) form (conv_wino.hip)
+_WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forward in TRAINING steps (never in eval)
+_WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
@@ -63,7 +65,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "wp_t16", "wp_w", "bwd_pair", "bwd_max_batch")
+                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "wp_t16", "wp_w", "wp_wf", "bwd_pair", "bwd_max_batch")
 
 
 class TrainEngine:
@@ -181,7 +183,7 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = L.wp_w = None
+            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = L.wp_w = L.wp_wf = None
             L.bwd_pair, L.bwd_max_batch = 2, 0
             if self.narrow and L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
@@ -197,10 +199,14 @@ class TrainEngine:
                     # flattened 18-cell rows (conv2; faster than the VALU kernel only while the batch is small)
                     L.bwd_pair, L.bwd_max_batch = MFMA_BWD[name]
                     L.wp_b = torch.empty(int(lib().nvf_pack_mfma_k4_floats(L.cout, L.bwd_pair)), device=self.dev)
-                if name == "conv2" and _WINO:
+                if _WINO and (name == "conv2" or (name == "conv1" and _WINO_C1)):
                     # backward-data in the reduced-multiplication form (Winograd over (y, x), z pairs on the matrix
-                    # cores: 52 us against 85 for the direct form at batch 16); backward passes only
+                    # cores: 52 us against 85 for the direct form at batch 16)
                     L.wp_w = torch.empty(int(lib().nvf_pack_wino_k4_floats()), device=self.dev)
+                if _WINO and _WINO_FWD and name == "conv2":
+                    # ... and the forward of TRAINING steps (mode 'train': NVFPCC.py:160, 234); the eval / encode / decode
+                    # forward keeps the direct fixed-order kernel (bit-exact batch invariance, the occupancy contract)
+                    L.wp_wf = torch.empty(int(lib().nvf_pack_wino_k4_floats()), device=self.dev)
             # wide decoder (16 / 32 channels): the output channels are the MFMA rows (conv16_mfma.hip) -- conv1 / conv2
             # forward and backward-data, and the backward-data of up2 / up1 (stride-2 gather with cin output channels)
             if _G16 and self.wide and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0 and name in ("conv1", "conv2"):
@@ -233,6 +239,8 @@ class TrainEngine:
         meta += [(row[nm], 1) for nm, L in named if L.wp_b is not None]
         jobs += [(L.w_bwd, L.wp_w, 40, L.cout, 8) for _, L in named if L.wp_w is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_w is not None]
+        jobs += [(L.w_fwd, L.wp_wf, 40, L.cin, 8) for _, L in named if L.wp_wf is not None]
+        meta += [(row[nm], 0) for nm, L in named if L.wp_wf is not None]
         jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for _, L in named if L.wp_t is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_t is not None]
         jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for _, L in named if L.wp_s is not None]
@@ -319,7 +327,9 @@ class TrainEngine:
             return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act, variant=var)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
-    def _conv(self, L, x, act):
+    def _conv(self, L, x, act, train=False):
+        if train and L.wp_wf is not None and act == R:
+            return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff)
         if L.wp_gf is not None:
             osz = tuple(s - 3 for s in x.shape[2:])
             return ops.conv3d_g16_mfma(x, L.wp_gf, L.b_eff, L.cout, 4, 1, 0, osz, act)
@@ -382,7 +392,7 @@ class TrainEngine:
             with self._on_side():
                 a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
         a["y4"] = self._convT(Ls["up2"], a["y3"], R)
-        a["y5"] = self._conv(Ls["conv2"], a["y4"], R)
+        a["y5"] = self._conv(Ls["conv2"], a["y4"], R, train=(mode == "train"))
         if self.heads3:                             # all three heads in one launch, after the trunk
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
             a["p0"], a["p1"], a["p2"] = ops.heads3_fwd([a["y1"], a["y3"], a["y5"]], [L.w_fwd for L in hl],
@@ -418,7 +428,7 @@ class TrainEngine:
             dx = ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 4, 1, 3, tuple(x_in.shape[2:]), addend=addend,
                                      mask=mask)
             return dx if bias_out is None else (dx, False)
-        if L.wp_w is not None and mask is not None and addend is None and g_out.shape[-1] == 32:
+        if L.wp_w is not None and mask is not None and addend is None and g_out.shape[-1] in (32, 16):
             if bias_out is not None:
                 base = self._wg.reserve(4096 * 8 * 4) if g_out.shape[0] <= 64 else None
                 if base is not None:

@@ -256,6 +256,19 @@ def conv3d_k4_wino_bwd(dy, wp, mask, out=None, bias_part=None, ppc=0):
     return dx if bias_part is None else (dx, nparts.value)
 
 
+def conv3d_k4_wino_fwd(x, wp, bias, out=None, ppc=0):
+    """relu(conv3d(x, w) + bias) of a valid 4^3 convolution (8 -> 8 channels) in the Winograd (y, x) form -- training steps
+    only (rounding-level differences from the direct fixed-order kernel).  wp = pack_wino_k4(w_fwd)."""
+    _f32(x, wp, bias)
+    B, c, di = x.shape[0], x.shape[1], x.shape[2]
+    if c != 8:
+        raise RuntimeError("conv3d_k4_wino_fwd: x [B,8,n^3]")
+    y = out if out is not None else torch.empty((B, 8, di - 3, di - 3, di - 3), device=x.device)
+    check(lib().nvf_conv3d_k4_wino_fwd(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, di, int(ppc), _stream()),
+          "nvf_conv3d_k4_wino_fwd")
+    return y
+
+
 def wgrad_k4_wino(dy, x, zsplit=1, want_bias=False):
     """conv2's weight gradient [8,8,4,4,4] (and the bias gradient [8]) in the Winograd (y, x) form: one launch of slabs +
     the fixed-order reduction."""

@@ -959,6 +959,23 @@ def test_threshold_points_match_nonzero(ops):
         assert torch.equal(counts.cpu().long(), (p[:, 0] > thh).flatten(1).sum(1))
 
 
+@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 2), (35, 3, 16), (19, 1, 0), (19, 5, 0), (19, 16, 4)])
+def test_conv3d_k4_wino_forward(ops, n, B, ppc):
+    """The training-step forward of conv2 / conv1 in the Winograd form against torch's conv3d on the CPU (float64) and
+    against the direct fixed-order matrix-core kernel: 1e-5 of max |y| (measured 1e-6), zeros of the ReLU in the same
+    places up to rounding at the kink."""
+    g = gen(4900 + n + B)
+    x = torch.relu(torch.randn(B, 8, n, n, n, generator=g) * 0.7)
+    w = torch.round(torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08 * 16) / 16 + 0.02 * torch.randn(8, 8, 4, 4, 4, generator=g)
+    b = torch.randn(8, generator=g) * 0.3
+    ref = F.relu(F.conv3d(x.double(), w.double(), b.double()))
+    wf, _ = ops.pack_conv_weight(dev(w))
+    y = ops.conv3d_k4_wino_fwd(dev(x), ops.pack_wino_k4(wf), dev(b), ppc=ppc)
+    assert rel_err(y, ref) < 1e-5, rel_err(y, ref)
+    y_direct = ops.conv3d_k4_mfma(dev(x), ops.pack_mfma_k4(wf, 8, 0), dev(b), 0, 0, ops.ACT_RELU)
+    assert rel_err(y, y_direct.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (2, 2), (3, 18)])
 def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     """conv2's backward-data in the reduced-multiplication form (conv_wino.hip: Winograd F(2x2, 4x4) over (y, x), direct
@@ -966,8 +983,18 @@ def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     at batches 1, 5 and 16 and with other chunkings of the z pairs; the channel sums it leaves (up2's bias gradient)
     against the sums of what it wrote.  Tolerance: 1e-5 of max |dx| (measured 1e-6; the direct MFMA form is held to the
     same figure above)."""
-    g = gen(4400 + B)
-    x = torch.randn(B, 8, 35, 35, 35, generator=g)
+    _wino_bwd_case(ops, 35, B, ppc)
+
+
+@pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (3, 4), (2, 10)])
+def test_conv3d_k4_wino_backward_data_conv1(ops, B, ppc):
+    """... and conv1's (16^3 -> 19^3: 10 x 10 tiles, three tile rows per group of sixteen)."""
+    _wino_bwd_case(ops, 19, B, ppc)
+
+
+def _wino_bwd_case(ops, n, B, ppc):
+    g = gen(4400 + B + n)
+    x = torch.randn(B, 8, n, n, n, generator=g)
     w = torch.round(torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08 * 16) / 16 + 0.02 * torch.randn(8, 8, 4, 4, 4, generator=g)
     x.requires_grad_(True)
     y_ref = F.conv3d(x, w)

@@ -55,6 +55,42 @@ def main():
         print(f"winograd (conv_k4_wino_bwd, ppc {ppc & 255:2d} dbg {ppc >> 8:2d}): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic   max|d| / max = {err:.2e}")
 
 
+def fwd_main(B, reps):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n in (35, 19):
+        w = (torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08).to(dev)
+        b = (torch.randn(8, generator=g) * 0.1).to(dev)
+        x = torch.relu(torch.randn(B, 8, n, n, n, generator=g)).to(dev)
+        wf, wb = ops.pack_conv_weight(w)
+        wp_d, wp_w = ops.pack_mfma_k4(wf, 8, 0), ops.pack_wino_k4(wf)
+        macs = B * 8 * 8 * 64 * (n - 3) ** 3
+        out = torch.empty(B, 8, n - 3, n - 3, n - 3, device=dev)
+        d = ops.conv3d_k4_mfma(x, wp_d, b, 0, 0, ops.ACT_RELU)
+        us = timeit(lambda: ops.conv3d_k4_mfma(x, wp_d, b, 0, 0, ops.ACT_RELU, out=out), reps)
+        print(f"fwd {n} direct:            {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
+        for ppc in ((4, 2, 6, 8) if n == 35 else (2, 4, 8)):
+            y = ops.conv3d_k4_wino_fwd(x, wp_w, b, ppc=ppc)
+            err = float((y - d).abs().max() / d.abs().max())
+            us = timeit(lambda: ops.conv3d_k4_wino_fwd(x, wp_w, b, out=out, ppc=ppc), reps)
+            print(f"fwd {n} winograd ppc {ppc}:    {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
+    # conv1 backward-data
+    w = (torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08).to(dev)
+    gy = torch.randn(B, 8, 16, 16, 16, generator=g).to(dev)
+    mask = torch.randn(B, 8, 19, 19, 19, generator=g).to(dev)
+    _, wb = ops.pack_conv_weight(w)
+    wp_d, wp_w = ops.pack_mfma_k4(wb, 8, 2), ops.pack_wino_k4(wb)
+    macs = B * 8 * 8 * 64 * 16 ** 3
+    d = ops.conv3d_k4_mfma(gy, wp_d, None, 3, 2, ops.ACT_NONE, mask=mask)
+    us = timeit(lambda: ops.conv3d_k4_mfma(gy, wp_d, None, 3, 2, ops.ACT_NONE, mask=mask), reps)
+    print(f"conv1 bwd-data direct (z pair): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
+    for ppc in (2, 4, 6, 10):
+        y = ops.conv3d_k4_wino_bwd(gy, wp_w, mask, ppc=ppc)
+        err = float((y - d).abs().max() / d.abs().max())
+        us = timeit(lambda: ops.conv3d_k4_wino_bwd(gy, wp_w, mask, ppc=ppc), reps)
+        print(f"conv1 bwd-data winograd ppc {ppc:2d}: {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
+
+
 def wgrad_main(B, reps):
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(2)
@@ -72,6 +108,14 @@ def wgrad_main(B, reps):
 
 
 if __name__ == "__main__":
+    if "--fwd" in sys.argv:
+        sys.argv.remove("--fwd")
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--batch", type=int, default=16)
+        ap.add_argument("--reps", type=int, default=50)
+        a = ap.parse_args()
+        fwd_main(a.batch, a.reps)
+        sys.exit(0)
     if "--wgrad" in sys.argv:
         sys.argv.remove("--wgrad")
         ap = argparse.ArgumentParser()
