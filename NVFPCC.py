@@ -103,42 +103,46 @@ def train(args):
         # NaN guards of NVFPCC.py:199-212 are checked here, on the summed counters (raises ValueError)
         acc = eng.read_epoch_stats(reduce=nd.allreduce_sum_ if world > 1 else None, world=world)
         say(TRAIN_LINE % ((epoch, time.time() - t0) + tuple(eng.train_log_fields(acc, nsteps))))
-        if epoch % 10 == 0 and rank == 0:
-            print('[INFO] Saving')
-            os.makedirs(args.checkpoint_dir, exist_ok=True)
-            sd = OrderedDict((k, v.detach().clone()) for k, v in net.state_dict().items())
-            torch.save(sd, './%s/%04d.ckpt' % (args.checkpoint_dir, epoch))
-            torch.save(eng.emb.detach().clone(), './%s/%04d_emb.ckpt' % (args.checkpoint_dir, epoch))
+        if epoch % 10 == 0:
+            if rank == 0:
+                print('[INFO] Saving')
+                os.makedirs(args.checkpoint_dir, exist_ok=True)
+                sd = OrderedDict((k, v.detach().clone()) for k, v in net.state_dict().items())
+                torch.save(sd, './%s/%04d.ckpt' % (args.checkpoint_dir, epoch))
+                torch.save(eng.emb.detach().clone(), './%s/%04d_emb.ckpt' % (args.checkpoint_dir, epoch))
+            # the every-10th-epoch evaluation (NVFPCC.py:308-392), sharded: each rank its contiguous blocks, one small
+            # all-reduce of the 22 log sums (the reference runs it on its single device)
             t1 = time.time()
-            fields = tuple(test_log_fields(eng, net, data.N, args.lmbda))
-            print(TEST_LINE % ((epoch, time.time() - t1) + fields))
+            fields = tuple(test_log_fields(eng, net, data.N, args.lmbda, rank, world, nd.allreduce_sum_))
+            say(TEST_LINE % ((epoch, time.time() - t1) + fields))
 
 
-def test_log_fields(eng, net, n_points, lmbda):
+def test_log_fields(eng, net, n_points, lmbda, rank=0, world=1, reduce=None):
     """The 17 numbers of the reference's TEST line (NVFPCC.py:308-392): full-batch net(emb, 'eval', 2), the same
     losses / metrics as the TRAIN line on ALL blocks (one "mini-batch": cnt = 1), and b_all = (latent bits + network
     bits incl. the side information of Net.get_network_bits) / N.  Quirk kept: its Loss adds lambda * (b_latent + b_net)
-    without the w1 / w2 weights (:347)."""
-    from nvfpcc_amd import ops
-    a = eng.eval_forward(q=2)
-    loss = torch.empty(4, device=eng.dev)
-    ops.focal_loss_multi([(a["p2"], eng.gt, eng.dist, 0.9, 1.0), (a["p0"], eng.gt8, None, 0.85, 0.0),
-                          (a["p1"], eng.gt16, None, 0.85, 0.0)], loss)
-    c = ops.metrics3([a["p2"], a["p0"], a["p1"]], [eng.gt, eng.gt8, eng.gt16], [eng.dist, None, None], 0.5, 0.6)
-    c = c.double().cpu().numpy()
-    ls = loss.double().cpu().numpy()
-    lat_bits = float(a["lbits"].item())
-    nbits = torch.empty(7, device=eng.dev)
-    lm = net.reconstructor.likelihood_model
-    ops.weight_rate_batch([eng.layers[n].mod.kernel for n in ("up0", "conv0", "up1", "conv1", "up2", "conv2",
-                                                               "conv2_cls")], None, lm.sigma, lm.mu, nbits)
-    n_pts = float(eng.counts.sum())
-    b_latent, b_net = lat_bits / n_pts, float(nbits.sum().item()) / float(n_points)
+    without the w1 / w2 weights (:347).
+    Data parallelism: every rank evaluates its contiguous shard of the blocks (dist.shard_range) and ONE all-reduce of
+    the 22 additive sums (`reduce`) gives every rank the full-batch numbers -- call it on every rank."""
+    from nvfpcc_amd import dist as nd
+    lo, hi = nd.shard_range(eng.N_leaf, rank, world)
+    sums = eng.eval_sums(lo, hi, q=2)
+    if reduce is not None and world > 1:
+        reduce(sums)
+    return test_fields_from_sums(sums.double().cpu().numpy(), eng.weight_bits(), float(eng.counts.sum()), float(n_points),
+                                 lmbda, net.get_network_bits())
+
+
+def test_fields_from_sums(sums, weight_bits, n_pts, n_points, lmbda, network_bits):
+    """Host arithmetic of the TEST line from the 22 additive sums of TrainEngine.eval_sums (focal terms [0:3], metric
+    counts [3:21], latent bits [21])."""
+    ls, c, lat_bits = sums[0:3], sums[3:21], float(sums[21])
+    b_latent, b_net = lat_bits / n_pts, float(weight_bits) / float(n_points)
     with np.errstate(divide="ignore", invalid="ignore"):
         r = [c[6 * t + k] / c[6 * t + k + 1] for t in range(3) for k in (0, 2)]
         mse1 = c[4] / c[5]
         psnr1 = 20 * np.log10(1023 / np.sqrt(mse1 / 3))
-    b_all = (lat_bits + net.get_network_bits()) / float(n_points)
+    b_all = (lat_bits + network_bits) / float(n_points)
     return [ls[0] + ls[1] + ls[2] + lmbda * (b_latent + b_net), 0.0, 0.0, r[0], r[1], ls[1], ls[2], r[2], r[3], r[4],
             r[5], b_latent + b_net, b_latent, b_net, b_all, mse1, psnr1]
 

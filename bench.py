@@ -124,10 +124,11 @@ class KernelProbe:
         probe = self
 
         def wrapped(*a, **k):
-            if probe.mark == label and match(*a, **k):
-                # PMC child pass: a marker dispatch (uniform_kernel over MARK_N floats) right in front of the probed
-                # launch, so the parent finds it in the counter CSV by position, whatever the kernel is called
-                ops_mod.uniform((probe.MARK_N,), a[0].device, 0, 0)      # tensors and WgradBatch both have .device
+            if probe.mark and label in probe.mark.split(",") and match(*a, **k):
+                # child pass under rocprofv3: a marker dispatch (uniform_kernel over MARK_N + 256 i floats, i = the
+                # label's position in the list) right in front of the probed launch, so the parent finds it in the
+                # counter / trace CSV by position, whatever the kernel is called
+                ops_mod.uniform((probe.mark_n(probe.mark.split(",").index(label)),), a[0].device, 0, 0)
                 return orig(*a, **k)
             if probe.enabled and match(*a, **k):
                 wb = a[0] if hasattr(a[0], "jobs") and hasattr(a[0], "offset") else None   # WgradBatch method
@@ -156,8 +157,12 @@ class KernelProbe:
         setattr(ops, fn_name, wrapped)
 
     enabled = False
-    mark = None
-    MARK_N = 7717          # grid of the marker dispatch: ceil(7717 / 256) workgroups of 256
+    mark = None            # comma list of labels to put markers in front of (child passes)
+    MARK_N = 7717          # grid of the marker dispatch of label 0: ceil(7717 / 256) workgroups of 256; label i: + i
+
+    @classmethod
+    def mark_n(cls, i):
+        return cls.MARK_N + 256 * i
 
     def summary(self):
         import numpy as np
@@ -274,6 +279,48 @@ def measure_traffic(args, label):
         f"{kernel_source_hash()}"), name
 
 
+def measure_in_step_us(args, labels):
+    """Duration of the launches behind `labels` AS THE STEP ISSUES THEM (the five-gradient launch with its bias-sum
+    workgroups, coefficient copy and the queued latent tail): one child run of this script -- host-launched steps, a marker
+    dispatch in front of each probed launch -- under `rocprofv3 --kernel-trace` (no counters: kernels are not serialised
+    beyond the stream's own order); per label the median End - Start of the dispatch that follows its marker.
+    Returns ({label: us}, {label: kernel name}, note)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(rocprof):
+        return {}, {}, "rocprofv3 not found"
+    base = tempfile.mkdtemp(prefix="nvf_trace_", dir="/tmp")
+    cmd = [rocprof, "--kernel-trace", "-d", base, "-o", "kt", "--output-format", "csv", "--",
+           "python3", os.path.abspath(__file__), "--pmc-child", "--pmc-mark", ",".join(labels), "--no-cpu-baseline",
+           "--no-pmc", "--no-graph", "--no-sweep", "--no-epoch", "--steps", "12", "--warmup", "3", "--repeats", "1",
+           "--batch", str(args.batch), "--blocks", str(args.blocks), "--distinct", str(args.distinct), "--ch", str(args.ch),
+           "--chanstr", args.chanstr, "--q", str(args.q)]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        shutil.rmtree(base, ignore_errors=True)
+        return {}, {}, "rocprofv3 --kernel-trace child timed out"
+    files = glob.glob(os.path.join(base, "**", "*kernel_trace.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        shutil.rmtree(base, ignore_errors=True)
+        return {}, {}, f"rocprofv3 --kernel-trace child failed (rc {r.returncode}): {r.stdout[-300:]}"
+    rows = list(csv.DictReader(open(files[0])))
+    rows.sort(key=lambda row: int(row["Start_Timestamp"]))
+    grids = {(KernelProbe.mark_n(i) + 255) // 256 * 256: lab for i, lab in enumerate(labels)}
+    per, names = {lab: [] for lab in labels}, {}
+    for prev, row in zip(rows, rows[1:]):
+        if "uniform_kernel" in prev["Kernel_Name"]:
+            g = int(prev["Grid_Size"])
+            lab = grids.get(g) or grids.get(g * 256)
+            if lab is not None:
+                per[lab].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
+                names[lab] = row["Kernel_Name"]
+    shutil.rmtree(base, ignore_errors=True)
+    return ({lab: statistics.median(v) for lab, v in per.items() if v}, names,
+            "in-step: rocprofv3 --kernel-trace child pass of this command (host-launched steps), median duration of the "
+            "dispatch behind a marker dispatch")
+
+
 def run(args):
     # stdout carries ONE line, the JSON: libraries that print there (RCCL writes a version banner to stdout when its
     # communicator is built) go to stderr for the life of the process; the line itself goes to the saved descriptor
@@ -311,9 +358,11 @@ def run(args):
     counts = eng.counts
 
     graphed = None
+    primed_steps = 0
     if not args.no_graph and args.mode == "step":
         graphed = GraphedTrainStep(eng, B, args.q)
         graphed.prime()      # setup, like the capture itself: every graph launched once before the W warm-up steps
+        primed_steps = sum(u for u in graphed.unrolls if u in graphed.graphs_u) + 1      # real optimiser steps
 
     def shares(i):
         ids, whole = nd.shard_minibatch(order, i, B * world, rank, world)
@@ -351,6 +400,9 @@ def run(args):
                lambda x, wp, b, pad, pair, *a, **kw: pad == 0 and x.shape[-1] == 35 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_k4_mfma", "conv2_bwd_data",
                lambda x, wp, b, pad, pair, *a, **kw: pad == 3 and x.shape[-1] == 32 and x.shape[1] == c3)
+    # ... in the Winograd (y, x) form since round 4 (conv_wino.hip): training-step forward and backward-data
+    probe.wrap(ops, "conv3d_k4_wino_fwd", "conv2_fwd", lambda x, wp, b, *a, **kw: x.shape[-1] == 35)
+    probe.wrap(ops, "conv3d_k4_wino_bwd", "conv2_bwd_data", lambda dy, wp, m, *a, **kw: dy.shape[-1] == 32)
     probe.wrap(ops, "conv3d_gather", "conv2_fwd",
                lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
     probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",
@@ -407,7 +459,7 @@ def run(args):
     if args.pmc_child:
         return 0
 
-    # ---- whole epochs of NVFPCC.py train: mini-batches (graph replay + the short last batch from the host), the
+    # ---- whole epochs of NVFPCC.py train: mini-batches (graph replay; the short last batch replays a graph of its own size), the
     # full-batch latent step on this rank's shard, the device-side sums of the log line, eval on every 10th epoch
     epoch_obj = None
     if (args.mode == "epoch" or not args.no_graph) and not (args.no_epoch and args.mode == "step"):
@@ -446,7 +498,7 @@ def run(args):
         step_ms = region_ms[0] if region_ms else None
         epoch_obj = {"epochs": args.epochs, "ms_per_epoch": round(de / args.epochs * 1e3, 3),
                      "blocks_per_s": round(N * args.epochs / de, 1), "minibatches_per_epoch": nst,
-                     "includes": "mini-batch steps (graph replay; short last batch host-launched), full-batch latent "
+                     "includes": "mini-batch steps (unrolled graph replays; the short last batch replays a single-step graph of its own size), full-batch latent "
                                  "step, per-epoch stats read-back, eval forward + metrics on every 10th epoch",
                      "latent_step_ms": round(latent_ms, 3),
                      "bound_steps_plus_latent_plus_10pct_ms": None if step_ms is None else round(
@@ -539,17 +591,39 @@ def run(args):
                           "wgrad_trunk5": macs + UP2_MACS[cs] + CONV1_MACS[cs] + UP1_MACS[cs] + CONV0_MACS[cs]
                                           + (HEADS_MACS[cs] if heads_in else 0)}
             flops = 2.0 * layer_macs.get(label, macs) * B
-            achieved = flops / (us * 1e-6) / 1e12
+            # the launch exactly as the step issues it (bias-sum workgroups, coefficient copy, queued latent tail): its
+            # duration inside host-launched steps from a kernel-trace child pass; the HIP-event bracket around 8 repeats
+            # (a slightly lighter launch: no bias sums, no tail) stays in the line as `event_bracket_us`
+            labels = [label] + [l for l in ("conv2_fwd", "conv2_bwd_data") if l in single and l != label]
+            in_step, in_names, in_note = ({}, {}, "not measured (--no-pmc or N > 1)")
+            if world == 1 and not args.no_pmc:
+                torch.cuda.synchronize()
+                in_step, in_names, in_note = measure_in_step_us(args, labels)
+            us_step = in_step.get(label, us)
+            achieved = flops / (us_step * 1e-6) / 1e12
             traffic, tnote, kname = None, "not measured (--no-pmc or N > 1)", None
             if world == 1 and not args.no_pmc:
                 torch.cuda.synchronize()
                 traffic, tnote, kname = measure_traffic(args, label)
+            per_kernel = {}
+            for lab in labels:
+                f = flops if lab == label else 2.0 * macs * B
+                u = in_step.get(lab, single[lab])
+                per_kernel[lab] = {"us": round(u, 2), "flops": f, "tflops": round(f / (u * 1e-6) / 1e12, 2),
+                                   "frac": round(f / (u * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                   "source": "in-step kernel trace" if lab in in_step else "HIP-event bracket, 8 repeats",
+                                   "kernel_name": in_names.get(lab)}
             roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                         "traffic": None if traffic is None else round(traffic), "traffic_source": tnote,
-                        "kernel_name": kname,
-                        "avg_launch_us": round(us, 2), "flops_per_launch": flops,
-                        "all_kernels_avg_us": {k: round(v, 2) for k, v in kern_us.items()}}
+                        "kernel_name": kname or in_names.get(label),
+                        "avg_launch_us": round(us_step, 2), "avg_launch_us_source": in_note,
+                        "event_bracket_us": round(us, 2), "flops_per_launch": flops,
+                        "all_kernels": per_kernel,
+                        "all_kernels_avg_us": {k: round(v, 2) for k, v in kern_us.items()},
+                        "note": "fp32 VALU instructions do not hide behind fp32 MFMAs on gfx950 (profiles/"
+                                "r04_mfma_valu_overlap.md): a kernel's time is 32 cycles per MFMA plus 2.5-5 per vector "
+                                "instruction, in series"}
         fwd = FWD_MACS.get(args.chanstr)
         workload = ("train_step: decoder mini-batch update, NVFPCC.py:149-223 (fwd mode=train q=%d, 3 focal losses + "
                     "rate terms, bwd, fused Adam)" % args.q) if args.mode == "step" else (
@@ -563,6 +637,8 @@ def run(args):
             "scaling": "weak" if args.mode == "step" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "launch": launch_desc, "collective": collective_desc,
+                       "primed_steps": primed_steps,      # optimiser steps run before the W warm-up steps (every captured
+                       # graph launched once): parameters / Adam moments / noise counters have advanced by that many
                        "batch_per_gpu": B, "global_batch": B * world, "blocks_resident": args.blocks,
                        "ch": args.ch, "chanstr": args.chanstr, "parallelism": f"dp{world}",
                        "data_detail": f"{min(args.blocks, args.distinct)} distinct synthetic 32^3 quadric-sheet blocks "

@@ -878,6 +878,33 @@ class TrainEngine:
         self.prepare_weights(q)
         return self.forward(self.emb[lo:hi], "eval", ids)
 
+    def eval_sums(self, lo=0, hi=None, q=2):
+        """Additive sums behind the TEST line (NVFPCC.py:308-364) over blocks [lo, hi): [0:3] the three focal terms,
+        [3:21] the 18 metric counts of ops.metrics3 (main output, head 0, head 1), [21] the latent bits.  Every entry is a
+        SUM over blocks, so a rank evaluates its contiguous shard and ONE all-reduce of these 22 floats gives the
+        full-batch numbers (eval shards contiguously; the reference evaluates on one device)."""
+        hi = self.N_leaf if hi is None else hi
+        out = torch.zeros(22, device=self.dev)
+        if hi <= lo:
+            return out
+        a = self.eval_forward(lo, hi, q)
+        loss = torch.empty(4, device=self.dev)
+        gt, dist, gt16, gt8 = self.gt[lo:hi], self.dist[lo:hi], self.gt16[lo:hi], self.gt8[lo:hi]
+        ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
+                              (a["p1"], gt16, None, 0.85, 0.0)], loss)
+        c = ops.metrics3([a["p2"], a["p0"], a["p1"]], [gt, gt8, gt16], [dist, None, None], 0.5, 0.6)
+        out[0:3] = loss[0:3]
+        out[3:21] = c[0:18]
+        out[21] = a["lbits"].reshape(-1)[0]
+        return out
+
+    def weight_bits(self):
+        """Sum of the 7 quantised kernels' rate terms (identical on every rank): host float, one sync."""
+        nbits = torch.empty(7, device=self.dev)
+        lm = self.net.reconstructor.likelihood_model
+        ops.weight_rate_batch([self.layers[n].mod.kernel for n in TRUNK], None, lm.sigma, lm.mu, nbits)
+        return float(nbits.sum().item())
+
     def loss_value(self):
         """Host scalar of the last step's objective (one sync; logging only)."""
         t = self.last

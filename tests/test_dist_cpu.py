@@ -142,6 +142,67 @@ def test_epoch_driver_world2_short_and_empty_shares_reproduce_one_rank():
     assert res[1][3][3][0] == () and len(res[0][3][3][0]) == 1          # the idle rank of the last step
 
 
+class _FakeEvalEngine:
+    """Stands in for TrainEngine in NVFPCC.test_log_fields: per-block additive sums (22 floats each), a replicated
+    weight-rate term and point counts -- the structure the sharded evaluation relies on."""
+
+    def __init__(self, n):
+        rng = np.random.default_rng(21)
+        self.N_leaf = n
+        self.per_block = torch.from_numpy(rng.uniform(0.5, 2.0, size=(n, 22)))
+        self.counts = rng.integers(800, 1100, size=n).astype(np.float64)
+
+    def eval_sums(self, lo, hi, q=2):
+        return self.per_block[lo:hi].sum(0) if hi > lo else torch.zeros(22, dtype=torch.float64)
+
+    def weight_bits(self):
+        return 12345.5
+
+
+class _FakeNet:
+    @staticmethod
+    def get_network_bits():
+        return 6789.0
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import NVFPCC as cli
+    nd.init(backend="gloo")
+    eng = _FakeEvalEngine(13)
+    f = cli.test_log_fields(eng, _FakeNet, 917 * 936.0, 200.0, rank, world, nd.allreduce_sum_)
+    q.put((rank, [float(v) for v in f], cli.TEST_LINE % ((10, 0.0) + tuple(f))))
+    dist.destroy_process_group()
+
+
+def test_sharded_eval_world2_prints_the_one_rank_test_line():
+    """The every-10th-epoch evaluation (NVFPCC.py:308-392) under data parallelism: each rank evaluates its contiguous shard
+    (13 blocks on 2 ranks: 7 + 6) and one all-reduce of the 22 additive log sums gives BOTH ranks the full-batch fields;
+    the formatted TEST line equals the one-rank line character for character."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import NVFPCC as cli
+    ref = cli.test_log_fields(_FakeEvalEngine(13), _FakeNet, 917 * 936.0, 200.0)
+    ref_line = cli.TEST_LINE % ((10, 0.0) + tuple(ref))
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, fields, line in res:
+        np.testing.assert_allclose(fields, [float(v) for v in ref], rtol=1e-12)
+        assert line == ref_line
+    assert "b_all:" in ref_line and "PSNR1:" in ref_line
+
+
 def test_bench_starts_its_own_ranks(monkeypatch):
     """`python bench.py --gpus N` without a torchrun environment launches N ranks through torch.distributed.run
     (127.0.0.1 rendezvous) before touching the GPU; inside a torchrun environment it does not."""

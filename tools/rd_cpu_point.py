@@ -6,7 +6,7 @@ same way: rate (latent bits from the Gaussian model + Huffman-coded 4-bit weight
 PSNR1 at the same threshold.  SURVEY.md section 8 row f4: "an oracle-CPU-trained point beside the HIP one".
 Rounding differences are amplified by ~60 x 4 Adam steps, so the comparison is statistical, not bit-wise.
 
-    python tools/rd_cpu_point.py --blocks 12 --epochs 61 --out profiles/r03_rd_cpu_vs_hip.md      (on the GPU box)
+    python tools/rd_cpu_point.py --blocks 12 --epochs 301 --seeds 5 --out profiles/r04_rd_cpu_vs_hip.md      (on the GPU box)
 """
 import argparse
 import os
@@ -42,17 +42,9 @@ def evaluate(P, emb, gt, dist, n_points, thh):
             "Pacc": float(tpr), "Nacc": float(tnr), "points": int((out > thh).sum())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--blocks", type=int, default=12)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--epochs", type=int, default=61)
-    ap.add_argument("--phase_change", type=int, default=20)
-    ap.add_argument("--lmbda", type=float, default=200.0)
-    ap.add_argument("--thh", type=float, default=0.5)
-    ap.add_argument("--seed", type=int, default=5)
-    ap.add_argument("--out", default="")
-    a = ap.parse_args()
+def run_one(a, seed):
+    """HIP engine and CPU oracle on the same cloud, the same epoch orders and the same noise draws (all derived from
+    `seed`).  Returns (hip metrics, cpu metrics, t_hip, t_cpu, max parameter difference, max latent difference)."""
     from nvfpcc_amd import network
     from nvfpcc_amd.engine import TrainEngine, EpochDriver
     from nvfpcc_amd.model import Net
@@ -65,13 +57,13 @@ def main():
     gts, dists = make_blocks(a.blocks)
     gt, dist = torch.from_numpy(gts).float(), torch.from_numpy(dists).float()
     n_points = float(gts.sum())
-    orders = [np.random.default_rng(1000 + e).permutation(a.blocks) for e in range(a.epochs)]
+    orders = [np.random.default_rng(1000 * seed + e).permutation(a.blocks) for e in range(a.epochs)]
 
     # ---- HIP engine
     dev = torch.device("cuda", 0)
     network.reset_seed(synthetic_seed())
     net = Net(None, "Gaussian", ch, ",".join(map(str, channels)), verbose=False).to(dev)
-    eng = TrainEngine(net, gt.to(dev), dist.to(dev), n_points_total=n_points, seed=a.seed, **H)
+    eng = TrainEngine(net, gt.to(dev), dist.to(dev), n_points_total=n_points, seed=seed, **H)
     drv = EpochDriver(eng, a.batch, use_graph=True)
     t0 = time.time()
     for e in range(a.epochs):
@@ -88,8 +80,8 @@ def main():
     shapes = {t[0].split(".")[-1]: t[2] for t in O.layer_table(ch, channels)}
 
     def noise(step, ids, q):
-        u_lat = torch.from_numpy(philox_np.latent_noise(a.seed, step, list(ids), ch))
-        u_w = {n: torch.from_numpy(philox_np.weight_noise(a.seed, step, i + 1, shapes[n])) for i, n in enumerate(TRUNK)} \
+        u_lat = torch.from_numpy(philox_np.latent_noise(seed, step, list(ids), ch))
+        u_w = {n: torch.from_numpy(philox_np.weight_noise(seed, step, i + 1, shapes[n])) for i, n in enumerate(TRUNK)} \
             if q == 1 else {}
         return u_lat, u_w
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -104,20 +96,58 @@ def main():
         tr.latent_step(gt, dist, q)
     t_cpu = time.time() - t0
     cpu = evaluate({k: v.detach() for k, v in tr.P.items()}, tr.emb, gt, dist, n_points, a.thh)
-
     dp = max((P_hip[k] - tr.P[k].detach()).abs().max().item() for k in tr.keys)
     de = (eng.emb.cpu() - tr.emb.detach()).abs().max().item()
-    head = (f"HIP engine vs CPU oracle, the same training run: {a.blocks} synthetic blocks ({int(n_points)} points), batch "
-            f"{a.batch}, {a.epochs} epochs (phase change {a.phase_change}), lambda {a.lmbda:g}, w1 10, w2 57, lr 1e-3, wemb 5, "
-            f"noise seed {a.seed} (the oracle is fed the engine's counter-RNG draws); kernels rounded to 1/16, evaluation by the "
-            f"oracle's eval forward at thh {a.thh}.  max |parameter difference| after training {dp:.2e}, latent table "
-            f"{de:.2e}.\n\n")
-    rows = ["| trained by | seconds | bpp latents | bpp weights (Huffman) | PSNR1 (dB) | Pacc | Nacc | points > thh |",
-            "|---|---|---|---|---|---|---|---|"]
-    for name, t, r in (("HIP engine (1 x MI355X)", t_hip, hip), ("CPU oracle (aten, 16 threads)", t_cpu, cpu)):
-        rows.append(f"| {name} | {t:.1f} | {r['bpp_latent']:.4f} | {r['bpp_weights']:.4f} | {r['PSNR1']:.2f} | {r['Pacc']:.4f} | "
-                    f"{r['Nacc']:.4f} | {r['points']} |")
+    return hip, cpu, t_hip, t_cpu, dp, de, n_points
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--epochs", type=int, default=61)
+    ap.add_argument("--phase_change", type=int, default=20)
+    ap.add_argument("--lmbda", type=float, default=200.0)
+    ap.add_argument("--thh", type=float, default=0.5)
+    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--seeds", type=int, default=1, help="number of (noise, epoch-order) seeds: seed, seed + 1, ...")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    runs = []
+    for k in range(a.seeds):
+        r = run_one(a, a.seed + k)
+        runs.append(r)
+        print(f"seed {a.seed + k}: HIP PSNR1 {r[0]['PSNR1']:.2f} bpp {r[0]['bpp_latent'] + r[0]['bpp_weights']:.4f} | "
+              f"CPU PSNR1 {r[1]['PSNR1']:.2f} bpp {r[1]['bpp_latent'] + r[1]['bpp_weights']:.4f} | "
+              f"{r[2]:.1f} s / {r[3]:.1f} s", flush=True)
+    n_points = runs[0][6]
+    head = (f"HIP engine vs CPU oracle, the same training runs: {a.blocks} synthetic blocks ({int(n_points)} points), batch "
+            f"{a.batch}, {a.epochs} epochs (phase change {a.phase_change}), lambda {a.lmbda:g}, w1 10, w2 57, lr 1e-3, wemb 5; "
+            f"{a.seeds} seed(s) from {a.seed} (a seed fixes the noise draws AND the epoch orders; the oracle is fed the engine's "
+            f"counter-RNG draws); kernels rounded to 1/16, evaluation by the oracle's eval forward at thh {a.thh}.  Divergence "
+            f"of the two trajectories (rounding amplified by {a.epochs} x {(a.blocks + a.batch - 1) // a.batch + 1} Adam steps): max "
+            f"|parameter difference| {max(r[4] for r in runs):.2e}, latent table {max(r[5] for r in runs):.2e}.\n\n")
+    rows = ["| seed | trained by | seconds | bpp latents | bpp weights (Huffman) | bpp | PSNR1 (dB) | Pacc | Nacc | points > thh |",
+            "|---|---|---|---|---|---|---|---|---|---|"]
+    for k, (hip, cpu, t_hip, t_cpu, dp, de, _) in enumerate(runs):
+        for name, t, r in (("HIP engine (1 x MI355X)", t_hip, hip), ("CPU oracle (aten, 16 threads)", t_cpu, cpu)):
+            rows.append(f"| {a.seed + k} | {name} | {t:.1f} | {r['bpp_latent']:.4f} | {r['bpp_weights']:.4f} | "
+                        f"{r['bpp_latent'] + r['bpp_weights']:.4f} | {r['PSNR1']:.2f} | {r['Pacc']:.4f} | {r['Nacc']:.4f} | {r['points']} |")
     text = head + "\n".join(rows) + "\n"
+    if a.seeds > 1:
+        def stat(idx, key):
+            v = np.array([(r[idx]['bpp_latent'] + r[idx]['bpp_weights']) if key == 'bpp' else r[idx][key] for r in runs], np.float64)
+            return v.mean(), v.std(ddof=1)
+        srows = ["| metric | HIP mean +- sd | CPU oracle mean +- sd | HIP mean - CPU mean | within one oracle sd |", "|---|---|---|---|---|"]
+        ok_all = True
+        for key in ("PSNR1", "bpp", "Pacc", "Nacc", "points"):
+            (mh, sh), (mc, sc) = stat(0, key), stat(1, key)
+            ok = abs(mh - mc) <= sc
+            if key in ("PSNR1", "bpp"):
+                ok_all &= ok
+            srows.append(f"| {key} | {mh:.4f} +- {sh:.4f} | {mc:.4f} +- {sc:.4f} | {mh - mc:+.4f} | {'yes' if ok else 'NO'} |")
+        text += (f"\nOver the {a.seeds} seeds (sample sd, n - 1).  Pass criterion (VERDICT r3 item 5): the HIP mean of PSNR1 and of "
+                 f"bpp within one oracle sd -- **{'met' if ok_all else 'NOT met'}**.\n\n" + "\n".join(srows) + "\n")
     print(text)
     if a.out:
         with open(os.path.join(ROOT, a.out), "w") as f:
