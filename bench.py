@@ -310,7 +310,7 @@ def measure_in_step_us(args, labels):
     per, names = {lab: [] for lab in labels}, {}
     for prev, row in zip(rows, rows[1:]):
         if "uniform_kernel" in prev["Kernel_Name"]:
-            g = int(prev["Grid_Size"])
+            g = int(prev.get("Grid_Size") or prev.get("Grid_Size_X") or 0)       # threads (kernel trace: Grid_Size_X)
             lab = grids.get(g) or grids.get(g * 256)
             if lab is not None:
                 per[lab].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)

@@ -37,7 +37,7 @@ extern "C" size_t nvf_pack_wino_k4_floats(void) { return (size_t)kWinoAFloats; }
 
 struct WDims {
   int batch, units, ppc;        // work units = (block, z chunk, column group); ppc pairs per chunk
-  int dbg;                      // tuning runs only (ppc >> 8): 1 no MFMAs, 2 no emit, 4 no transform, 8 no staging; results meaningless
+  int dbg;                      // tuning runs only (ppc >> 8): 1 no MFMAs, 2 no emit, 4 no transform, 8 no staging, 16 no A copy, 32 no zero fill; results meaningless
   float* bias_part;             // optional: per unit the 8 channel sums of what it stored
 };
 
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   __shared__ __attribute__((aligned(16))) float lds[kWinoAFloats + 4 * C::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  {                                             // the A fragments: every load of a thread in flight before its first store
+  if (!(d.dbg & 16)) {                          // the A fragments: every load of a thread in flight before its first store
     constexpr int NV = kWinoAFloats / 4, NI = (NV + 255) / 256;
     float4 tmp[NI];
 #pragma unroll
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
       if (i * 256 + tid < NV) ((float4*)lds)[i * 256 + tid] = tmp[i];
   }
   float* raw = lds + kWinoAFloats + wave * C::BUF;
-  for (int i = lane; i < C::BUF; i += 64) raw[i] = 0.f;          // the margins stay zero for the whole launch
+  if (!(d.dbg & 32))
+    for (int i = lane; i < C::BUF; i += 64) raw[i] = 0.f;        // the margins stay zero for the whole launch
   __syncthreads();
   const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   const int j = lane & 15, kq = lane >> 4;
