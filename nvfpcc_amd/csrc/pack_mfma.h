@@ -18,42 +18,48 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
   if (kind == 40) {
     // Winograd (y, x) backward-data of a 4^3 conv (conv_wino.hip): [g][zw][f][lane], lane = (co, s) + 16 k, value
     // U = G w' G^T of the gather-form kernel slice kz = zw - s, G = Cook-Toom F(2, 4) on {0, 1, -1, 2, inf} with the
-    // rational factors of B^T folded in (rows / 2, / 2, / 6, / -6, 1).  One thread per (slice (ci, kz, co), fy): the 16
-    // weights of a slice are fetched once per thread (src may draw counter-RNG noise per element), five outputs each go
-    // to (zw = kz, s = 0) and (zw = kz + 1, s = 1); the entries without a tap (zw = 0, s = 1 and zw = 4, s = 0) are zeroed
+    // rational factors of B^T folded in (rows / 2, / 2, / 6, / -6, 1).  Every output of slice (ci, kz, co) goes to
+    // (zw = kz, s = 0) and (zw = kz + 1, s = 1); the entries without a tap (zw = 0, s = 1 and zw = 4, s = 0) are zeroed
     const float G[5][4] = {{0.5f, 0.f, 0.f, 0.f},
                            {0.5f, 0.5f, 0.5f, 0.5f},
                            {1.f / 6.f, -1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
                            {-1.f / 6.f, -2.f / 6.f, -4.f / 6.f, -8.f / 6.f},
                            {0.f, 0.f, 0.f, 1.f}};
-    for (int t = bx * blockDim.x + threadIdx.x; t < 256 * 5 + 3200; t += nbx * blockDim.x) {
-      if (t < 256 * 5) {
-        const int fy = t % 5, sl = t / 5, cog = sl % 8, kz = (sl / 8) % 4, ci = sl / 32, g = ci / 4, k = ci % 4;
-        float row[4][5];
-        for (int ky = 0; ky < 4; ++ky) {
-          float w4[4];
-          for (int kx = 0; kx < 4; ++kx) w4[kx] = src(job, (ci * 64 + (kz * 4 + ky) * 4 + kx) * 8 + cog);
-          for (int fx = 0; fx < 5; ++fx) {
-            float r = 0.f;
-            for (int kx = 0; kx < 4; ++kx) r = fmaf(G[fx][kx], w4[kx], r);
-            row[ky][fx] = r;
-          }
-        }
+    // four lanes per slice: lane ky fetches the four weights of its kernel row (src may draw counter-RNG noise per
+    // element: 4 draws per thread, not 16), transforms the row along x, and the quad exchanges rows by shuffles; lane ky
+    // then produces the outputs of fy = ky (lane 0 also fy = 4).  Same arithmetic as one thread per (slice, fy).
+    const int nthreads = nbx * blockDim.x;                       // a multiple of 64: whole quads
+    for (int t = bx * blockDim.x + threadIdx.x; t < 256 * 4; t += nthreads) {        // quads are whole: in or out together
+      const int ky = t & 3, sl = t >> 2, cog = sl % 8, kz = (sl / 8) % 4, ci = sl / 32, g = ci / 4, k = ci % 4;
+      float w4[4], mine[5];
+      for (int kx = 0; kx < 4; ++kx) w4[kx] = src(job, (ci * 64 + (kz * 4 + ky) * 4 + kx) * 8 + cog);
+      for (int fx = 0; fx < 5; ++fx) {
+        float r = 0.f;
+        for (int kx = 0; kx < 4; ++kx) r = fmaf(G[fx][kx], w4[kx], r);
+        mine[fx] = r;
+      }
+      float row[4][5];
+      for (int q = 0; q < 4; ++q)
+        for (int fx = 0; fx < 5; ++fx) row[q][fx] = __shfl(mine[fx], (threadIdx.x & ~3) + q, 64);
+      for (int pass = 0; pass < 2; ++pass) {
+        const int fy = pass == 0 ? ky : 4;
+        if (pass == 1 && ky != 0) break;
         for (int fx = 0; fx < 5; ++fx) {
           float v = 0.f;
-          for (int ky = 0; ky < 4; ++ky) v = fmaf(G[fy][ky], row[ky][fx], v);
+          for (int q = 0; q < 4; ++q) v = fmaf(G[fy][q], row[q][fx], v);
           const int f = fy * 5 + fx;
           wp[((g * 5 + kz) * 25 + f) * 64 + 16 * k + 2 * cog] = v;
           wp[((g * 5 + kz + 1) * 25 + f) * 64 + 16 * k + 2 * cog + 1] = v;
         }
-      } else {
-        int r = t - 256 * 5;
-        const int cog = r % 8; r /= 8;
-        const int k = r % 4; r /= 4;
-        const int f = r % 25; r /= 25;
-        const int g = r % 2, s1 = r / 2;                      // s1 = 1: (zw 0, s 1); 0: (zw 4, s 0)
-        wp[((g * 5 + (s1 ? 0 : 4)) * 25 + f) * 64 + 16 * k + 2 * cog + s1] = 0.f;
       }
+    }
+    for (int r0 = bx * blockDim.x + threadIdx.x; r0 < 3200; r0 += nthreads) {
+      int r = r0;
+      const int cog = r % 8; r /= 8;
+      const int k = r % 4; r /= 4;
+      const int f = r % 25; r /= 25;
+      const int g = r % 2, s1 = r / 2;                      // s1 = 1: (zw 0, s 1); 0: (zw 4, s 0)
+      wp[((g * 5 + (s1 ? 0 : 4)) * 25 + f) * 64 + 16 * k + 2 * cog + s1] = 0.f;
     }
     return;
   }
