@@ -108,14 +108,25 @@ def main():
                 pack = pickle.load(open(f"pack_{tagq}.pk", "rb"))
                 bits_lat = 8 * len(pack["latent_pack"]["latent_byte_stream"])
                 bits_net = 8 * len(pack["net_weight_pack"]["bit_stream"])
+                # what a degenerate row is: said in the table, not left to the reader
+                if qp != 16:
+                    note = ("qp != 16: the decoder's forward re-rounds every kernel to the 1/16 grid (network.py:611-620, "
+                            "q = 2) whatever grid the checkpoint was stored on, so it runs weights it was not trained "
+                            "with -- collapse expected, the reference behaves the same")
+                elif len(dec) == 0:
+                    note = "no probability above thh: this lambda trains a flatter occupancy, the threshold is too high for it"
+                elif len(dec) > 1.5 * n_pts:
+                    note = f"over-decoded ({len(dec) / n_pts:.1f} x the input points): thh too low for this lambda"
+                else:
+                    note = ""
                 rows.append((lam, qp, thh, (bits_lat + bits_net) / n_pts, bits_lat / n_pts, bits_net / n_pts, psnr1,
-                             d1_psnr(pts, dec) if len(dec) else float("nan"), len(dec), same, t_train))
+                             d1_psnr(pts, dec) if len(dec) else float("nan"), len(dec), same, t_train, note))
                 print(rows[-1])
-    lines = ["| lambda | qp | thh | bpp | bpp latents | bpp weights | PSNR1 (dB) | D1 PSNR sym. (dB) | decoded points | rc_enc == rc_dec | train s |",
-             "|---|---|---|---|---|---|---|---|---|---|---|"]
+    lines = ["| lambda | qp | thh | bpp | bpp latents | bpp weights | PSNR1 (dB) | D1 PSNR sym. (dB) | decoded points | rc_enc == rc_dec | train s | note |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         lines.append(f"| {r[0]:g} | {r[1]} | {r[2]:g} | {r[3]:.4f} | {r[4]:.4f} | {r[5]:.4f} | {r[6]:.2f} | {r[7]:.2f} | {r[8]} | "
-                     f"{r[9]} | {r[10]:.0f} |")
+                     f"{r[9]} | {r[10]:.0f} | {r[11]} |")
     table = "\n".join(lines)
     head = (f"RD sweep on a synthetic 10-bit surface: {n_pts} points, {n_blk} level-5 cubes; ch={a.ch}, chanstr={a.chanstr}, "
             f"{a.epochs} epochs (phase change {a.phase_change}), batch 16, lr 1e-3, w1 10, w2 57, wemb {a.wemb:g}, weights on "
