@@ -183,7 +183,8 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     ref0 = ops.wgrad(g5, y4, 4, 1, 0, out_mode=0)
     assert (outs[0] - ref0).abs().max().item() < 2e-5 * ref0.abs().max().item()
     assert torch.equal(outs[1], ops.wgrad(y3, g4, 5, 2, 0, out_mode=0))
-    assert torch.equal(outs[2], ops.wgrad(g3, y2, 4, 1, 0, out_mode=0))
+    ref2 = ops.wgrad(g3, y2, 4, 1, 0, out_mode=0)                  # conv1: direct form by default (NVF_WGRAD_WINO1=1: Winograd)
+    assert (outs[2] - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
     # ... and so do up1 + conv0
     y1, g2 = R(B, 16, 8, 8, 8), R(B, 8, 19, 19, 19)
     h0, g1 = R(B, 8, 4, 4, 4), R(B, 16, 8, 8, 8)
@@ -197,7 +198,7 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     wg.add_trunk5([g5, y3, g3, y1, h0], [y4, g4, y2, g2, g1], outs5)
     wg.finish()
     for i, (got, ref) in enumerate(zip(outs5, outs + outs2)):
-        if i in (0, 3):     # conv2 (Winograd form: the same arithmetic in both launches, but other work items per
+        if i in (0, 2, 3):  # conv2, conv1 (Winograd form: the same arithmetic in both launches, but other work items per
             # workgroup) and up1 (on the matrix cores inside the five-gradient launch): another summation order
             assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
         else:
