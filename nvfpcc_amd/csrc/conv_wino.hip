@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   if (!(d.dbg & 32))
     for (int i = lane; i < C::BUF; i += 64) raw[i] = 0.f;        // the margins stay zero for the whole launch
   __syncthreads();
-  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  // XCD k (workgroups k, k + 8, ...) takes a CONTIGUOUS range of work units: neighbouring column groups and z chunks of a
+  // block share input rows / planes, and each XCD has its own L2 (round-robin units made every XCD fetch every block)
+  const int per = (int)(gridDim.x >> 3);                         // the grid is a multiple of 8
+  const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
   const int j = lane & 15, kq = lane >> 4;
   if (unit >= d.units) {
     if (d.bias_part && j == 0) { d.bias_part[(size_t)unit * 8 + 2 * kq] = 0.f; d.bias_part[(size_t)unit * 8 + 2 * kq + 1] = 0.f; }
@@ -322,7 +326,7 @@ static int launch_wino(const float* x, const float* wp, float* y, const float* a
   if (ppc & 1) return NVF_EINVAL;       // chunks start at even pairs (two alternating accumulator sets)
   const int nchunk = (C::NPAIR + ppc - 1) / ppc;
   WDims d{batch, batch * nchunk * C::NCG, ppc, dbg, bias_part};
-  const int grid = (d.units + 3) / 4;
+  const int grid = ((d.units + 3) / 4 + 7) / 8 * 8;      // a multiple of the 8 XCDs (idle workgroups write zero partials)
   if (bias_nparts) *bias_nparts = grid * 4;
   conv_k4_wino<C, EPI><<<grid, 256, 0, s>>>(x, wp, y, aux, d);
   return NVF_OK;

@@ -514,7 +514,8 @@ static int wino_items(WgDims& d, int batch, int zsplit, int cap, int ngrp = WgWi
   const int quads = (d.items + 3) / 4;                         // a workgroup's four waves take one walker each per round
   int n = quads < cap ? quads : cap;
   d.items_per_wg = (quads + n - 1) / n * 4;
-  return (d.items + d.items_per_wg - 1) / d.items_per_wg;
+  d.tiles_y = (d.items + d.items_per_wg - 1) / d.items_per_wg;      // workgroups of the job (XCD-local item ranges)
+  return d.tiles_y;
 }
 
 // dW [8][8][4][4][4] (and, optional, db [8] = channel sums of dy) of conv2 from dy [batch, 8, 32^3] and x [batch, 8, 35^3]

@@ -70,7 +70,11 @@ __device__ __forceinline__ void wgrad_k4_wino_body(const float* __restrict__ g, 
     ldsg[k] = c * GCS + r * GRS + col;
   }
   const int zsplit = d.tiles_z > 0 ? d.tiles_z : 1;            // z steps of a (block, tile group) shared by this many items
-  const int first = bx * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
+  // XCD-local work: workgroups bx, bx + 8, ... share an XCD (and its L2); they take consecutive item ranges, i.e. the
+  // neighbouring tile groups of the same blocks, when the job's workgroup count d.tiles_y is a multiple of 8
+  const int nwg = d.tiles_y;
+  const int bxl = (nwg > 0 && nwg % 8 == 0) ? (bx & 7) * (nwg >> 3) + (bx >> 3) : bx;
+  const int first = bxl * d.items_per_wg, last = min(first + d.items_per_wg, d.items);
 #pragma unroll 1
   for (int item = first + wave; item < last; item += 4) {
     const int it = __builtin_amdgcn_readfirstlane(item);
