@@ -199,3 +199,30 @@ def test_other_channel_strings_match_the_oracle_or_refuse(ch, channels, gpu):
     p_all = eng.eval_forward(q=2)["p2"]
     one = eng.eval_forward(lo=3, hi=4, q=2)["p2"]
     assert torch.equal(one[0], p_all[3])
+
+
+def test_winograd_step_equals_the_direct_step(gpu, monkeypatch):
+    """Round 4 runs the 4^3 layers of a TRAINING step in a reduced-multiplication (Winograd) form.  With the engine's
+    switch off (NVF_WINO=0: conv2's forward and backward-data and conv1's backward-data through the direct fixed-order
+    kernels of rounds 1-3) the same step must give the same probabilities, loss and gradients to rounding -- and the EVAL
+    forward must not depend on the switch at all, bit for bit (it never uses the Winograd kernels).  (conv2's weight
+    gradient inside the five-gradient launch is switched by NVF_WGRAD_WINO, read once per process by the library: its two
+    forms are compared by tests/test_gpu_ops.py::test_wgrad_k4_wino and ::test_three_mfma_weight_gradients_in_one_launch.)"""
+    from nvfpcc_amd import engine as E
+    got = {}
+    for wino in (True, False):
+        monkeypatch.setattr(E, "_WINO", wino)
+        net, eng, P, gt, dist, emb = make(gpu, 3, (8, 16, 8, 8), 24)
+        assert (eng.layers["conv2"].wp_w is not None) == wino and (eng.layers["conv2"].wp_wf is not None) == wino
+        ids = np.arange(16)
+        a = eng.train_step(ids, 1, update=False)
+        ev = eng.eval_forward(lo=0, hi=5, q=2)["p2"].clone()
+        got[wino] = (a["p2"].clone(), eng.loss_value(), eng.flat_g.clone(), ev)
+    (p_w, l_w, g_w, e_w), (p_d, l_d, g_d, e_d) = got[True], got[False]
+    assert torch.equal(e_w, e_d)
+    assert float((p_w - p_d).abs().max()) < 1e-5
+    assert abs(l_w - l_d) < 2e-5 * abs(l_d)
+    for name, (off, n) in eng.slices.items():
+        ref = g_d[off:off + n]
+        err = float((g_w[off:off + n] - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+        assert err < 2e-5, (name, err)
