@@ -40,7 +40,7 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       }
       float row[4][5];
       for (int q = 0; q < 4; ++q)
-        for (int fx = 0; fx < 5; ++fx) row[q][fx] = __shfl(mine[fx], (threadIdx.x & ~3) + q, 64);
+        for (int fx = 0; fx < 5; ++fx) row[q][fx] = __shfl(mine[fx], (int)((threadIdx.x & 63u) & ~3u) + q, 64);
       for (int pass = 0; pass < 2; ++pass) {
         const int fy = pass == 0 ? ky : 4;
         if (pass == 1 && ky != 0) break;
