@@ -1034,11 +1034,11 @@ class GraphedTrainStep:
                       nbits_scale=1.0 / eng.n_points_total, counts=eng.step_counts if stats else None,
                       acc=eng.epoch_acc, done=eng._tail_done, sched=(self.buf, self.rows, self.cursor, self.nw))
 
-    def load_schedule(self, steps):
-        """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
-        CAP) -- or the same as two arrays (ids [n, batch] int64 ndarray, n_pts [n] ndarray).  One host-to-device copy
-        for all of them; Adam / noise counters continue from the engine's.  Nothing is touched before the input has been
-        validated."""
+    def stage_schedule(self, steps):
+        """Host half of load_schedule: validates `steps` and fills the rows (block ids, noise steps, rate and Adam
+        coefficients continuing from the engine's counters) into a pinned staging buffer; nothing reaches the device and no
+        engine state changes.  Returns a handle for load_schedule -- valid while the engine's step counters and learning rate
+        stay what they were (a training loop can prepare the next epoch's schedule while the GPU still runs this one)."""
         eng, B, nw = self.eng, self.batch, self.nw
         # the arrays form is recognised by its first member being a 2-D ndarray (a tuple of two (ids, n_pts) pairs is a
         # two-step list, not the arrays form)
@@ -1051,15 +1051,15 @@ class GraphedTrainStep:
             npts = np.array([float(eng.counts[ids_all[k]].sum()) if p is None else float(p)
                              for k, (_, p) in enumerate(steps)], np.float64)
         n = ids_all.shape[0]
-        if not (0 < n <= self.CAP) or self.pending:
-            raise ValueError("load_schedule: 1..%d steps, and only after every loaded step has been replayed" % self.CAP)
+        if not (0 < n <= self.CAP):
+            raise ValueError("load_schedule: 1..%d steps" % self.CAP)
         if ids_all.shape != (n, B) or npts.shape != (n,):
             raise ValueError("load_schedule: ids must be [n, %d] and n_pts [n]; got %s, %s" % (B, ids_all.shape, npts.shape))
         slot = self.loads % len(self.pins)
         self.loads += 1
         if self.pin_events[slot] is not None:
             self.pin_events[slot].synchronize()
-        pin, host = self.pins[slot], self.pin_np[slot]
+        host = self.pin_np[slot]
         # the rows are filled as ONE NumPy array (per-element writes into a torch tensor cost ~10 us each: milliseconds per
         # epoch of host time that a short timed region would see)
         rows = host[nw + 2:nw + 2 + (n + 1) * nw].reshape(n + 1, nw)      # written in place (pinned memory)
@@ -1072,9 +1072,23 @@ class GraphedTrainStep:
         rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
         host[:nw] = rows[0]                       # the step buffer starts as row 0 ...
         host[nw], host[nw + 1] = 1, 0             # ... and the cursor at 1: the tail of the first step fetches row 1
-        self.pending.extend(npts.tolist())
-        m = nw + 2 + (n + 1) * nw
-        self.sched[:m].copy_(pin[:m], non_blocking=True)
+        return {"_staged": True, "slot": slot, "n": n, "npts": npts.tolist(), "words": nw + 2 + (n + 1) * nw,
+                "state": (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1)}
+
+    def load_schedule(self, steps):
+        """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
+        CAP) -- or the same as two arrays (ids [n, batch] int64 ndarray, n_pts [n] ndarray) -- or a handle from
+        stage_schedule.  One host-to-device copy for all of them; Adam / noise counters continue from the engine's.
+        Nothing is touched before the input has been validated."""
+        eng = self.eng
+        if self.pending:
+            raise ValueError("load_schedule: only after every loaded step has been replayed")
+        h = steps if (isinstance(steps, dict) and steps.get("_staged")) else self.stage_schedule(steps)
+        if h["state"] != (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1):
+            raise ValueError("load_schedule: the staged schedule was made for other step counters / coefficients")
+        slot, m = h["slot"], h["words"]
+        self.pending.extend(h["npts"])
+        self.sched[:m].copy_(self.pins[slot][:m], non_blocking=True)
         ev = self.pin_events[slot]
         if ev is None:
             ev = self.pin_events[slot] = torch.cuda.Event()
@@ -1095,23 +1109,31 @@ class GraphedTrainStep:
         return self.out
 
     def replay_all(self):
-        """Run every loaded step: through the largest unrolled graphs that fit, the rest one by one."""
+        """Run every loaded step: the run of n steps is cut greedily into the largest unrolled graphs that fit (57 = 16 + 16
+        + 16 + 8 + 1) and replayed SMALLEST FIRST: launching a graph costs the host time that grows with its node count, and
+        only the first launch of a run is exposed (the later ones are issued while the GPU is busy) -- so the first one
+        should be the cheapest (a 20-step timed region: 4 + 16 instead of 16 + 4)."""
         eng = self.eng
+        n, sizes = len(self.pending), []
         for U in self.unrolls:
-            if U not in self.graphs_u:
+            if U in self.graphs_u:
+                while n >= U:
+                    sizes.append(U)
+                    n -= U
+        sizes += [1] * n
+        for U in reversed(sizes):
+            if U == 1:
+                self.replay()
                 continue
             g, out, last = self.graphs_u[U]
-            while len(self.pending) >= U:
-                n_pts = self.pending[U - 1]
-                del self.pending[:U]
-                eng.noise_step += U
-                eng.opt_step += U
-                g.replay()
-                self.out, self.last = out, last
-                eng.last = dict(self.last)
-                eng.last["n_pts"] = n_pts
-        while self.pending:
-            self.replay()
+            n_pts = self.pending[U - 1]
+            del self.pending[:U]
+            eng.noise_step += U
+            eng.opt_step += U
+            g.replay()
+            self.out, self.last = out, last
+            eng.last = dict(self.last)
+            eng.last["n_pts"] = n_pts
         return self.out
 
     def prime(self):
