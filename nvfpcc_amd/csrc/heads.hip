@@ -89,7 +89,7 @@ struct HPCfg {
   static constexpr int WORDS = IZ * IY * S;            // one channel's tile
   static constexpr int NACT = TZ * TY * XG;            // one thread per four outputs
   static constexpr int NT = 256, NW = 4;
-  static constexpr int NIT = (WORDS + NT - 1) / NT;    // DMA instructions per wave per channel
+  static constexpr int NIT = (WORDS + NT - 1) / NT;    // (dword DMA instructions per wave per channel: no longer used)
   static_assert(S % 4 == 0 && NACT <= NT && NACT % 64 == 0 && WORDS % 4 == 0, "tile");
 };
 template <class H>
@@ -110,32 +110,40 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const
   const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
   for (int i = tid; i < C * 9 * 4; i += NT) ws[i] = (i & 3) < 3 ? w[(i >> 2) * 3 + (i & 3)] : 0.f;
-  // which element of a channel volume each of this lane's DMA instructions fetches (the same for every channel)
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xs;
-  unsigned soff[NIT];
-  bool sok[NIT];
+  // which 16-byte piece of a channel volume each of this lane's DMA instructions fetches (the same for every channel).
+  // global_load_lds_dwordx4: a wave-instruction moves 1 KiB (64 lanes x 16 B, LDS destination = wave base + 16 lane); the
+  // tile image is rows of S words with nothing between them, so 64 consecutive pieces are 64 consecutive LDS quadwords;
+  // the per-lane SOURCE follows the (z, y) of the piece's row.  (The dword form was four times the instructions: the
+  // DMA issue rate, not its latency, bound this kernel.)
+  constexpr int NPC = WORDS / 4, NI4 = (NPC + NT - 1) / NT;       // pieces per channel tile, instructions per wave
+  unsigned soff[NI4];
+  bool sok[NI4];
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int wd = (i * H::NW + wave) * 64 + lane;
+  for (int i = 0; i < NI4; ++i) {
+    const int pc = i * NT + tid, wd = 4 * pc;
     const int r = wd / S, xx = wd - r * S, yi = r % IY, zi = r / IY;
     const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
-    const bool live = wd < WORDS;
+    const bool live = pc < NPC;
     sok[i] = live && gz >= 0 && gz < S && gy >= 0 && gy < S;
-    soff[i] = sok[i] ? (unsigned)((gz * S + gy) * S + xx) * 4u : 0u;
+    soff[i] = sok[i] ? (unsigned)((gz * S + gy) * S + xx) : 0u;
     if (live && !sok[i]) {
 #pragma unroll
-      for (int q = 0; q < 2 * CPS; ++q) xs[q * WORDS + wd] = 0.f;
+      for (int q = 0; q < 2 * CPS; ++q) *(float4*)(xs + q * WORDS + wd) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const float* xb = x + (size_t)b * C * S * S * S;
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
   auto stage = [&](int step, int buf) {
 #pragma unroll
     for (int cc = 0; cc < CPS; ++cc) {
-      const float* src = nvf_uniform_ptr(xb + (size_t)(step * CPS + cc) * S * S * S);
+      const float* src = xb + (size_t)(step * CPS + cc) * S * S * S;
 #pragma unroll
-      for (int i = 0; i < NIT; ++i)
-        if (sok[i])
-          nvf_glds_row(src, soff[i], lds0 + (unsigned)((buf * CPS + cc) * WORDS + (i * H::NW + wave) * 64) * 4u);
+      for (int i = 0; i < NI4; ++i) {
+        // wave-uniform LDS base of this instruction's 64 pieces
+        float* dst = xs + (buf * CPS + cc) * WORDS + (i * NT + wave * 64) * 4;
+        if (sok[i]) __builtin_amdgcn_global_load_lds((glb_vp)(src + soff[i]), (lds_vp)dst, 16, 0, 0);
+      }
     }
   };
   stage(0, 0);
