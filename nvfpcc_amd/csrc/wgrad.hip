@@ -522,7 +522,7 @@ static int wino_items(WgDims& d, int batch, int zsplit, int cap, int ngrp = WgWi
 // in the Winograd form: one launch of partial slabs + the fixed-order reduction.  workspace: 512 slabs of 4096 + 8 floats.
 extern "C" int nvf_wgrad_k4_wino(const float* dy, const float* x, float* dw, float* db, void* workspace,
                                  size_t workspace_bytes, int batch, int zsplit, void* stream) {
-  if (!dy || !x || !dw || !workspace || batch <= 0) return NVF_EINVAL;
+  if (!dy || !x || !dw || !workspace || batch <= 0 || zsplit < 1 || zsplit > 8) return NVF_EINVAL;
   if (workspace_bytes < (size_t)kMaxSlabs * (4096 + 8) * sizeof(float)) return NVF_EWORKSPACE;
   WgDims d{};
   d.batch = batch; d.bc = 8;
