@@ -53,6 +53,10 @@ int nvf_version(void);
 typedef struct NvfStepCtx NvfStepCtx;
 size_t nvf_step_ctx_bytes(void);
 int nvf_step_ctx_init(NvfStepCtx* ctx);
+/* on != 0: launches given this context keep the direct summation order (no Winograd form of a weight gradient): the
+ * arithmetic that follows the reference's training trajectory to 1e-7 (torch's conv backward, NVFPCC.py:164-172);
+ * 0 (default): the reduced-multiplication forms, statistically equivalent training. */
+int nvf_step_ctx_set_direct(NvfStepCtx* ctx, int on);
 
 /* Adam fused into the launch that produces a gradient: an element g_base[i] written by that launch is followed by the
  * nvf_step_tail update of p_base[i], m_base[i], v_base[i] (same coefficients, same arithmetic, same non-finite rule;

@@ -21,6 +21,7 @@ PROTOTYPES = {
     "nvf_version": (I, []),
     "nvf_step_ctx_bytes": (Z, []),
     "nvf_step_ctx_init": (I, [P]),
+    "nvf_step_ctx_set_direct": (I, [P, I]),
     "nvf_pack_conv_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_pack_convT_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_effective_params": (I, [P, P, P, P, I, P, P, P, I, I, U, U, P]),

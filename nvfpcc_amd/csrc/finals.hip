@@ -90,6 +90,15 @@ extern "C" int nvf_step_ctx_init(NvfStepCtx* ctx) {
   return NVF_OK;
 }
 
+// on != 0: every launch that takes this context keeps the DIRECT arithmetic (no Winograd form of a weight gradient,
+// whatever NVF_WGRAD_WINO says) -- the summation order that reproduces the reference's training trajectory to 1e-7
+// (tests/test_gpu_engine.py, the trajectory golden); 0 (the state after nvf_step_ctx_init): the faster forms.
+extern "C" int nvf_step_ctx_set_direct(NvfStepCtx* ctx, int on) {
+  if (!nvf_ctx_ok(ctx)) return NVF_EINVAL;
+  ctx->direct_forms = on ? 1 : 0;
+  return NVF_OK;
+}
+
 // Start queueing the final passes of nvf_focal_loss_multi, nvf_wgrad_reduce_multi_and_sums / nvf_multi_channel_sum
 // and nvf_weight_rate_batch issued with this context (at most one of each kind; a second one is launched as usual).
 // NVF_EINVAL: not an initialised context, or a queue is already open on it.

@@ -13,7 +13,7 @@ struct NvfStepCtx {
   uint32_t magic;
   int32_t deferring;
   int32_t tail_pending;
-  int32_t reserved;
+  int32_t direct_forms;   // nonzero: every launch given this context keeps the direct (non-Winograd) arithmetic
   FinalsArgs args;
   LatentTail tail;
 };

@@ -927,7 +927,8 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     // work items (default 1 = 256 workgroups at batch 16: step 0.375 ms against 0.3825 with 2 and 0.3886 for the direct form)
     static int wino = -1;
     if (wino < 0) { const char* e = getenv("NVF_WGRAD_WINO"); wino = e ? atoi(e) : 1; if (wino > 8) wino = 8; }
-    if (j == 0 && wino > 0) {
+    const bool direct = nvf_ctx_ok(ctx) && ctx->direct_forms;   // nvf_step_ctx_set_direct: the caller's choice wins
+    if (j == 0 && wino > 0 && !direct) {
       static int wcap = 0;
       if (!wcap) { const char* e = getenv("NVF_WGRAD_WINO_CAP"); wcap = e ? atoi(e) : 512; if (wcap < 1 || wcap > 512) wcap = 512; }
       n = wino_items(d, batch, wino, wcap);
@@ -937,7 +938,7 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     // reference's (entries whose gradient is rounding noise take Adam's first steps with the other sign)
     static int wino1 = -1;
     if (wino1 < 0) { const char* e = getenv("NVF_WGRAD_WINO1"); wino1 = e ? atoi(e) : 0; }
-    if (j == 2 && wino1 > 0) n = wino_items(d, batch, 1, cap, WgWino1::NGRP);
+    if (j == 2 && wino1 > 0 && !direct) n = wino_items(d, batch, 1, cap, WgWino1::NGRP);
     if (bias_slabs && j != 1) d.bias_slab = bias_slabs[j];     // conv2 (job 0) and conv1 (job 2): p = dY
     m.d[j] = d; m.n[j] = n; nslabs[j] = n;
   }

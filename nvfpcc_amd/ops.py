@@ -65,6 +65,10 @@ class StepCtx:
         self._retired = []  # outgrown workspaces (see workspace())
         check(lib().nvf_step_ctx_init(self.ptr), "nvf_step_ctx_init")
 
+    def set_direct(self, on=True):
+        """Launches given this context keep the direct summation order (nvf_step_ctx_set_direct)."""
+        check(lib().nvf_step_ctx_set_direct(self.ptr, int(bool(on))), "nvf_step_ctx_set_direct")
+
     def begin(self):
         """Queue the final passes of focal_loss_multi / heads3_loss_bwd_data / WgradBatch.finish_with_sums /
         weight_rate_batch / metrics issued with this context (their outputs exist only after flush())."""
