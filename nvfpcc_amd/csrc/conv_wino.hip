@@ -33,6 +33,11 @@ typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWinoAFloats = 2 * 5 * 25 * 64;     // [g][zw][f][lane]
 
+#ifndef NVF_WINO_DBG
+#define NVF_WINO_DBG 0        // tuning builds (tools/ab_build.py .. -DNVF_WINO_DBG=1): WDims::dbg switches phases off.  In the
+#endif                        // regular build the switches are compiled out (as run-time tests they cost 150 moves per step)
+#define WDBG(bit) (NVF_WINO_DBG && (d.dbg & (bit)))
+
 extern "C" size_t nvf_pack_wino_k4_floats(void) { return (size_t)kWinoAFloats; }
 
 struct WDims {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   __shared__ __attribute__((aligned(16))) float lds[kWinoAFloats + 4 * C::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (!(d.dbg & 16)) {                          // the A fragments: every load of a thread in flight before its first store
+  if (!WDBG(16)) {                          // the A fragments: every load of a thread in flight before its first store
     constexpr int NV = kWinoAFloats / 4, NI = (NV + 255) / 256;
     float4 tmp[NI];
 #pragma unroll
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
       if (i * 256 + tid < NV) ((float4*)lds)[i * 256 + tid] = tmp[i];
   }
   float* raw = lds + kWinoAFloats + wave * C::BUF;
-  if (!(d.dbg & 32))
+  if (!WDBG(32))
     for (int i = lane; i < C::BUF; i += 64) raw[i] = 0.f;        // the margins stay zero for the whole launch
   __syncthreads();
   // XCD k (workgroups k, k + 8, ...) takes a CONTIGUOUS range of work units: neighbouring column groups and z chunks of a
@@ -125,14 +130,14 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   // plane offset is forced into an SGPR or every load becomes a waterfall loop)
   auto fetch = [&](int p) {
     const int pz = p - PAD;
-    if (d.dbg & 8) return;
+    if (WDBG(8)) return;
     const bool pin = pz >= 0 && pz < DIN;
     const int so = __builtin_amdgcn_readfirstlane(pin ? pz * DIN * DIN * 4 : 0);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) st[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pin ? voff[k] : 0x7ffffff0, so, 0);
   };
   auto commit = [&]() {
-    if (d.dbg & 8) return;
+    if (WDBG(8)) return;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       if (ldst[k] < 0) continue;
@@ -162,27 +167,33 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   auto transform = [&](auto gi, float (&V)[25]) {
     constexpr int G = decltype(gi)::value;
     const float* p = win + G * 4 * CS;
-    if (d.dbg & 4) {
+    if (WDBG(4)) {
 #pragma unroll
       for (int f = 0; f < 25; ++f) V[f] = 1.f + f;
       return;
     }
-    float e[5][5];
+    // y pass on the packed pipe: the window's x pairs (0,1) and (2,3) are the 8-byte LDS reads themselves; then the x
+    // pass row by row (wino_common.h)
+    wino_f2 a[5], bb[5], ea[5], eb[5];
+    float c[5], ec[5];
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy) {
-      const float2 a = *(const float2*)(p + dy * RS), bb = *(const float2*)(p + dy * RS + 2);
-      const float c = p[dy * RS + 4];
-      wino_bt(a.x, a.y, bb.x, bb.y, c, e[dy][0], e[dy][1], e[dy][2], e[dy][3], e[dy][4]);
+      a[dy] = *(const wino_f2*)(p + dy * RS);
+      bb[dy] = *(const wino_f2*)(p + dy * RS + 2);
+      c[dy] = p[dy * RS + 4];
     }
+    wino_bt2(a[0], a[1], a[2], a[3], a[4], ea[0], ea[1], ea[2], ea[3], ea[4]);
+    wino_bt2(bb[0], bb[1], bb[2], bb[3], bb[4], eb[0], eb[1], eb[2], eb[3], eb[4]);
+    wino_bt(c[0], c[1], c[2], c[3], c[4], ec[0], ec[1], ec[2], ec[3], ec[4]);
 #pragma unroll
-    for (int fx = 0; fx < 5; ++fx)
-      wino_bt(e[0][fx], e[1][fx], e[2][fx], e[3][fx], e[4][fx], V[fx], V[5 + fx], V[10 + fx], V[15 + fx], V[20 + fx]);
+    for (int fy = 0; fy < 5; ++fy)
+      wino_bt_row(ea[fy], eb[fy], ec[fy], V[5 * fy], V[5 * fy + 1], V[5 * fy + 2], V[5 * fy + 3], V[5 * fy + 4]);
   };
   auto mfma25 = [&](auto slot, auto zwc, auto gi, const float (&V)[25]) {
     constexpr int S = decltype(slot)::value, ZW = decltype(zwc)::value, G = decltype(gi)::value;
     constexpr bool FIRST = ZW == 0 && G == 0;       // the first block of a pair starts from zero: no clearing pass
     const float* ap = abase + (G * 5 + ZW) * 25 * 64;
-    if (d.dbg & 1) return;
+    if (WDBG(1)) return;
     __builtin_amdgcn_sched_barrier(0);        // keeps the A reads of other (slot, tap) blocks out of this one: registers
 #pragma unroll
     for (int f = 0; f < 25; ++f)
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   // A^T M A per row, ReLU mask, stores, channel sums (a masked-out or out-of-range output is 0 and adds nothing)
   auto emit = [&](auto slot, int q) {
     constexpr int S = decltype(slot)::value;
-    if (d.dbg & 2) return;
+    if (WDBG(2)) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float c[2][5];

@@ -122,29 +122,37 @@ __device__ __forceinline__ void wgrad_k4_wino_body(const float* __restrict__ g, 
       if (more) { load_g(z + 2); load_x(z + 4); }
       const float* gp = gr + sa * GPS + ch * GCS + 2 * kq;
       const float* xp = xr + sb * XPS + ch * XCS + 2 * kq;
-      const float2 g0 = *(const float2*)gp, g1 = *(const float2*)(gp + GRS);
-      float e[5][5];
-#pragma unroll
-      for (int dy = 0; dy < 5; ++dy) {
-        const float2 a = *(const float2*)(xp + dy * XRS), bb = *(const float2*)(xp + dy * XRS + 2);
-        const float c = xp[dy * XRS + 4];
-        wino_bt(a.x, a.y, bb.x, bb.y, c, e[dy][0], e[dy][1], e[dy][2], e[dy][3], e[dy][4]);
-      }
+      const wino_f2 g0 = *(const wino_f2*)gp, g1 = *(const wino_f2*)(gp + GRS);
+      // transforms on the packed fp32 pipe (wino_common.h): every vector instruction is SIMD time next to the MFMAs
       float Xh[25], Gh[25];
+      {
+        wino_f2 a[5], bb[5], ea[5], eb[5];
+        float c[5], ec[5];
 #pragma unroll
-      for (int fx = 0; fx < 5; ++fx)
-        wino_bt(e[0][fx], e[1][fx], e[2][fx], e[3][fx], e[4][fx], Xh[fx], Xh[5 + fx], Xh[10 + fx], Xh[15 + fx], Xh[20 + fx]);
+        for (int dy = 0; dy < 5; ++dy) {
+          a[dy] = *(const wino_f2*)(xp + dy * XRS);
+          bb[dy] = *(const wino_f2*)(xp + dy * XRS + 2);
+          c[dy] = xp[dy * XRS + 4];
+        }
+        wino_bt2(a[0], a[1], a[2], a[3], a[4], ea[0], ea[1], ea[2], ea[3], ea[4]);
+        wino_bt2(bb[0], bb[1], bb[2], bb[3], bb[4], eb[0], eb[1], eb[2], eb[3], eb[4]);
+        wino_bt(c[0], c[1], c[2], c[3], c[4], ec[0], ec[1], ec[2], ec[3], ec[4]);
+#pragma unroll
+        for (int fy = 0; fy < 5; ++fy)
+          wino_bt_row(ea[fy], eb[fy], ec[fy], Xh[5 * fy], Xh[5 * fy + 1], Xh[5 * fy + 2], Xh[5 * fy + 3], Xh[5 * fy + 4]);
+      }
       bs += (g0.x + g0.y) + (g1.x + g1.y);
       {                                                         // Gh = G g G^T, G = [1 0; 1 1; 1 -1; 1 2; 0 1]
-        const float r0[5] = {g0.x, g0.x + g0.y, g0.x - g0.y, fmaf(2.f, g0.y, g0.x), g0.y};
-        const float r1[5] = {g1.x, g1.x + g1.y, g1.x - g1.y, fmaf(2.f, g1.y, g1.x), g1.y};
+        // y pass on the pairs (x0, x1) the LDS reads return, then per row (x, x + y, x - y, x + 2 y, y)
+        const wino_f2 cy[5] = {g0, g0 + g1, g0 - g1, wino_fma2(wino_f2{2.f, 2.f}, g1, g0), g1};
 #pragma unroll
-        for (int fx = 0; fx < 5; ++fx) {
-          Gh[fx] = r0[fx];
-          Gh[5 + fx] = r0[fx] + r1[fx];
-          Gh[10 + fx] = r0[fx] - r1[fx];
-          Gh[15 + fx] = fmaf(2.f, r1[fx], r0[fx]);
-          Gh[20 + fx] = r1[fx];
+        for (int fy = 0; fy < 5; ++fy) {
+          const wino_f2 pm = wino_fma2(cy[fy].yy, wino_f2{1.f, -1.f}, cy[fy].xx);
+          Gh[5 * fy] = cy[fy].x;
+          Gh[5 * fy + 1] = pm.x;
+          Gh[5 * fy + 2] = pm.y;
+          Gh[5 * fy + 3] = fmaf(2.f, cy[fy].y, cy[fy].x);
+          Gh[5 * fy + 4] = cy[fy].y;
         }
       }
 #pragma unroll
