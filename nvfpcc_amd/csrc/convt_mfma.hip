@@ -14,6 +14,7 @@
 // classes are separate accumulators; one B fragment feeds every (plane parity, row parity) that uses it.
 // Per output the accumulation order is fixed: (ci group, jy, jx, jz).
 #include "nvf_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,13 +65,26 @@ struct TMCfg {
   static_assert((XS + AS) * 4 <= 160 * 1024, "LDS");
 };
 
+// Item -> (batch element, cell plane, column split).  A cell plane cz reads the input planes cz - jz, jz = 0..2: the two
+// first and two last cell planes have one or two of them outside the input, and those (ez, jz) blocks are skipped
+// (cost_of() fifteenths of a full plane: 6, 12 / 9, 3).  Items are ordered by cost, heaviest first, so that whatever hands
+// them out -- the dispatcher when the grid covers the items, the stride loop below otherwise -- ends on the short ones.
+template <int NIN>
+__device__ __forceinline__ void convT_item(int item, int nsplit, int batch, int& b, int& cz, int& split) {
+  constexpr int NCELL = NIN + 2;
+  split = item % nsplit;
+  b = (item / nsplit) % batch;
+  const int k = item / (nsplit * batch);                       // rank by cost: NIN - 2 full planes, then 1, NIN, 0, NIN + 1
+  cz = k < NIN - 2 ? k + 2 : (k == NIN - 2 ? 1 : (k == NIN - 1 ? NIN : (k == NIN ? 0 : NCELL - 1)));
+}
+
 // Persistent workgroups: the A fragments are fetched once per workgroup; a workgroup then walks the items
-// (batch element, cell plane cz, column split) w, w + G, w + 2 G ... with the next item's three input planes already
+// w, w + G, w + 2 G ... with the next item's three input planes already
 // in registers while this item's MFMAs issue (two workgroups share a CU and fill each other's barriers).
 template <class T>
 __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ y, int act,
-                                                       int items) {
+                                                       int items, int batch) {
   constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
                 NG = T::NG, NOUT = 2 * NIN + 3, NTH = T::NTH;
   __shared__ __attribute__((aligned(16))) float xs[T::XS];
@@ -84,7 +98,8 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
   constexpr int NX4 = (ITEMS + NTH - 1) / NTH;
   float4 xv[NX4];
   auto load_x = [&](int item) {
-    const int cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
+    int b, cz, split_;
+    convT_item<NIN>(item, T::NSPLIT, batch, b, cz, split_);
     const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
@@ -126,7 +141,8 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
   const size_t cstride = (size_t)NOUT * NOUT * NOUT;
   // ---- epilogue of one item: lane holds rows i = 4 kq + r -> co = 2 kq + (r >> 1), ex = r & 1 of cell p
   auto epilogue = [&](int item, const f32x4 (&res)[NCT][2][2]) {
-    const int split = item % T::NSPLIT, cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
+    int b, cz, split;
+    convT_item<NIN>(item, T::NSPLIT, batch, b, cz, split);
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
       const int tl = split * T::CPW + c * T::NW + wave;
@@ -172,33 +188,51 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
       // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
       colbase[c] = kq * CS + 16 * min(tl, NPT - 1) + j + 2 * NCELL + 2;
     }
+    // MASK: bit jz set = input plane cz - jz exists.  A skipped block would have added exact zeros, so the sums are the
+    // same bits as the unmasked loop's; the order of the remaining terms is unchanged
+    auto mfma_phase = [&](auto maskc) {
+      constexpr int MASK = decltype(maskc)::value;
 #pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
-      const float* xg = xs + g * 4 * CS;
-      const float* ag = as + g * kAPerGroup * 64 + lane;
+      for (int g = 0; g < NG; ++g) {
+        const float* xg = xs + g * 4 * CS;
+        const float* ag = as + g * kAPerGroup * 64 + lane;
 #pragma unroll
-      for (int jy = 0; jy < 3; ++jy)
+        for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
-        for (int jx = 0; jx < 3; ++jx)
+          for (int jx = 0; jx < 3; ++jx)
 #pragma unroll
-          for (int jz = 0; jz < 3; ++jz) {
-            float a[2][2];
-#pragma unroll
-            for (int ez = 0; ez < 2; ++ez)
-#pragma unroll
-              for (int ey = 0; ey < 2; ++ey)
-                a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey) ? ag[a_index(ez, ey, jz, jy, jx) * 64] : 0.f;
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-              const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // input plane cz - jz
+            for (int jz = 0; jz < 3; ++jz) {
+              if (!((MASK >> jz) & 1)) continue;
+              float a[2][2];
 #pragma unroll
               for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
                 for (int ey = 0; ey < 2; ++ey)
-                  if (jz <= 2 - ez && jy <= 2 - ey && !(NVF_CT_DBG & 1))
-                    acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
+                  a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey) ? ag[a_index(ez, ey, jz, jy, jx) * 64] : 0.f;
+#pragma unroll
+              for (int c = 0; c < NCT; ++c) {
+                const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // input plane cz - jz
+#pragma unroll
+                for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+                  for (int ey = 0; ey < 2; ++ey)
+                    if (jz <= 2 - ez && jy <= 2 - ey && !(NVF_CT_DBG & 1))
+                      acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
+              }
             }
-          }
+      }
+    };
+    {
+      int b_, cz, split_;
+      convT_item<NIN>(item, T::NSPLIT, batch, b_, cz, split_);
+      const int mask = (cz < NIN ? 1 : 0) | ((cz >= 1 && cz <= NIN) ? 2 : 0) | (cz >= 2 ? 4 : 0);     // wave-uniform
+      switch (mask) {
+        case 7: mfma_phase(std::integral_constant<int, 7>{}); break;
+        case 3: mfma_phase(std::integral_constant<int, 3>{}); break;
+        case 6: mfma_phase(std::integral_constant<int, 6>{}); break;
+        case 1: mfma_phase(std::integral_constant<int, 1>{}); break;
+        default: mfma_phase(std::integral_constant<int, 4>{}); break;
+      }
     }
     epilogue(item, acc);
   }
@@ -219,6 +253,14 @@ extern "C" int nvf_pack_convT_mfma(const float* w_fwd, int cin, int cout, float*
 
 // y[b,co,o] = act(bias[co] + sum_{ci,k : o - k = 2 i} x[b,ci,i] w[ci][k][co]), padding 0, dout = 2 din + 3.
 // NVF_EINVAL = no instantiation for this shape (the caller then uses nvf_convT3d_k5s2_fwd).
+// workgroups per launch: 512 = two resident per CU, each walking items with a stride; NVF_CT_CAP (tuning) raises it so
+// that the dispatcher hands the items out one workgroup each
+static int convT_cap() {
+  static int cap = 0;
+  if (!cap) { const char* e = getenv("NVF_CT_CAP"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
+  return cap;
+}
+
 extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const float* bias, float* y, int batch, int cin,
                                      int cout, int din, int act, int variant, void* stream) {
   if (!x || !wp || !y || batch <= 0 || cout != 8) return NVF_EINVAL;
@@ -228,8 +270,8 @@ extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const floa
   if (rc == 1 && variant == VAR && cin == CI && din == NIN) {                                          \
     using T = TMCfg<CI, NIN, NCT, NSPLIT, ##__VA_ARGS__>;                                              \
     const int items = batch * T::NCELL * NSPLIT;                                                       \
-    constexpr int cap = 512;                               /* two resident workgroups per CU */        \
-    convT_k5s2_mfma<T><<<items < cap ? items : cap, T::NTH, 0, s>>>(x, wp, bias, y, act, items);       \
+    const int cap = convT_cap();                                                                       \
+    convT_k5s2_mfma<T><<<items < cap ? items : cap, T::NTH, 0, s>>>(x, wp, bias, y, act, items, batch); \
     rc = NVF_OK;                                                                                       \
   }
   NVF_TM(0, 8, 16, 2, 3)     // up2: 21 column tiles per cell plane, 8 per workgroup
