@@ -64,10 +64,21 @@ struct T16 {
   static_assert(XS * 4 <= 80 * 1024, "LDS: two workgroups per CU");
 };
 
+// item -> (batch element, cell plane, column split), heaviest planes first (convt_mfma.hip, convT_item)
+template <int NIN>
+__device__ __forceinline__ void convT16_item(int item, int nsplit, int batch, int& b, int& cz, int& split) {
+  constexpr int NCELL = NIN + 2;
+  split = item % nsplit;
+  b = (item / nsplit) % batch;
+  const int k = item / (nsplit * batch);
+  if (NIN < 3) { cz = k; return; }                             // up0 (2^3): no full plane at all, keep the order
+  cz = k < NIN - 2 ? k + 2 : (k == NIN - 2 ? 1 : (k == NIN - 1 ? NIN : (k == NIN ? 0 : NCELL - 1)));
+}
+
 template <class T>
 __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ y, int act,
-                                                         int items) {
+                                                         int items, int batch) {
   constexpr int CIN = T::CIN, NIN = T::NIN, NCELL = T::NCELL, NCT = T::NCT, NPT = T::NPT, PLANE = T::PLANE, CS = T::CS,
                 NG = T::NG, NOUT = T::NOUT, PAD = T::PAD, COUT = T::COUT;
   __shared__ __attribute__((aligned(16))) float xs[T::XS];
@@ -80,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
   float4 xv[NX4];
   const int cog = blockIdx.y;                                  // group of 16 output channels
   auto load_x = [&](int item) {
-    const int cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
+    int b, cz, split_;
+    convT16_item<NIN>(item, T::NSPLIT, batch, b, cz, split_);
     const float* xb = x + (size_t)b * CIN * NIN * NIN * NIN;
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
@@ -126,14 +138,25 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
           dst[n++] = wl[((size_t)g * kA16 + a16_index(ez, ey, ex, jz, jy, jx)) * 64];
       }
   };
+  // rounds of the stride loop: see convT_k5s2_mfma (convt_mfma.hip) -- items sorted by cost, odd rounds run the CUs
+  // backwards on their second workgroup
+  const int G = gridDim.x, half = G >> 1, w = blockIdx.x;
+  auto item_of = [&](int r) {
+    const int k = ((r & 1) && !(G & 1)) ? (w < half ? w : G + half - 1 - w) : w;
+    return r * G + k;
+  };
+  const int rounds = (items + G - 1) / G;
 #pragma unroll 1
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int split = item % T::NSPLIT, cz = (item / T::NSPLIT) % NCELL, b = item / (T::NSPLIT * NCELL);
+  for (int r = 0; r < rounds; ++r) {
+    const int item = item_of(r);
+    if (item >= items) break;                                  // only the last round is partial
+    int b, cz, split;
+    convT16_item<NIN>(item, T::NSPLIT, batch, b, cz, split);
     __syncthreads();                                           // zero fill done / the previous item's reads done
     store_x();
     load_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, ac);
     __syncthreads();
-    if (item + (int)gridDim.x < items) load_x(item + gridDim.x);   // in flight under this item's MFMAs
+    if (item_of(r + 1) < items) load_x(item_of(r + 1));        // in flight under this item's MFMAs
     f32x4 acc[NCT][8];
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -147,6 +170,9 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
       // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
       colbase[c] = kq * CS + 16 * min(tl, NPT - 1) + j + 2 * NCELL + 2;
     }
+    // MASK: bit jz set = input plane cz - jz exists; a skipped block would have added exact zeros (same bits)
+    auto phase = [&](auto maskc) {
+    constexpr int MASK = decltype(maskc)::value;
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
       const float* xg = xs + g * 4 * CS;
@@ -166,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
             const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
             if (jz <= 2 - ez && jy <= 2 - ey && jx <= 2 - ex) {
               const float a = ac[n++];
+              if (!((MASK >> jz) & 1)) continue;
 #pragma unroll
               for (int c = 0; c < NCT; ++c) acc[c][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c], acc[c][e], 0, 0, 0);
             }
@@ -186,6 +213,18 @@ __global__ __launch_bounds__(256, 2) void convT16_k5s2_mfma(const float* __restr
       column(I2{}, I0{}, I2{}, I1{}, false);
       column(I2{}, I1{}, I2{}, I2{}, false);
       column(I2{}, I2{}, I0{}, I0{}, true);
+    }
+    };
+    {
+      // input plane zi = cz - jz (PAD 2 layers have the same cells)
+      const int mask = (cz < NIN ? 1 : 0) | ((cz >= 1 && cz <= NIN) ? 2 : 0) | (cz >= 2 ? 4 : 0);     // wave-uniform
+      switch (mask) {
+        case 7: phase(std::integral_constant<int, 7>{}); break;
+        case 3: phase(std::integral_constant<int, 3>{}); break;
+        case 6: phase(std::integral_constant<int, 6>{}); break;
+        case 1: phase(std::integral_constant<int, 1>{}); break;
+        default: phase(std::integral_constant<int, 4>{}); break;
+      }
     }
     // epilogue: lane holds rows co = 4 kq + r of cell p for each parity class
 #pragma unroll
@@ -240,7 +279,7 @@ extern "C" int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const fl
     using T = T16<CI, NIN, NCT, PADV, CO>;                                                             \
     const int items = batch * T::NCELL * T::NSPLIT;                                                    \
     const int cap = 512 / (CO / 16);                       /* two workgroups per CU */                  \
-    convT16_k5s2_mfma<T><<<dim3(items < cap ? items : cap, CO / 16), 256, 0, s>>>(x, wp, bias, y, act, items); \
+    convT16_k5s2_mfma<T><<<dim3(items < cap ? items : cap, CO / 16), 256, 0, s>>>(x, wp, bias, y, act, items, batch); \
     rc = NVF_OK;                                                                                       \
   }
   NVF_T16(0, 16, 16, 0, 16, 2)   // up2: 21 column tiles per cell plane, 8 per workgroup

@@ -168,13 +168,25 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
         }
     }
   };
+  // Round r of the stride loop hands out items r G .. r G + G - 1 (G workgroups, sorted by cost).  Workgroups w and
+  // w + G / 2 share a CU (the dispatcher fills the CUs once, then a second time), so odd rounds run the CUs backwards on
+  // their second workgroup: a CU's second-round items are the k-th heaviest and the k-th lightest, and with the items of
+  // this kernel (160 full planes + 4 x 48 partial ones at batch 16) every CU ends with the same MFMA count
+  const int G = gridDim.x, half = G >> 1, w = blockIdx.x;
+  auto item_of = [&](int r) {
+    const int k = ((r & 1) && !(G & 1)) ? (w < half ? w : G + half - 1 - w) : w;
+    return r * G + k;
+  };
+  const int rounds = (items + G - 1) / G;
 #pragma unroll 1
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+  for (int r = 0; r < rounds; ++r) {
+    const int item = item_of(r);
+    if (item >= items) break;                                  // only the last round is partial
     const int split = item % T::NSPLIT;
     __syncthreads();                                           // zero fill done / the previous item's reads done
     store_x();
     __syncthreads();
-    if (item + (int)gridDim.x < items) load_x(item + gridDim.x);
+    if (item_of(r + 1) < items) load_x(item_of(r + 1));
     f32x4 acc[NCT][2][2];
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
