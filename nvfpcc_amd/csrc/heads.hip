@@ -234,9 +234,13 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
     const bool ok = i < ITEMS && gz >= 0 && gz < S && gy >= 0 && gy < S;
     const size_t off = ok ? b * vol + ((size_t)gz * S + gy) * S + 4 * xq : 0;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    pv[u] = ok ? *(const float4*)(f.p + off) : z4;
-    gv[u] = ok ? *(const float4*)(f.gt + off) : z4;
-    dv[u] = ok && f.dist ? *(const float4*)(f.dist + off) : z4;
+    // (unconditional loads from a valid address, then a select: `ok ? *p : zero` becomes a select of ADDRESSES -- a
+    // private zero against the global pointer -- i.e. four flat_load_dword per element instead of one global_load_dwordx4)
+    const float4 pl = *(const float4*)(f.p + off), gl = *(const float4*)(f.gt + off);
+    const float4 dl4 = *(const float4*)((f.dist ? f.dist : f.p) + off);
+    pv[u] = ok ? pl : z4;
+    gv[u] = ok ? gl : z4;
+    dv[u] = ok && f.dist ? dl4 : z4;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
