@@ -78,29 +78,17 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
   __shared__ __attribute__((aligned(16))) float lds[kWinoAFloats + 4 * C::BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (!WDBG(16)) {                          // the A fragments: every load of a thread in flight before its first store
-    constexpr int NV = kWinoAFloats / 4, NI = (NV + 255) / 256;
-    float4 tmp[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) tmp[i] = (i * 256 + tid < NV) ? ((const float4*)wp)[i * 256 + tid] : float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      if (i * 256 + tid < NV) ((float4*)lds)[i * 256 + tid] = tmp[i];
-  }
   float* raw = lds + kWinoAFloats + wave * C::BUF;
   if (!WDBG(32))
     for (int i = lane; i < C::BUF; i += 64) raw[i] = 0.f;        // the margins stay zero for the whole launch
-  __syncthreads();
   // XCD k (workgroups k, k + 8, ...) takes a CONTIGUOUS range of work units: neighbouring column groups and z chunks of a
   // block share input rows / planes, and each XCD has its own L2 (round-robin units made every XCD fetch every block)
   const int per = (int)(gridDim.x >> 3);                         // the grid is a multiple of 8
   const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int unit = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
+  const int unit_ = __builtin_amdgcn_readfirstlane(wg * 4 + wave);
   const int j = lane & 15, kq = lane >> 4;
-  if (unit >= d.units) {
-    if (d.bias_part && j == 0) { d.bias_part[(size_t)unit * 8 + 2 * kq] = 0.f; d.bias_part[(size_t)unit * 8 + 2 * kq + 1] = 0.f; }
-    return;
-  }
+  const bool idle = unit_ >= d.units;                            // a wave past the last unit: zero partials, no work
+  const int unit = idle ? 0 : unit_;
   const int nchunk = (C::NPAIR + d.ppc - 1) / d.ppc;
   const int cg = unit % C::NCG, zc = (unit / C::NCG) % nchunk, b = unit / (C::NCG * nchunk);
   const int q0 = zc * d.ppc, q1 = min(q0 + d.ppc, C::NPAIR);
@@ -309,7 +297,24 @@ __global__ __launch_bounds__(256) void conv_k4_wino(const float* __restrict__ g,
     commit();
     return true;
   };
-  fetch(2 * q0);
+  // prologue: the first plane's loads go out BEFORE the A fragments are copied, so that their latency (HBM on a cold
+  // tile) passes under the 64 KB copy instead of after it
+  if (!idle) fetch(2 * q0);
+  if (!WDBG(16)) {                          // the A fragments, L2 -> LDS by DMA (1 KB per wave instruction, no registers)
+    constexpr int NV = kWinoAFloats / 4, NI = (NV + 255) / 256;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i * 256 + tid < NV)
+        __builtin_amdgcn_global_load_lds((glb_vp)(wp + (size_t)(i * 256 + tid) * 4), (lds_vp)(lds + (i * 256 + wave * 64) * 4), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (idle) {
+    if (d.bias_part && j == 0) { d.bias_part[(size_t)unit_ * 8 + 2 * kq] = 0.f; d.bias_part[(size_t)unit_ * 8 + 2 * kq + 1] = 0.f; }
+    return;
+  }
   commit();
   int s = q0;                                         // q0 is even (ppc is): the set of pair q is q & 1
 #pragma unroll 1
