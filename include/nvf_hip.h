@@ -162,6 +162,17 @@ int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const fl
 int nvf_conv3d_k4_wino_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int din, int ppc,
                            void* stream);
 
+/* The same form for the WIDE decoder's 4^3 layers (16 -> 16 channels; conv16_wino.hip): rows = the 16 output channels,
+ * two output planes in flight, the five input planes of a pair walked once per pair.  Training steps only, as above.
+ * wp = nvf_pack_mfma_all kind 41 (c0 = c1 = 16) of w_bwd (backward-data) / w_fwd (forward), nvf_pack_wino16_k4_floats()
+ * floats.  bwd: dy [batch, 16, din^3] (din 32 / 16), dx, mask [batch, 16, (din + 3)^3]; fwd: x [batch, 16, din^3]
+ * (din 35 / 19), y [batch, 16, (din - 3)^3].  ppc = pairs of output planes per work unit (0: default). */
+size_t nvf_pack_wino16_k4_floats(void);
+int nvf_conv3d_k4_wino16_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
+                             void* stream);
+int nvf_conv3d_k4_wino16_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int din, int ppc,
+                             void* stream);
+
 /* ... and conv2's WEIGHT gradient in the corresponding form (wgrad_wino.h: Winograd F(4x4, 2x2) over (y, x) -- the taps
  * are the output, 2 x 2 tiles of dy the filter -- direct over z on the matrix cores, every MFMA lane useful): the weight
  * half of the autograd backward of F.conv3d, network.py:687.  dy [batch, 8, 32^3], x [batch, 8, 35^3] -> dw [8][8][4][4][4]
@@ -218,10 +229,11 @@ int nvf_pack_convT16_mfma(const float* w_fwd, int cin, int cout, float* wp, void
 int nvf_convT3d_k5s2_mfma16(const float* x, const float* wp, const float* bias, float* y, int batch, int cin, int cout,
                             int pad, int din, int act, int variant, void* stream);
 
-/* every MFMA weight packing of a step in one launch (<= 12 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
+/* every MFMA weight packing of a step in one launch (<= 16 jobs): kind 0 / 2 = nvf_pack_mfma_k4 with that pair
  * axis (c0 = cin), 10 = nvf_pack_convT_mfma (c0 = cin), 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout),
  * 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog),
- * 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout) */
+ * 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout), 40 / 41 = the Winograd packings of
+ * nvf_conv3d_k4_wino_* (c0 = c1 = 8) / nvf_conv3d_k4_wino16_* (c0 = c1 = 16) */
 int nvf_pack_mfma_all(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s, const int* c1s,
                       int n, void* stream);
 

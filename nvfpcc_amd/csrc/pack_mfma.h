@@ -4,10 +4,10 @@
 #include "nvf_common.h"
 
 struct PackJobs {
-  const float* src[12];
-  float* dst[12];
-  int32_t kind[12], c0[12], c1[12], total[12];
-  int32_t layer[12], bwd[12];      // step head only: row of the layer table and which layout (0 w_fwd, 1 w_bwd) src is
+  const float* src[16];
+  float* dst[16];
+  int32_t kind[16], c0[16], c1[16], total[16];
+  int32_t layer[16], bwd[16];      // step head only: row of the layer table and which layout (0 w_fwd, 1 w_bwd) src is
   int32_t n;
 };
 
@@ -60,6 +60,39 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       const int f = r % 25; r /= 25;
       const int g = r % 2, s1 = r / 2;                      // s1 = 1: (zw 0, s 1); 0: (zw 4, s 0)
       wp[((g * 5 + (s1 ? 0 : 4)) * 25 + f) * 64 + 16 * k + 2 * cog + s1] = 0.f;
+    }
+    return;
+  }
+  if (kind == 41) {
+    // Winograd (y, x) form of a 4^3 conv with 16 -> 16 channels (conv16_wino.hip): [g][tz][f][lane], lane = co + 16 k, value
+    // U = G w G^T of the gather-form kernel slice (ci = 4 g + k, kz = tz, co); G and the quad scheme as kind 40
+    const float G[5][4] = {{0.5f, 0.f, 0.f, 0.f},
+                           {0.5f, 0.5f, 0.5f, 0.5f},
+                           {1.f / 6.f, -1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
+                           {-1.f / 6.f, -2.f / 6.f, -4.f / 6.f, -8.f / 6.f},
+                           {0.f, 0.f, 0.f, 1.f}};
+    const int nthreads = nbx * blockDim.x;
+    for (int t = bx * blockDim.x + threadIdx.x; t < 1024 * 4; t += nthreads) {
+      const int ky = t & 3, sl = t >> 2, cog = sl % 16, kz = (sl / 16) % 4, ci = sl / 64, g = ci / 4, k = ci % 4;
+      float w4[4], mine[5];
+      for (int kx = 0; kx < 4; ++kx) w4[kx] = src(job, (ci * 64 + (kz * 4 + ky) * 4 + kx) * 16 + cog);
+      for (int fx = 0; fx < 5; ++fx) {
+        float r = 0.f;
+        for (int kx = 0; kx < 4; ++kx) r = fmaf(G[fx][kx], w4[kx], r);
+        mine[fx] = r;
+      }
+      float row[4][5];
+      for (int q = 0; q < 4; ++q)
+        for (int fx = 0; fx < 5; ++fx) row[q][fx] = __shfl(mine[fx], (int)((threadIdx.x & 63u) & ~3u) + q, 64);
+      for (int pass = 0; pass < 2; ++pass) {
+        const int fy = pass == 0 ? ky : 4;
+        if (pass == 1 && ky != 0) break;
+        for (int fx = 0; fx < 5; ++fx) {
+          float v = 0.f;
+          for (int q = 0; q < 4; ++q) v = fmaf(G[fy][q], row[q][fx], v);
+          wp[((g * 4 + kz) * 25 + fy * 5 + fx) * 64 + 16 * k + cog] = v;
+        }
+      }
     }
     return;
   }
@@ -118,17 +151,18 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
 }
 
 // kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
-// 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout); 40 = Winograd backward-data of a 4^3 conv (c0 = c1 = 8; conv_wino.hip).
+// 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout); 40 = Winograd form of a 4^3 conv (c0 = c1 = 8; conv_wino.hip); 41 = the same with 16 -> 16 channels (conv16_wino.hip).
 // Fills m (sources optional: the step head derives them).
 static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
                                  const int* c1s, int n, PackJobs& m) {
-  if (!dsts || !kinds || !c0s || !c1s || n <= 0 || n > 12) return NVF_EINVAL;
+  if (!dsts || !kinds || !c0s || !c1s || n <= 0 || n > 16) return NVF_EINVAL;
   for (int j = 0; j < n; ++j) {
     if (!dsts[j] || c0s[j] <= 0 || c0s[j] % 4) return NVF_EINVAL;
     m.src[j] = srcs ? srcs[j] : nullptr; m.dst[j] = dsts[j]; m.kind[j] = kinds[j]; m.c0[j] = c0s[j]; m.c1[j] = c1s[j];
     if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
     else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
     else if (kinds[j] == 40 && c0s[j] == 8 && c1s[j] == 8) m.total[j] = 2 * 5 * 25 * 64;
+    else if (kinds[j] == 41 && c0s[j] == 16 && c1s[j] == 16) m.total[j] = 4 * 4 * 25 * 64;
     else if (kinds[j] == 11 && c1s[j] > 0 && c1s[j] % 16 == 0) m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * 125 * 64;
     else if (kinds[j] == 20 && (c1s[j] == 8 || c1s[j] == 16)) m.total[j] = (c0s[j] / 4) * 25 * (c1s[j] == 8 ? 7 : 5) * 64;
     else if ((kinds[j] == 30 || kinds[j] == 31) && c1s[j] > 0 && (c1s[j] % 16 == 0 || c1s[j] == 8))

@@ -35,6 +35,7 @@ _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
 _WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's / conv1's backward-data in the Winograd (y, x) form (conv_wino.hip)
 _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forward in TRAINING steps (never in eval)
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
+_WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
@@ -217,6 +218,11 @@ class TrainEngine:
             if _G16 and self.wide and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0 and name in ("conv1", "conv2"):
                 L.wp_gf = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
+                if self.winograd and _WINO16:
+                    # the Winograd (y, x) form with the 16 output channels as MFMA rows (conv16_wino.hip), training steps
+                    # only: conv2 backward-data 257 -> 140 us, forward 170 -> 95, conv1 59 -> 33 / 27 -> 25 at batch 16
+                    L.wp_w = torch.empty(int(lib().nvf_pack_wino16_k4_floats()), device=self.dev)
+                    L.wp_wf = torch.empty(int(lib().nvf_pack_wino16_k4_floats()), device=self.dev)
             if _G16 and self.wide and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
             if _G16 and self.wide and L.k == 5 and (name, L.cin, L.cout, L.pad) in (("up1", 32, 16, 0), ("up2", 16, 16, 0),
@@ -242,9 +248,10 @@ class TrainEngine:
         meta = [(row[nm], 0) for nm, L in named if L.wp_f is not None]
         jobs += [(L.w_bwd, L.wp_b, L.bwd_pair, L.cout, 8) for _, L in named if L.wp_b is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_b is not None]
-        jobs += [(L.w_bwd, L.wp_w, 40, L.cout, 8) for _, L in named if L.wp_w is not None]
+        wk, wc = (41, 16) if self.wide else (40, 8)          # Winograd packing of the decoder class
+        jobs += [(L.w_bwd, L.wp_w, wk, L.cout, wc) for _, L in named if L.wp_w is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_w is not None]
-        jobs += [(L.w_fwd, L.wp_wf, 40, L.cin, 8) for _, L in named if L.wp_wf is not None]
+        jobs += [(L.w_fwd, L.wp_wf, wk, L.cin, wc) for _, L in named if L.wp_wf is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_wf is not None]
         jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for _, L in named if L.wp_t is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_t is not None]
@@ -257,7 +264,7 @@ class TrainEngine:
         meta += [(row[nm], 1) for nm, L in named if L.wp_gb is not None]
         jobs += [(L.w_fwd, L.wp_t16, 11, L.cin, L.cout) for _, L in named if L.wp_t16 is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_t16 is not None]
-        assert len(jobs) <= 12
+        assert len(jobs) <= 16
         self._mfma_jobs = jobs
         self._mfma_job_layers = meta           # (layer-table row, 0 = w_fwd / 1 = w_bwd) of each job's source
         self._table_host = table
@@ -334,6 +341,8 @@ class TrainEngine:
 
     def _conv(self, L, x, act, train=False):
         if train and L.wp_wf is not None and act == R:
+            if self.wide:
+                return ops.conv3d_k4_wino16_fwd(x, L.wp_wf, L.b_eff)
             return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff)
         if L.wp_gf is not None:
             osz = tuple(s - 3 for s in x.shape[2:])
@@ -429,6 +438,9 @@ class TrainEngine:
         """Backward-data of a 4^3 convolution.  ``bias_out``: the bias gradient of the layer BELOW (whose masked output
         gradient this pass writes): the matrix-core kernel leaves its channel sums as slabs for the reduction launch;
         returns (dx, True) then, (dx, False) when the caller has to sum dx itself."""
+        if self.wide and L.wp_w is not None and mask is not None and addend is None and g_out.shape[-1] in (32, 16):
+            dx = ops.conv3d_k4_wino16_bwd(g_out, L.wp_w, mask)
+            return dx if bias_out is None else (dx, False)
         if L.wp_gb is not None:
             dx = ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 4, 1, 3, tuple(x_in.shape[2:]), addend=addend,
                                      mask=mask)

@@ -273,6 +273,38 @@ def conv3d_k4_wino_fwd(x, wp, bias, out=None, ppc=0):
     return y
 
 
+def pack_wino16_k4(w):
+    """A fragments of nvf_conv3d_k4_wino16_bwd / _fwd from a gather-form weight [16][64][16] (one pack_mfma_all job)."""
+    wp = torch.empty(int(lib().nvf_pack_wino16_k4_floats()), device=w.device)
+    pack_mfma_all([(w, wp, 41, 16, 16)])
+    return wp
+
+
+def conv3d_k4_wino16_bwd(dy, wp, mask, out=None, ppc=0):
+    """conv3d_k4_wino_bwd for 16 -> 16 channels (the wide decoder): dx = mask > 0 ? conv_full(dy, w) : 0."""
+    _f32(dy, wp, mask)
+    B, c, di = dy.shape[0], dy.shape[1], dy.shape[2]
+    shape = (B, 16, di + 3, di + 3, di + 3)
+    if c != 16 or tuple(mask.shape) != shape:
+        raise RuntimeError("conv3d_k4_wino16_bwd: dy [B,16,n^3], mask [B,16,(n+3)^3]")
+    dx = out if out is not None else torch.empty(shape, device=dy.device)
+    check(lib().nvf_conv3d_k4_wino16_bwd(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(mask), B, di, int(ppc), _stream()),
+          "nvf_conv3d_k4_wino16_bwd")
+    return dx
+
+
+def conv3d_k4_wino16_fwd(x, wp, bias, out=None, ppc=0):
+    """conv3d_k4_wino_fwd for 16 -> 16 channels: relu(conv3d(x, w) + bias), training steps only."""
+    _f32(x, wp, bias)
+    B, c, di = x.shape[0], x.shape[1], x.shape[2]
+    if c != 16:
+        raise RuntimeError("conv3d_k4_wino16_fwd: x [B,16,n^3]")
+    y = out if out is not None else torch.empty((B, 16, di - 3, di - 3, di - 3), device=x.device)
+    check(lib().nvf_conv3d_k4_wino16_fwd(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), B, di, int(ppc), _stream()),
+          "nvf_conv3d_k4_wino16_fwd")
+    return y
+
+
 def wgrad_k4_wino(dy, x, zsplit=1, want_bias=False):
     """conv2's weight gradient [8,8,4,4,4] (and the bias gradient [8]) in the Winograd (y, x) form: one launch of slabs +
     the fixed-order reduction."""

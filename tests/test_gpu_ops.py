@@ -977,6 +977,45 @@ def test_conv3d_k4_wino_forward(ops, n, B, ppc):
     assert rel_err(y, y_direct.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 1), (35, 3, 16), (19, 1, 0), (19, 5, 0), (19, 16, 3)])
+def test_conv3d_k4_wino16_forward(ops, n, B, ppc):
+    """The wide decoder's conv2 / conv1 (16 -> 16 channels) training-step forward in the Winograd form (conv16_wino.hip:
+    rows = the 16 output channels, two output planes in flight) against torch's conv3d on the CPU (float64) and against
+    the direct 16-row matrix-core kernel: 1e-5 of max |y|."""
+    g = gen(5100 + n + B)
+    x = torch.relu(torch.randn(B, 16, n, n, n, generator=g) * 0.7)
+    w = torch.round(torch.randn(16, 16, 4, 4, 4, generator=g) * 0.06 * 16) / 16 + 0.02 * torch.randn(16, 16, 4, 4, 4, generator=g)
+    b = torch.randn(16, generator=g) * 0.3
+    ref = F.relu(F.conv3d(x.double(), w.double(), b.double()))
+    wf, _ = ops.pack_conv_weight(dev(w))
+    y = ops.conv3d_k4_wino16_fwd(dev(x), ops.pack_wino16_k4(wf), dev(b), ppc=ppc)
+    assert rel_err(y, ref) < 1e-5, rel_err(y, ref)
+    no = n - 3
+    y_direct = ops.conv3d_g16_mfma(dev(x), ops.pack_g16_mfma(wf, 16, 16, 4), dev(b), 16, 4, 1, 0, (no, no, no), ops.ACT_RELU)
+    assert rel_err(y, y_direct.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 1), (35, 3, 18), (19, 1, 0), (19, 5, 0), (19, 16, 5)])
+def test_conv3d_k4_wino16_backward_data(ops, n, B, ppc):
+    """... and their backward-data through the ReLU mask of the layer below, against torch's autograd on the CPU; zeros
+    exactly where the mask is not positive."""
+    g = gen(5300 + B + n)
+    x = torch.randn(B, 16, n, n, n, generator=g)
+    w = torch.round(torch.randn(16, 16, 4, 4, 4, generator=g) * 0.06 * 16) / 16 + 0.02 * torch.randn(16, 16, 4, 4, 4, generator=g)
+    x.requires_grad_(True)
+    y_ref = F.conv3d(x, w)
+    gy = torch.randn(y_ref.shape, generator=g) * (torch.rand(y_ref.shape, generator=g) < 0.6)
+    y_ref.backward(gy)
+    mask = torch.randn(x.shape, generator=g)
+    _, wb = ops.pack_conv_weight(dev(w))
+    dx = ops.conv3d_k4_wino16_bwd(dev(gy), ops.pack_wino16_k4(wb), dev(mask), ppc=ppc)
+    ref = x.grad * (mask > 0)
+    assert rel_err(dx, ref) < 1e-5, rel_err(dx, ref)
+    assert bool(((dx.cpu() == 0) >= (mask <= 0)).all())
+    dx_direct = ops.conv3d_g16_mfma(dev(gy), ops.pack_g16_mfma(wb, 16, 16, 4), None, 16, 4, 1, 3, (n, n, n), mask=dev(mask))
+    assert rel_err(dx, dx_direct.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (2, 2), (3, 18)])
 def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     """conv2's backward-data in the reduced-multiplication form (conv_wino.hip: Winograd F(2x2, 4x4) over (y, x), direct

@@ -91,6 +91,41 @@ def fwd_main(B, reps):
         print(f"conv1 bwd-data winograd ppc {ppc:2d}: {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
 
 
+def wide_main(B, reps):
+    """The wide decoder's 4^3 layers (16 -> 16 channels): direct 16-row kernel against conv16_wino.hip."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for n in (35, 19):
+        no = n - 3
+        w = (torch.randn(16, 16, 4, 4, 4, generator=g) * 0.06).to(dev)
+        b = (torch.randn(16, generator=g) * 0.1).to(dev)
+        x = torch.relu(torch.randn(B, 16, n, n, n, generator=g)).to(dev)
+        gy = (torch.randn(B, 16, no, no, no, generator=g) * (torch.rand(B, 16, no, no, no, generator=g) < 0.6)).to(dev)
+        wf, wb = ops.pack_conv_weight(w)
+        macs = B * 16 * 16 * 64 * no ** 3
+        out = torch.empty(B, 16, no, no, no, device=dev)
+        dxo = torch.empty(B, 16, n, n, n, device=dev)
+        wpf, wpb = ops.pack_g16_mfma(wf, 16, 16, 4), ops.pack_g16_mfma(wb, 16, 16, 4)
+        d = ops.conv3d_g16_mfma(x, wpf, b, 16, 4, 1, 0, (no, no, no), ops.ACT_RELU)
+        us = timeit(lambda: ops.conv3d_g16_mfma(x, wpf, b, 16, 4, 1, 0, (no, no, no), ops.ACT_RELU, out=out), reps)
+        print(f"wide fwd {n} direct:            {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
+        ww = ops.pack_wino16_k4(wf)
+        for ppc in ((4, 2, 8, 16) if n == 35 else (2, 1, 4, 8)):
+            y = ops.conv3d_k4_wino16_fwd(x, ww, b, ppc=ppc)
+            err = float((y - d).abs().max() / d.abs().max())
+            us = timeit(lambda: ops.conv3d_k4_wino16_fwd(x, ww, b, out=out, ppc=ppc), reps)
+            print(f"wide fwd {n} winograd ppc {ppc:2d}:   {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
+        d = ops.conv3d_g16_mfma(gy, wpb, None, 16, 4, 1, 3, (n, n, n), mask=x)
+        us = timeit(lambda: ops.conv3d_g16_mfma(gy, wpb, None, 16, 4, 1, 3, (n, n, n), mask=x, out=dxo), reps)
+        print(f"wide bwd-data {n} direct:       {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
+        ww = ops.pack_wino16_k4(wb)
+        for ppc in ((6, 3, 9, 18) if n == 35 else (2, 1, 5, 10)):
+            y = ops.conv3d_k4_wino16_bwd(gy, ww, x, ppc=ppc)
+            err = float((y - d).abs().max() / d.abs().max())
+            us = timeit(lambda: ops.conv3d_k4_wino16_bwd(gy, ww, x, out=dxo, ppc=ppc), reps)
+            print(f"wide bwd-data {n} winograd ppc {ppc:2d}: {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
+
+
 def wgrad_main(B, reps):
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(2)
@@ -115,6 +150,14 @@ if __name__ == "__main__":
         ap.add_argument("--reps", type=int, default=50)
         a = ap.parse_args()
         fwd_main(a.batch, a.reps)
+        sys.exit(0)
+    if "--wide" in sys.argv:
+        sys.argv.remove("--wide")
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--batch", type=int, default=16)
+        ap.add_argument("--reps", type=int, default=20)
+        a = ap.parse_args()
+        wide_main(a.batch, a.reps)
         sys.exit(0)
     if "--wgrad" in sys.argv:
         sys.argv.remove("--wgrad")
