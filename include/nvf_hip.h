@@ -173,6 +173,13 @@ int nvf_conv3d_k4_wino16_bwd(const float* dy, const float* wp, float* dx, const 
 int nvf_conv3d_k4_wino16_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int din, int ppc,
                              void* stream);
 
+/* ... and their WEIGHT gradient (wgrad16_wino.hip: Winograd F(4x4, 2x2) over (y, x), rows = the 16 dY channels, columns =
+ * the 16 X channels, two z taps per pass): partial sums only -- *nslab <= max_slabs slabs of 16384 floats, layout
+ * [co][ci][kz][ky][kx], for a jtotal = 16384 job of nvf_wgrad_reduce_multi*.  dy [batch, 16, w^3] (w 32 / 16), x [batch, 16,
+ * (w + 3)^3]; zsplit: z steps of an item split over this many work items (0: default; <= 8). */
+int nvf_wgrad16_k4_wino_partial(const float* dy, const float* x, float* slabs, int batch, int w, int zsplit, int max_slabs,
+                                int* nslab, void* stream);
+
 /* ... and conv2's WEIGHT gradient in the corresponding form (wgrad_wino.h: Winograd F(4x4, 2x2) over (y, x) -- the taps
  * are the output, 2 x 2 tiles of dy the filter -- direct over z on the matrix cores, every MFMA lane useful): the weight
  * half of the autograd backward of F.conv3d, network.py:687.  dy [batch, 8, 32^3], x [batch, 8, 35^3] -> dw [8][8][4][4][4]

@@ -36,6 +36,7 @@ _WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's / conv1's backward-da
 _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forward in TRAINING steps (never in eval)
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
 _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
+_WINO16_WGRAD = tuple(int(v) for v in os.environ.get("NVF_WINO16_WGRAD", "32,16").split(",") if v)   # ... weight gradients (dY extents)
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
@@ -427,7 +428,14 @@ class TrainEngine:
         return torch.cuda.stream(self.side) if self.overlap else _NullCtx()
 
     def _wgrad_conv(self, L, g_out, x_in):
-        self._wg.add(g_out, x_in, L.k, 1, L.pad, 0, L.gk)
+        if (self.wide and self.winograd and _WINO16 and L.k == 4 and L.cin == 16 and L.cout == 16 and L.pad == 0
+                and g_out.shape[-1] in _WINO16_WGRAD):
+            # the Winograd (y, x) form (wgrad16_wino.hip): slabs for the common reduction (conv2 172 -> 100 us at batch 16)
+            base = self._wg.reserve(256 * 16384 * 4)
+            n = ops.wgrad16_k4_wino_partial(g_out, x_in, base, zsplit=0 if g_out.shape[-1] == 32 else 8)
+            self._wg.add_job(base, L.gk, n, 16384)
+        else:
+            self._wg.add(g_out, x_in, L.k, 1, L.pad, 0, L.gk)
         self._bias_jobs.append((g_out, L.gb))
 
     def _wgrad_convT(self, L, g_out, x_in):

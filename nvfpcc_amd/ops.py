@@ -305,6 +305,21 @@ def conv3d_k4_wino16_fwd(x, wp, bias, out=None, ppc=0):
     return y
 
 
+def wgrad16_k4_wino_partial(dy, x, slabs, max_slabs=256, zsplit=0):
+    """Partial sums of the weight gradient of a valid 4^3 convolution with 16 -> 16 channels in the Winograd (y, x) form
+    (wgrad16_wino.hip): writes <= max_slabs slabs of 16384 floats at device address ``slabs`` (WgradBatch.reserve) and
+    returns their number -- a WgradBatch.add_job(slabs, dw, n, 16384) adds them."""
+    import ctypes
+    _f32(dy, x)
+    B, c, w = dy.shape[0], dy.shape[1], dy.shape[2]
+    if c != 16 or tuple(x.shape) != (B, 16, w + 3, w + 3, w + 3):
+        raise RuntimeError("wgrad16_k4_wino_partial: dy [B,16,w^3], x [B,16,(w+3)^3]")
+    n = ctypes.c_int(0)
+    check(lib().nvf_wgrad16_k4_wino_partial(_ptr(dy), _ptr(x), int(slabs), B, w, int(zsplit), int(max_slabs),
+                                            ctypes.byref(n), _stream()), "nvf_wgrad16_k4_wino_partial")
+    return n.value
+
+
 def wgrad_k4_wino(dy, x, zsplit=1, want_bias=False):
     """conv2's weight gradient [8,8,4,4,4] (and the bias gradient [8]) in the Winograd (y, x) form: one launch of slabs +
     the fixed-order reduction."""

@@ -1016,6 +1016,26 @@ def test_conv3d_k4_wino16_backward_data(ops, n, B, ppc):
     assert rel_err(dx, dx_direct.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("w,B,zsplit", [(32, 1, 0), (32, 5, 0), (32, 16, 0), (32, 3, 2), (32, 20, 0), (16, 1, 0), (16, 5, 0), (16, 16, 0), (16, 3, 1)])
+def test_wgrad16_k4_wino(ops, w, B, zsplit):
+    """The wide decoder's conv2 / conv1 weight gradient in the Winograd (y, x) form (wgrad16_wino.hip) + the fixed-order slab
+    reduction against torch's autograd of F.conv3d on the CPU (float64): 2e-5 of max |dW| (measured 4e-6; the gradient
+    goldens are held to 2e-4); more items than workgroups (batch 20) and a split z range."""
+    g = gen(5500 + B + w)
+    x = torch.relu(torch.randn(B, 16, w + 3, w + 3, w + 3, generator=g) * 0.7)
+    gy = torch.randn(B, 16, w, w, w, generator=g) * (torch.rand(B, 16, w, w, w, generator=g) < 0.6)
+    wt = torch.zeros(16, 16, 4, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), wt).backward(gy.double())
+    wb = ops.WgradBatch(torch.device("cuda"))
+    base = wb.reserve(256 * 16384 * 4)
+    n = ops.wgrad16_k4_wino_partial(dev(gy), dev(x), base, zsplit=zsplit)
+    assert 0 < n <= 256
+    dw = torch.full((16 * 16 * 64,), float("nan"), device="cuda")
+    wb.add_job(base, dw, n, 16384)
+    wb.finish()
+    assert rel_err(dw.view(16, 16, 4, 4, 4), wt.grad) < 2e-5, rel_err(dw.view(16, 16, 4, 4, 4), wt.grad)
+
+
 @pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (2, 2), (3, 18)])
 def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     """conv2's backward-data in the reduced-multiplication form (conv_wino.hip: Winograd F(2x2, 4x4) over (y, x), direct

@@ -52,8 +52,8 @@ def run_one(a, seed):
     from nvfpcc_amd.synth import make_blocks
     from oracle import nvf_oracle as O
     from tests import philox_np
-    ch, channels = 3, (8, 16, 8, 8)
-    H = dict(lmbda=a.lmbda, w1=10.0, w2=57.0, lr=1e-3, wemb=5.0)
+    ch, channels = (8, (16, 32, 16, 16)) if a.wide else (3, (8, 16, 8, 8))      # BASELINE configs[4] / [1]
+    H = dict(lmbda=a.lmbda, w1=10.0, w2=57.0, lr=1e-3, wemb=8.0 if a.wide else 5.0)
     gts, dists = make_blocks(a.blocks)
     gt, dist = torch.from_numpy(gts).float(), torch.from_numpy(dists).float()
     n_points = float(gts.sum())
@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--seeds", type=int, default=1, help="number of (noise, epoch-order) seeds: seed, seed + 1, ...")
     ap.add_argument("--out", default="")
+    ap.add_argument("--wide", action="store_true", help="the wide decoder: --ch 8 --chanstr 16,32,16,16 --wemb 8")
     a = ap.parse_args()
     runs = []
     for k in range(a.seeds):
@@ -122,7 +123,8 @@ def main():
               f"{r[2]:.1f} s / {r[3]:.1f} s", flush=True)
     n_points = runs[0][6]
     head = (f"HIP engine vs CPU oracle, the same training runs: {a.blocks} synthetic blocks ({int(n_points)} points), batch "
-            f"{a.batch}, {a.epochs} epochs (phase change {a.phase_change}), lambda {a.lmbda:g}, w1 10, w2 57, lr 1e-3, wemb 5; "
+            f"{a.batch}, {a.epochs} epochs (phase change {a.phase_change}), lambda {a.lmbda:g}, w1 10, w2 57, lr 1e-3, "
+            f"{'ch 8, chanstr 16,32,16,16, wemb 8' if a.wide else 'ch 3, chanstr 8,16,8,8, wemb 5'}; "
             f"{a.seeds} seed(s) from {a.seed} (a seed fixes the noise draws AND the epoch orders; the oracle is fed the engine's "
             f"counter-RNG draws); kernels rounded to 1/16, evaluation by the oracle's eval forward at thh {a.thh}.  Divergence "
             f"of the two trajectories (rounding amplified by {a.epochs} x {(a.blocks + a.batch - 1) // a.batch + 1} Adam steps): max "

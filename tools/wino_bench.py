@@ -126,6 +126,33 @@ def wide_main(B, reps):
             print(f"wide bwd-data {n} winograd ppc {ppc:2d}: {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
 
 
+def wide_wgrad_main(B, reps):
+    """The wide decoder's conv2 / conv1 weight gradients: direct 16-row kernel (+ reduction) against wgrad16_wino.hip."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(6)
+    for w in (32, 16):
+        x = torch.relu(torch.randn(B, 16, w + 3, w + 3, w + 3, generator=g) * 0.7).to(dev)
+        gy = (torch.randn(B, 16, w, w, w, generator=g) * (torch.rand(B, 16, w, w, w, generator=g) < 0.6)).to(dev)
+        macs = B * 16 * 16 * 64 * w ** 3
+        wb = ops.WgradBatch(dev)
+        out_d, out_w = torch.empty(16 * 16 * 64, device=dev), torch.empty(16 * 16 * 64, device=dev)
+
+        def direct():
+            wb.add(gy, x, 4, 1, 0, 0, out_d)
+            wb.finish()
+        us = timeit(direct, reps)
+        print(f"wide wgrad {w} direct (+ reduce):        {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
+        for zs in ((1, 2) if w == 32 else (4, 2, 8, 1)):
+            def wino():
+                base = wb.reserve(256 * 16384 * 4)
+                n = ops.wgrad16_k4_wino_partial(gy, x, base, zsplit=zs)
+                wb.add_job(base, out_w, n, 16384)
+                wb.finish()
+            us = timeit(wino, reps)
+            err = float((out_w - out_d).abs().max() / out_d.abs().max())
+            print(f"wide wgrad {w} winograd zsplit {zs} (+ reduce): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF   max|d| / max = {err:.2e}")
+
+
 def wgrad_main(B, reps):
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(2)
@@ -158,6 +185,7 @@ if __name__ == "__main__":
         ap.add_argument("--reps", type=int, default=20)
         a = ap.parse_args()
         wide_main(a.batch, a.reps)
+        wide_wgrad_main(a.batch, a.reps)
         sys.exit(0)
     if "--wgrad" in sys.argv:
         sys.argv.remove("--wgrad")
