@@ -96,12 +96,12 @@ __global__ __launch_bounds__(256) void wgrad16_k4_wino(const float* __restrict__
       // end of step z + 1 (one wave per SIMD: a plane needs more than one step's MFMAs to arrive)
       ww_u4 xvA[4], gvA, xvB[4], gvB;
       auto load_x = [&](int p, ww_u4 (&xv)[4]) {                // X plane p (always inside the tensor when called)
-        const int so = __builtin_amdgcn_readfirstlane(((p * WQ + 2 * tr) * WQ + 8 * tg) * 4);
+        const int so = ((p * WQ + 2 * tr) * WQ + 8 * tg) * 4;           // wave-uniform by construction
 #pragma unroll
         for (int u = 0; u < 4; ++u) xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx[u], so, 0);
       };
       auto load_g = [&](int p, ww_u4& gv) {
-        const int so = __builtin_amdgcn_readfirstlane(((p * W + 2 * tr) * W + 8 * tg) * 4);
+        const int so = ((p * W + 2 * tr) * W + 8 * tg) * 4;
         gv = __builtin_amdgcn_raw_buffer_load_b128(rg_, voffg, so, 0);
       };
       auto commit_x = [&](int slot, const ww_u4 (&xv)[4]) {
