@@ -588,6 +588,27 @@ def run(args):
                                               "frac_of_fp32_peak": frac(nbig / dt5, 2.0 * fwd_macs),
                                               "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
             del eng2
+            # BASELINE configs[4]'s decoder (--ch 8 --chanstr 16,32,16,16 --wemb 8) at the reference's batch of 16:
+            # the same train step, host-launched (its ~20 launches of 10-140 us hide the launch latency)
+            if args.chanstr == "8,16,8,8" and world == 1:
+                torch.cuda.empty_cache()
+                wide = argparse.Namespace(**dict(vars(args), ch=8, chanstr="16,32,16,16", force_collective=False))
+                eng3 = build_engine(wide, device, 1)
+                order3 = np.concatenate([rng.permutation(args.blocks) for _ in range(40 * B // args.blocks + 2)])
+                it3 = [0]
+
+                def wide_step():
+                    ids = order3[it3[0] * B:(it3[0] + 1) * B]
+                    it3[0] += 1
+                    eng3.train_step(ids, args.q, n_pts=float(counts[ids].sum()))
+                for _ in range(3):
+                    wide_step()
+                dt6 = timed(wide_step, 20)
+                wm = FWD_MACS["16,32,16,16"]
+                extra["train_step_wide_B16"] = {"blocks_per_s": round(B / dt6, 1), "ms_per_step": round(dt6 * 1e3, 4),
+                                                "ch": 8, "chanstr": "16,32,16,16", "launch": "host",
+                                                "frac_of_fp32_peak": round(B / dt6 * 6.0 * wm / 1e12 / PEAK_FP32_TFLOPS, 4)}
+                del eng3
 
     if rank == 0:
         kern_us = probe.summary()
