@@ -35,6 +35,10 @@ FWD_MACS = {"8,16,8,8": 201190992, "16,32,16,16": 788428800}      # SURVEY.md se
 CONV2_MACS = {"8,16,8,8": 134217728, "16,32,16,16": 536870912}     # per block, each of fwd / bwd-data / bwd-weight
 # per-block MACs of the other trunk layers (each of fwd / bwd-data / bwd-weight), SURVEY.md section 2.1
 UP2_MACS = {"8,16,8,8": 32768000, "16,32,16,16": 131072000}
+# v_mfma_f32_16x16x4_f32 instructions (2048 FLOP each) per block of the Winograd launches (SQ_INSTS_MFMA / batch,
+# profiles/r04_pmc_sq_b16.md, tools/wino16_prof.py)
+WINO_MFMAS = {"8,16,8,8": {"conv2_fwd": 64000, "conv2_bwd_data": 84000, "wgrad_trunk5": 158528},
+              "16,32,16,16": {"conv2_fwd": 204800, "conv2_bwd_data": 268800, "conv2_bwd_weight": 204800}}
 CONV1_MACS = {"8,16,8,8": 16777216, "16,32,16,16": 67108864}
 UP1_MACS = {"8,16,8,8": 8192000, "16,32,16,16": 32768000}
 CONV0_MACS = {"8,16,8,8": 1024000, "16,32,16,16": 4096000}
@@ -426,6 +430,10 @@ def run(args):
                lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 0 and x.shape[-1] == 35)
     probe.wrap(ops, "conv3d_g16_mfma", "conv2_bwd_data",
                lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 3 and x.shape[-1] == 32)
+    # ... in the Winograd (y, x) form since round 4 (conv16_wino.hip, wgrad16_wino.hip)
+    probe.wrap(ops, "conv3d_k4_wino16_fwd", "conv2_fwd", lambda x, wp, b, *a, **kw: x.shape[-1] == 35)
+    probe.wrap(ops, "conv3d_k4_wino16_bwd", "conv2_bwd_data", lambda dy, wp, m, *a, **kw: dy.shape[-1] == 32)
+    probe.wrap(ops, "wgrad16_k4_wino_partial", "conv2_bwd_weight", lambda dy, x, slabs, *a, **kw: dy.shape[-1] == 32)
     probe.wrap(ops.WgradBatch, "add", "conv2_bwd_weight",
                lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
     # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
@@ -643,13 +651,24 @@ def run(args):
                 torch.cuda.synchronize()
                 traffic, tnote, kname = measure_traffic(args, label)
             per_kernel = {}
+            # (the five-gradient launch's count was measured at batch 16: its workgroup caps make it non-linear in the batch)
+            wino = {k: v for k, v in WINO_MFMAS.get(cs, {}).items() if k != "wgrad_trunk5" or B == 16} if _E._WINO else {}
             for lab in labels:
                 f = flops if lab == label else 2.0 * macs * B
                 u = in_step.get(lab, single[lab])
-                per_kernel[lab] = {"us": round(u, 2), "flops": f, "tflops": round(f / (u * 1e-6) / 1e12, 2),
-                                   "frac": round(f / (u * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
-                                   "source": "in-step kernel trace" if lab in in_step else "HIP-event bracket, 8 repeats",
-                                   "kernel_name": in_names.get(lab)}
+                ent = {"us": round(u, 2), "flops": f, "tflops": round(f / (u * 1e-6) / 1e12, 2),
+                       "frac": round(f / (u * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                       "source": "in-step kernel trace" if lab in in_step else "HIP-event bracket, 8 repeats",
+                       "kernel_name": in_names.get(lab)}
+                if lab in wino:
+                    # a reduced-multiplication (Winograd) launch: `flops` / `frac` are the layer's direct-form (algorithmic)
+                    # count, which the kernel does not execute -- and which can therefore exceed the pipe's peak; the
+                    # fraction of the pipe it really occupies is the MFMA work it issues
+                    ex = wino[lab] * B * 2048.0
+                    ent.update({"form": "Winograd (y, x): 25 products per 2 x 2 outputs and z tap instead of 64",
+                                "mfma_flops_executed": ex,
+                                "executed_frac": round(ex / (u * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4)})
+                per_kernel[lab] = ent
             roofline = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                         "traffic": None if traffic is None else round(traffic), "traffic_source": tnote,
@@ -657,6 +676,11 @@ def run(args):
                         "avg_launch_us": round(us_step, 2), "avg_launch_us_source": in_note,
                         "event_bracket_us": round(us, 2), "flops_per_launch": flops,
                         "all_kernels": per_kernel,
+                        **({"mfma_flops_executed": wino[label] * B * 2048.0,
+                            "executed_frac": round(wino[label] * B * 2048.0 / (us_step * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                            "executed_note": "frac = the launch's algorithmic (direct-form) FLOPs over its time; part of it runs "
+                                             "in a Winograd form, so the MFMA work it executes is less (SQ_INSTS_MFMA x 2048)"}
+                           if label in wino else {}),
                         "all_kernels_avg_us": {k: round(v, 2) for k, v in kern_us.items()},
                         "note": "fp32 VALU instructions do not hide behind fp32 MFMAs on gfx950 (profiles/"
                                 "r04_mfma_valu_overlap.md): a kernel's time is 32 cycles per MFMA plus 2.5-5 per vector "
