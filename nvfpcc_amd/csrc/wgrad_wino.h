@@ -17,7 +17,7 @@
 // The A operand of lane (co, a, tile k) is Gh of ITS tile, the B operand of lane (ci, b, k) Xh of its tile: both transforms
 // run in the lane that feeds them (21 + 90 VALU operations per step and 25 MFMAs).  A wave walks z for one group of four
 // tiles of a tile row; its windows (X: 5 rows x 11 columns x 8 channels per plane, three planes live; dY: 2 x 8 x 8, two
-// planes) sit in a 7 KB LDS ring of its own, the next planes arrive in registers (9 dword buffer loads per step) and are
+// planes) sit in a 7 KB LDS ring of its own, the next planes arrive in registers (three 16-byte buffer loads per step) and are
 // committed after the step's reads -- no barrier before the epilogue.  Epilogue: A^T M A in registers, then the existing
 // cross-wave sum (one padded LDS region per wave, fixed order) and one 4096-float slab per workgroup.
 #pragma once
@@ -42,7 +42,6 @@ __device__ __forceinline__ void wgrad_k4_wino_body(const float* __restrict__ g, 
                                                    float* __restrict__ slabs, const WgDims& d, int bx, float* lds,
                                                    int region) {
   constexpr int W = C::W, WQ = C::WQ, XRS = C::XRS, XCS = C::XCS, XPS = C::XPS, GRS = C::GRS, GCS = C::GCS, GPS = C::GPS;
-  constexpr int NLX = C::NLX, NLG = C::NLG;
   typedef float f32x4_ __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,21 +53,19 @@ __device__ __forceinline__ void wgrad_k4_wino_body(const float* __restrict__ g, 
 #pragma unroll
   for (int f = 0; f < 25; ++f) acc[f] = f32x4_{0.f, 0.f, 0.f, 0.f};
   float bs = 0.f;
-  // staging descriptors (one plane slice = NLX / NLG dword loads per lane)
+  // staging descriptors: an X plane slice is 40 (channel, row) rows of three 16-byte pieces (tile groups start on 32-byte
+  // boundaries; the twelfth word of a row is never read), a dY slice 16 rows of two: 2 + 1 loads per lane
+  typedef unsigned wwu4 __attribute__((ext_vector_type(4)));
   constexpr int kOob = 0x7ffffff0;
-  int voffx[NLX], ldsx[NLX], voffg[NLG], ldsg[NLG];
+  int voffx[2], ldsx[2];
 #pragma unroll
-  for (int k = 0; k < NLX; ++k) {
-    const int e = lane + 64 * k, c = e / 55, r = (e % 55) / 11, col = e % 11;
-    voffx[k] = e < C::NXE ? ((c * WQ * WQ + r) * WQ + col) * 4 : kOob;
-    ldsx[k] = e < C::NXE ? c * XCS + r * XRS + col : -1;
+  for (int k = 0; k < 2; ++k) {
+    const int e = lane + 64 * k, r = e / 3, seg = e % 3, c = r / 5, row = r % 5;
+    voffx[k] = e < 120 ? ((c * WQ * WQ + row) * WQ + 4 * seg) * 4 : kOob;
+    ldsx[k] = e < 120 ? c * XCS + row * XRS + 4 * seg : -1;
   }
-#pragma unroll
-  for (int k = 0; k < NLG; ++k) {
-    const int e = lane + 64 * k, c = e / 16, r = (e % 16) / 8, col = e % 8;
-    voffg[k] = ((c * W * W + r) * W + col) * 4;
-    ldsg[k] = c * GCS + r * GRS + col;
-  }
+  const int voffg = lane < 32 ? (((lane >> 2) * W * W + ((lane >> 1) & 1)) * W + 4 * (lane & 1)) * 4 : kOob;
+  const int ldsg = lane < 32 ? (lane >> 2) * GCS + ((lane >> 1) & 1) * GRS + 4 * (lane & 1) : -1;
   const int zsplit = d.tiles_z > 0 ? d.tiles_z : 1;            // z steps of a (block, tile group) shared by this many items
   // XCD-local work: workgroups bx, bx + 8, ... share an XCD (and its L2); they take consecutive item ranges, i.e. the
   // neighbouring tile groups of the same blocks, when the job's workgroup count d.tiles_y is a multiple of 8
@@ -86,26 +83,24 @@ __device__ __forceinline__ void wgrad_k4_wino_body(const float* __restrict__ g, 
                                                                          8 * WQ * WQ * WQ * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(g + (size_t)n * 8 * W * W * W), 0,
                                                                          8 * W * W * W * 4, 0x00020000);
-    float xv[NLX], gv[NLG];
+    wwu4 xv[2], gv;
     auto load_x = [&](int p) {                                  // X plane p (always inside the tensor when called)
       const int so = __builtin_amdgcn_readfirstlane(((p * WQ + 2 * tr) * WQ + 8 * tg) * 4);
 #pragma unroll
-      for (int k = 0; k < NLX; ++k) xv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, voffx[k], so, 0));
+      for (int k = 0; k < 2; ++k) xv[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx[k], so, 0);
     };
     auto load_g = [&](int p) {                                  // dY plane p; outside [0, W): zeros
       const bool in = p >= 0 && p < W;
       const int so = __builtin_amdgcn_readfirstlane(in ? ((p * W + 2 * tr) * W + 8 * tg) * 4 : 0);
-#pragma unroll
-      for (int k = 0; k < NLG; ++k) gv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, in ? voffg[k] : kOob, so, 0));
+      gv = __builtin_amdgcn_raw_buffer_load_b128(rg, in ? voffg : kOob, so, 0);
     };
     auto commit_x = [&](int slot) {
 #pragma unroll
-      for (int k = 0; k < NLX; ++k)
-        if (ldsx[k] >= 0) xr[slot * XPS + ldsx[k]] = xv[k];
+      for (int k = 0; k < 2; ++k)
+        if (ldsx[k] >= 0) *(wwu4*)(xr + slot * XPS + ldsx[k]) = xv[k];
     };
     auto commit_g = [&](int slot) {
-#pragma unroll
-      for (int k = 0; k < NLG; ++k) gr[slot * GPS + ldsg[k]] = gv[k];
+      if (ldsg >= 0) *(wwu4*)(gr + slot * GPS + ldsg) = gv;
     };
     // prologue: dY planes z0, z0 + 1; X planes z0 + 1 .. z0 + 3 (slot of plane p: p & 1 / p % 3)
     load_g(z0); commit_g(z0 & 1);
