@@ -166,10 +166,11 @@ int nvf_conv3d_k4_wino_fwd(const float* x, const float* wp, const float* bias, f
  * two output planes in flight, the five input planes of a pair walked once per pair.  Training steps only, as above.
  * wp = nvf_pack_mfma_all kind 41 (c0 = c1 = 16) of w_bwd (backward-data) / w_fwd (forward), nvf_pack_wino16_k4_floats()
  * floats.  bwd: dy [batch, 16, din^3] (din 32 / 16), dx, mask [batch, 16, (din + 3)^3]; fwd: x [batch, 16, din^3]
- * (din 35 / 19), y [batch, 16, (din - 3)^3].  ppc = pairs of output planes per work unit (0: default). */
+ * (din 35 / 19), y [batch, 16, (din - 3)^3].  ppc = pairs of output planes per work unit (0: default).  bias_part (optional,
+ * bwd): *bias_nparts slabs of 16 floats, the channel sums of dx per work unit (a jtotal = 16 job of nvf_wgrad_reduce_multi*). */
 size_t nvf_pack_wino16_k4_floats(void);
 int nvf_conv3d_k4_wino16_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
-                             void* stream);
+                             float* bias_part, int* bias_nparts, void* stream);
 int nvf_conv3d_k4_wino16_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int din, int ppc,
                              void* stream);
 

@@ -39,7 +39,7 @@ PROTOTYPES = {
     "nvf_conv3d_k4_wino_fwd": (I, [P, P, P, P, I, I, I, P]),
     "nvf_wgrad_k4_wino": (I, [P, P, P, P, P, Z, I, I, P]),
     "nvf_pack_wino16_k4_floats": (Z, []),
-    "nvf_conv3d_k4_wino16_bwd": (I, [P, P, P, P, I, I, I, P]),
+    "nvf_conv3d_k4_wino16_bwd": (I, [P, P, P, P, I, I, I, P, P, P]),
     "nvf_conv3d_k4_wino16_fwd": (I, [P, P, P, P, I, I, I, P]),
     "nvf_wgrad16_k4_wino_partial": (I, [P, P, P, I, I, I, I, P, P]),
     "nvf_pack_convT_mfma_floats": (Z, [I]),

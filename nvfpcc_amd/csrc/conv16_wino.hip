@@ -30,6 +30,7 @@ extern "C" size_t nvf_pack_wino16_k4_floats(void) { return (size_t)kWino16AFloat
 
 struct W16Dims {
   int batch, units, ppc;        // work units = (block, z chunk, column group); ppc pairs of output planes per chunk
+  float* bias_part;             // optional (EPI 1): per unit the 16 channel sums of what it stored
 };
 
 // DIN: input extent; PAD: zero padding of the gather (3: backward-data, 0: forward); output extent DIN + 2 PAD - 3.  The
@@ -56,7 +57,9 @@ struct W16Cfg {
 
 // EPI 1: y = mask > 0 ? acc : 0 (backward-data through the ReLU of the layer below; `mask` = that layer's output)
 // EPI 0: y = relu(acc + bias[channel])  (forward; `mask` = the 16 biases)
-template <class C, int EPI>
+// BIAS (EPI 1 only): also leave the channel sums of what was stored (d.bias_part); a template switch because the eight adds
+// per emitted plane cost the backward-data kernel 2-3 us whether anyone reads the sums or not
+template <class C, int EPI, bool BIAS = false>
 __global__ __launch_bounds__(256) void conv16_k4_wino(const float* __restrict__ g, const float* __restrict__ wp,
                                                       float* __restrict__ y, const float* __restrict__ mask, W16Dims d) {
   constexpr int DIN = C::DIN, PAD = C::PAD, DOUT = C::DOUT, TPR = C::TPR, RS = C::RS, CS = C::CS, NLD = C::NLD;
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(256) void conv16_k4_wino(const float* __restrict__ 
     vs64[yo] = ok && full ? o : kOob;
     vs32[yo] = ok && !full ? o : kOob;
   }
-  w16_u2 mk[8];                                           // the ReLU mask of the plane being finished, fetched a plane ahead
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};                   // channel sums of what this lane stored (a masked-out or
+  w16_u2 mk[8];                                           // out-of-range output is 0); mk: the ReLU mask, a plane ahead
   auto mask_fetch = [&](int z) {
     if constexpr (EPI != 1) return;
     const bool zin = z < DOUT;                            // wave-uniform
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(256) void conv16_k4_wino(const float* __restrict__ 
         }
         __builtin_amdgcn_raw_buffer_store_b64(w16_u2{__float_as_uint(o0), __float_as_uint(o1)}, rs_y, zin ? vs64[yo] : kOob, so, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0), rs_y, zin ? vs32[yo] : kOob, so, 0);
+        if constexpr (BIAS) bsum[r] += o0 + o1;
       }
     }
   };
@@ -283,7 +288,13 @@ __global__ __launch_bounds__(256) void conv16_k4_wino(const float* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  if (idle) return;
+  if (idle) {
+    if (BIAS && d.bias_part && j == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d.bias_part[(size_t)unit_ * 16 + 4 * kq + r] = 0.f;
+    }
+    return;
+  }
 #pragma unroll 1
   for (int q = q0; q < q1; ++q) {
     plane(I0{}, q);
@@ -294,28 +305,42 @@ __global__ __launch_bounds__(256) void conv16_k4_wino(const float* __restrict__ 
     plane(I4{}, q);
     emit(I1{}, 2 * q + 1);
   }
+  if (BIAS && d.bias_part) {                              // the unit's channel sums (the bias gradient of the layer below)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = bsum[r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (j == 0) d.bias_part[(size_t)unit * 16 + 4 * kq + r] = v;
+    }
+  }
 }
 
 template <class C, int EPI>
-static int launch_wino16(const float* x, const float* wp, float* y, const float* aux, int batch, int ppc, hipStream_t s) {
+static int launch_wino16(const float* x, const float* wp, float* y, const float* aux, int batch, int ppc, float* bias_part,
+                         int* bias_nparts, hipStream_t s) {
   if (ppc <= 0) return NVF_EINVAL;
   const int nchunk = (C::NPAIR + ppc - 1) / ppc;
-  W16Dims d{batch, batch * nchunk * C::NCG, ppc};
-  const int grid = ((d.units + 3) / 4 + 7) / 8 * 8;      // a multiple of the 8 XCDs
-  conv16_k4_wino<C, EPI><<<grid, 256, 0, s>>>(x, wp, y, aux, d);
+  W16Dims d{batch, batch * nchunk * C::NCG, ppc, bias_part};
+  const int grid = ((d.units + 3) / 4 + 7) / 8 * 8;      // a multiple of the 8 XCDs (idle waves write zero partials)
+  if (bias_nparts) *bias_nparts = grid * 4;
+  if (EPI == 1 && bias_part) conv16_k4_wino<C, EPI, EPI == 1><<<grid, 256, 0, s>>>(x, wp, y, aux, d);
+  else conv16_k4_wino<C, EPI, false><<<grid, 256, 0, s>>>(x, wp, y, aux, d);
   return NVF_OK;
 }
 
 // dx[b, ci, :] = relu-mask( sum_co conv_full(dy[b, co], w) ): backward-data of a valid 4^3 convolution with 16 -> 16
 // channels through the ReLU of the layer below.  dy [batch, 16, din^3] (din = 32: conv2, 16: conv1), dx / mask
 // [batch, 16, (din + 3)^3]; wp = nvf_pack_mfma_all kind 41 of the layer's w_bwd (nvf_pack_wino16_k4_floats() floats).
-// ppc: pairs of output planes per work unit (0 = default).  NVF_EINVAL for shapes without an instantiation.
+// ppc: pairs of output planes per work unit (0 = default).  bias_part (optional): *bias_nparts slabs of 16 channel sums of dx
+// (the bias gradient of the layer below; a jtotal = 16 job of nvf_wgrad_reduce_multi*).  NVF_EINVAL for shapes without an
+// instantiation.
 extern "C" int nvf_conv3d_k4_wino16_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din,
-                                        int ppc, void* stream) {
-  if (!dy || !wp || !dx || !mask || batch <= 0 || ppc < 0) return NVF_EINVAL;
+                                        int ppc, float* bias_part, int* bias_nparts, void* stream) {
+  if (!dy || !wp || !dx || !mask || batch <= 0 || ppc < 0 || (bias_part && !bias_nparts)) return NVF_EINVAL;
   int rc;
-  if (din == 32) rc = launch_wino16<W16Cfg<32, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 6, nvf_stream(stream));
-  else if (din == 16) rc = launch_wino16<W16Cfg<16, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 1, nvf_stream(stream));
+  if (din == 32) rc = launch_wino16<W16Cfg<32, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 6, bias_part, bias_nparts, nvf_stream(stream));
+  else if (din == 16) rc = launch_wino16<W16Cfg<16, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 1, bias_part, bias_nparts, nvf_stream(stream));
   else return NVF_EINVAL;
   if (rc != NVF_OK) return rc;
   NVF_LAUNCH_CHECK();
@@ -328,8 +353,8 @@ extern "C" int nvf_conv3d_k4_wino16_fwd(const float* x, const float* wp, const f
                                         int ppc, void* stream) {
   if (!x || !wp || !bias || !y || batch <= 0 || ppc < 0) return NVF_EINVAL;
   int rc;
-  if (din == 35) rc = launch_wino16<W16Cfg<35, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 4, nvf_stream(stream));
-  else if (din == 19) rc = launch_wino16<W16Cfg<19, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 1, nvf_stream(stream));
+  if (din == 35) rc = launch_wino16<W16Cfg<35, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 4, nullptr, nullptr, nvf_stream(stream));
+  else if (din == 19) rc = launch_wino16<W16Cfg<19, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 1, nullptr, nullptr, nvf_stream(stream));
   else return NVF_EINVAL;
   if (rc != NVF_OK) return rc;
   NVF_LAUNCH_CHECK();

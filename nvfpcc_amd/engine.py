@@ -36,6 +36,9 @@ _WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's / conv1's backward-da
 _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forward in TRAINING steps (never in eval)
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
 _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
+# ... bias sums of the layer below from its backward-data epilogue: measured neutral (the reduction launch 48.9 -> 44.0 us
+# without its 51 MB of re-reads, the two epilogues + 2.7 / + 2.1 us): off by default
+_WINO16_BIAS = os.environ.get("NVF_WINO16_BIAS", "0") != "0"
 _WINO16_WGRAD = tuple(int(v) for v in os.environ.get("NVF_WINO16_WGRAD", "32,16").split(",") if v)   # ... weight gradients (dY extents)
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
@@ -438,15 +441,23 @@ class TrainEngine:
             self._wg.add(g_out, x_in, L.k, 1, L.pad, 0, L.gk)
         self._bias_jobs.append((g_out, L.gb))
 
-    def _wgrad_convT(self, L, g_out, x_in):
+    def _wgrad_convT(self, L, g_out, x_in, bias=True):
         self._wg.add(x_in, g_out, 5, 2, L.pad, 0, L.gk)
-        self._bias_jobs.append((g_out, L.gb))
+        if bias:        # (False: the kernel that wrote g_out left its channel sums as slabs, see _dx_conv)
+            self._bias_jobs.append((g_out, L.gb))
 
     def _dx_conv(self, L, g_out, x_in, mask=None, addend=None, bias_out=None):
         """Backward-data of a 4^3 convolution.  ``bias_out``: the bias gradient of the layer BELOW (whose masked output
         gradient this pass writes): the matrix-core kernel leaves its channel sums as slabs for the reduction launch;
         returns (dx, True) then, (dx, False) when the caller has to sum dx itself."""
         if self.wide and L.wp_w is not None and mask is not None and addend is None and g_out.shape[-1] in (32, 16):
+            if bias_out is not None and g_out.shape[0] <= 64 and _WINO16_BIAS:
+                # the channel sums of dx (the bias gradient of the layer below) leave with the kernel's stores instead of a
+                # second pass over the 44 MB it wrote (conv2 at batch 16)
+                base = self._wg.reserve(8192 * 16 * 4)
+                dx, nparts = ops.conv3d_k4_wino16_bwd(g_out, L.wp_w, mask, bias_part=base)
+                self._wg.add_job(base, bias_out, nparts, 16)
+                return dx, True
             dx = ops.conv3d_k4_wino16_bwd(g_out, L.wp_w, mask)
             return dx if bias_out is None else (dx, False)
         if L.wp_gb is not None:
@@ -568,12 +579,16 @@ class TrainEngine:
                     self._wgrad_conv(Ls["conv1_cls"], dl1, a["y3"])
                     self._wgrad_conv(Ls["conv0_cls"], dl0, a["y1"])
 
-        def side_wgrad(fn, L, g, x):
+        def side_wgrad(fn, L, g, x, **kw):
             if not want_w:
                 return
             self._fork()
             with self._on_side():
-                fn(L, g, x)
+                fn(L, g, x, **kw)
+
+        # wide decoder: the Winograd backward-data kernels leave the channel sums of what they write (the bias gradients
+        # of up2 / up1) as slabs for the reduction launch
+        wbias = want_w and self.wide and _WINO16_BIAS and Ls["conv2"].wp_w is not None
 
         if not self.heads3:
             g5 = self._dx_conv(Ls["conv2_cls"], dl2, a["y5"], mask=a["y5"])
@@ -582,6 +597,9 @@ class TrainEngine:
             side_wgrad(self._wgrad_conv, Ls["conv2"], g5, a["y4"])
         if wg3:     # up2's bias gradient = the channel sums of g4: left by the kernel that writes g4
             g4, up2_bias_done = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"], bias_out=Ls["up2"].gb)
+        elif wbias:
+            g4, done = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"], bias_out=Ls["up2"].gb)
+            side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"], bias=not done)
         else:
             g4 = self._dx_conv(Ls["conv2"], g5, a["y4"], mask=a["y4"])
             side_wgrad(self._wgrad_convT, Ls["up2"], g4, a["y3"])
@@ -596,6 +614,9 @@ class TrainEngine:
             side_wgrad(self._wgrad_conv, Ls["conv1"], g3, a["y2"])
         if wg3:
             g2, up1_bias_done = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"], bias_out=Ls["up1"].gb)
+        elif wbias:
+            g2, done = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"], bias_out=Ls["up1"].gb)
+            side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"], bias=not done)
         else:
             g2 = self._dx_conv(Ls["conv1"], g3, a["y2"], mask=a["y2"])
             side_wgrad(self._wgrad_convT, Ls["up1"], g2, a["y1"])

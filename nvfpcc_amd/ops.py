@@ -280,17 +280,22 @@ def pack_wino16_k4(w):
     return wp
 
 
-def conv3d_k4_wino16_bwd(dy, wp, mask, out=None, ppc=0):
-    """conv3d_k4_wino_bwd for 16 -> 16 channels (the wide decoder): dx = mask > 0 ? conv_full(dy, w) : 0."""
+def conv3d_k4_wino16_bwd(dy, wp, mask, out=None, ppc=0, bias_part=None):
+    """conv3d_k4_wino_bwd for 16 -> 16 channels (the wide decoder): dx = mask > 0 ? conv_full(dy, w) : 0.  ``bias_part``:
+    device address of the slabs that receive the 16 channel sums of dx per work unit; returns (dx, number of slabs) then."""
+    import ctypes
     _f32(dy, wp, mask)
     B, c, di = dy.shape[0], dy.shape[1], dy.shape[2]
     shape = (B, 16, di + 3, di + 3, di + 3)
     if c != 16 or tuple(mask.shape) != shape:
         raise RuntimeError("conv3d_k4_wino16_bwd: dy [B,16,n^3], mask [B,16,(n+3)^3]")
     dx = out if out is not None else torch.empty(shape, device=dy.device)
-    check(lib().nvf_conv3d_k4_wino16_bwd(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(mask), B, di, int(ppc), _stream()),
+    nparts = ctypes.c_int(0)
+    check(lib().nvf_conv3d_k4_wino16_bwd(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(mask), B, di, int(ppc),
+                                         None if bias_part is None else int(bias_part),
+                                         ctypes.byref(nparts) if bias_part is not None else None, _stream()),
           "nvf_conv3d_k4_wino16_bwd")
-    return dx
+    return dx if bias_part is None else (dx, nparts.value)
 
 
 def conv3d_k4_wino16_fwd(x, wp, bias, out=None, ppc=0):

@@ -1014,6 +1014,13 @@ def test_conv3d_k4_wino16_backward_data(ops, n, B, ppc):
     assert bool(((dx.cpu() == 0) >= (mask <= 0)).all())
     dx_direct = ops.conv3d_g16_mfma(dev(gy), ops.pack_g16_mfma(wb, 16, 16, 4), None, 16, 4, 1, 3, (n, n, n), mask=dev(mask))
     assert rel_err(dx, dx_direct.cpu()) < 1e-5
+    # the channel sums it leaves per work unit (the bias gradient of the layer below): slabs of 16 floats
+    slabs = torch.full((8192 * 16,), float("nan"), device=dx.device)
+    dx2, nparts = ops.conv3d_k4_wino16_bwd(dev(gy), ops.pack_wino16_k4(wb), dev(mask), ppc=ppc, bias_part=slabs.data_ptr())
+    assert torch.equal(dx2, dx) and 0 < nparts <= 8192
+    sums = slabs[:16 * nparts].view(nparts, 16).double().sum(0).cpu()
+    want = dx.double().sum(dim=(0, 2, 3, 4)).cpu()
+    assert float((sums - want).abs().max()) < 1e-4 * float(want.abs().max() + dx.abs().max().cpu() * 100)
 
 
 @pytest.mark.parametrize("w,B,zsplit", [(32, 1, 0), (32, 5, 0), (32, 16, 0), (32, 3, 2), (32, 20, 0), (16, 1, 0), (16, 5, 0), (16, 16, 0), (16, 3, 1)])
