@@ -522,7 +522,8 @@ class TrainEngine:
         self._bias_jobs = []
         self._bias_cover = []     # bias gradients some launch's own final pass writes (no channel-sum job needed)
         if self._wg is None:
-            self._wg = ops.WgradBatch(self.dev, ctx=self.ctx)    # partial sums now, ONE reduction launch for all ten
+            # (wide decoder: 125 MiB of slabs at batch 16 -- a workspace that had to grow mid-step would be reallocated)
+            self._wg = ops.WgradBatch(self.dev, nbytes=(256 if self.wide else 128) << 20, ctx=self.ctx)    # partial sums now, ONE reduction launch for all ten
         loss = torch.empty(4, device=self.dev)   # [main, head0, head1, unused]
         nbits = torch.empty(7, device=self.dev)
         # the one-block final passes of the focal terms, the bias sums and the weight rate feed nothing inside the
