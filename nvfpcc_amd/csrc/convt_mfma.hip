@@ -123,19 +123,21 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
     }
   };
   {
-    float4 av[NA4];
+    // the A fragments go L2 -> LDS by DMA (1 KB per wave instruction, no registers); the first item's planes and the zero
+    // fill of the image pass under their latency
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    if (!(NVF_CT_DBG & 4)) {
 #pragma unroll
-    for (int u = 0; u < NA4; ++u) {
-      const int i = tid + u * NTH;
-      av[u] = (i < T::AS / 4 && !(NVF_CT_DBG & 4)) ? ((const float4*)wp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < NA4; ++u) {
+        const int i = tid + u * NTH;
+        if (i < T::AS / 4)
+          __builtin_amdgcn_global_load_lds((glb_vp)(wp + (size_t)i * 4), (lds_vp)(as + (u * NTH + wave * 64) * 4), 16, 0, 0);
+      }
     }
     if ((int)blockIdx.x < items) load_x(blockIdx.x);
     for (int i = tid * 4; i < T::XS; i += NTH * 4) *(float4*)(xs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < NA4; ++u) {
-      const int i = tid + u * NTH;
-      if (i < T::AS / 4) ((float4*)as)[i] = av[u];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the first __syncthreads of the item loop publishes it)
   }
   const int j = lane & 15, kq = lane >> 4;
   const size_t cstride = (size_t)NOUT * NOUT * NOUT;
