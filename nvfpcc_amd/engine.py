@@ -466,7 +466,8 @@ class TrainEngine:
             return dx if bias_out is None else (dx, False)
         if L.wp_w is not None and mask is not None and addend is None and g_out.shape[-1] in (32, 16):
             if bias_out is not None:
-                base = self._wg.reserve(4096 * 8 * 4) if g_out.shape[0] <= 64 else None
+                # (one slab of 8 sums per work unit: 126 units per block in conv2's default kernel, conv_wino1.hip)
+                base = self._wg.reserve(16384 * 8 * 4) if g_out.shape[0] <= 64 else None
                 if base is not None:
                     dx, nparts = ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask, bias_part=base)
                     self._wg.add_job(base, bias_out, nparts, 8)

@@ -960,7 +960,8 @@ def test_threshold_points_match_nonzero(ops):
         assert torch.equal(counts.cpu().long(), (p[:, 0] > thh).flatten(1).sum(1))
 
 
-@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 2), (35, 3, 16), (19, 1, 0), (19, 5, 0), (19, 16, 4)])
+@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 2), (35, 3, 16), (35, 16, 4), (35, 3, 65537),
+                                      (35, 2, 65544), (19, 1, 0), (19, 5, 0), (19, 16, 4)])
 def test_conv3d_k4_wino_forward(ops, n, B, ppc):
     """The training-step forward of conv2 / conv1 in the Winograd form against torch's conv3d on the CPU (float64) and
     against the direct fixed-order matrix-core kernel: 1e-5 of max |y| (measured 1e-6), zeros of the ReLU in the same
@@ -1043,7 +1044,7 @@ def test_wgrad16_k4_wino(ops, w, B, zsplit):
     assert rel_err(dw.view(16, 16, 4, 4, 4), wt.grad) < 2e-5, rel_err(dw.view(16, 16, 4, 4, 4), wt.grad)
 
 
-@pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (2, 2), (3, 18)])
+@pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (2, 2), (3, 18), (16, 6), (3, 65537), (2, 65545)])
 def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     """conv2's backward-data in the reduced-multiplication form (conv_wino.hip: Winograd F(2x2, 4x4) over (y, x), direct
     over z on the matrix cores) against torch's autograd of F.conv3d on the CPU, through the ReLU mask of the layer below,
@@ -1057,6 +1058,27 @@ def test_conv3d_k4_wino_backward_data(ops, B, ppc):
 def test_conv3d_k4_wino_backward_data_conv1(ops, B, ppc):
     """... and conv1's (16^3 -> 19^3: 10 x 10 tiles, three tile rows per group of sixteen)."""
     _wino_bwd_case(ops, 19, B, ppc)
+
+
+def test_conv2_winograd_kernels_give_the_same_bits(ops):
+    """conv2's default Winograd kernel keeps one accumulator set per wave and runs two waves per SIMD (conv_wino1.hip; ppc 0
+    or bit 16 of ppc); the two-set kernel of conv_wino.hip (an explicit ppc) walks every plane once.  Every output's sum
+    has the same order in both -- taps 0..4, channel group 0 then 1 -- so forward and backward-data agree bit for bit, at
+    any chunking of the z pairs."""
+    g = gen(4450)
+    for B in (1, 5, 16):
+        x = torch.relu(torch.randn(B, 8, 35, 35, 35, generator=g) * 0.7)
+        gy = torch.randn(B, 8, 32, 32, 32, generator=g) * (torch.rand(B, 8, 32, 32, 32, generator=g) < 0.6)
+        w = torch.randn(8, 8, 4, 4, 4, generator=g) * 0.08
+        b = torch.randn(8, generator=g) * 0.3
+        wf, wb = ops.pack_conv_weight(dev(w))
+        wpf, wpb = ops.pack_wino_k4(wf), ops.pack_wino_k4(wb)
+        y = ops.conv3d_k4_wino_fwd(dev(x), wpf, dev(b))                      # default: conv_wino1.hip
+        for ppc in (4, 2, 65537, 65540):
+            assert torch.equal(ops.conv3d_k4_wino_fwd(dev(x), wpf, dev(b), ppc=ppc), y), (B, ppc)
+        dx = ops.conv3d_k4_wino_bwd(dev(gy), wpb, dev(x))
+        for ppc in (6, 2, 65537, 65542):
+            assert torch.equal(ops.conv3d_k4_wino_bwd(dev(gy), wpb, dev(x), ppc=ppc), dx), (B, ppc)
 
 
 def _wino_bwd_case(ops, n, B, ppc):
