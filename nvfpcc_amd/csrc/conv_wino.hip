@@ -362,7 +362,10 @@ static bool wino1_default() {
 
 int nvf_wino1_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int ppc, float* bias_part,
                   int* bias_nparts, hipStream_t s);
+int nvf_wino1_bwd16(const float* dy, const float* wp, float* dx, const float* mask, int batch, int ppc, float* bias_part,
+                    int* bias_nparts, hipStream_t s);
 int nvf_wino1_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int ppc, hipStream_t s);
+int nvf_wino1_fwd19(const float* x, const float* wp, const float* bias, float* y, int batch, int ppc, hipStream_t s);
 
 extern "C" int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din,
                                       int ppc, float* bias_part, int* bias_nparts, void* stream) {
@@ -370,10 +373,11 @@ extern "C" int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* d
   int rc;
   // conv2 (din 32): by default (ppc 0) the one-accumulator-set kernel with two waves per SIMD (conv_wino1.hip: the same
   // bits, 44.1 -> 42.8 us in the step); an explicit ppc selects the kernel below, bit 16 of ppc the other one
-  if (din == 32 && (ppc & 0x100ff) == 0 && wino1_default()) ppc |= 1 << 16;
+  if ((din == 32 || din == 16) && (ppc & 0x100ff) == 0 && wino1_default()) ppc |= 1 << 16;   // (conv1: 18.8 -> 16.7 us)
   if ((ppc >> 16) & 1) {
-    if (din != 32) return NVF_EINVAL;
-    rc = nvf_wino1_bwd(dy, wp, dx, mask, batch, ppc & 255, bias_part, bias_nparts, nvf_stream(stream));
+    if (din == 32) rc = nvf_wino1_bwd(dy, wp, dx, mask, batch, ppc & 255, bias_part, bias_nparts, nvf_stream(stream));
+    else if (din == 16) rc = nvf_wino1_bwd16(dy, wp, dx, mask, batch, ppc & 255, bias_part, bias_nparts, nvf_stream(stream));
+    else return NVF_EINVAL;
     if (rc != NVF_OK) return rc;
     NVF_LAUNCH_CHECK();
     return NVF_OK;
@@ -396,8 +400,9 @@ extern "C" int nvf_conv3d_k4_wino_fwd(const float* x, const float* wp, const flo
   int rc;
   if (din == 35 && (ppc & 0x100ff) == 0 && wino1_default()) ppc |= 1 << 16;        // conv2's forward: as above (31.3 -> 30.4 us)
   if ((ppc >> 16) & 1) {
-    if (din != 35) return NVF_EINVAL;
-    rc = nvf_wino1_fwd(x, wp, bias, y, batch, ppc & 255, nvf_stream(stream));
+    if (din == 35) rc = nvf_wino1_fwd(x, wp, bias, y, batch, ppc & 255, nvf_stream(stream));
+    else if (din == 19) rc = nvf_wino1_fwd19(x, wp, bias, y, batch, ppc & 255, nvf_stream(stream));
+    else return NVF_EINVAL;
     if (rc != NVF_OK) return rc;
     NVF_LAUNCH_CHECK();
     return NVF_OK;

@@ -22,7 +22,7 @@ struct W1Dims {
   float* bias_part;
 };
 
-template <int DIN_, int PAD_>
+template <int DIN_, int PAD_, int NWAVE_ = 8>
 struct W1Cfg {
   static constexpr int DIN = DIN_, PAD = PAD_, DOUT = DIN_ + 2 * PAD_ - 3, TPR = (DOUT + 1) / 2, NTILE = TPR * TPR;
   static constexpr int NCG = (NTILE + 15) / 16, NPAIR = TPR;
@@ -38,12 +38,12 @@ struct W1Cfg {
   static constexpr int cs_for() { int c = NR * RS; while (c % 64 != 32) ++c; return c; }
   static constexpr int CS = cs_for();
   static constexpr int BUF = 8 * CS;
-  static constexpr int NWAVE = 8;
+  static constexpr int NWAVE = NWAVE_;
   static_assert((kWino1AFloats + NWAVE * BUF) * 4 <= 160 * 1024, "LDS");
 };
 
 template <class C, int EPI>
-__global__ __launch_bounds__(512, 2) void conv_k4_wino1(const float* __restrict__ g, const float* __restrict__ wp,
+__global__ __launch_bounds__(C::NWAVE * 64, 2) void conv_k4_wino1(const float* __restrict__ g, const float* __restrict__ wp,
                                                         float* __restrict__ y, const float* __restrict__ mask, W1Dims d) {
   constexpr int DIN = C::DIN, PAD = C::PAD, DOUT = C::DOUT, TPR = C::TPR, RS = C::RS, CS = C::CS, NLD = C::NLD;
   __shared__ __attribute__((aligned(16))) float lds[kWino1AFloats + C::NWAVE * C::BUF];
@@ -218,13 +218,13 @@ __global__ __launch_bounds__(512, 2) void conv_k4_wino1(const float* __restrict_
   };
   if (!idle) fetch(2 * q0);
   {
-    constexpr int NV = kWino1AFloats / 4, NI = (NV + 511) / 512;
+    constexpr int NT = C::NWAVE * 64, NV = kWino1AFloats / 4, NI = (NV + NT - 1) / NT;
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef const __attribute__((address_space(1))) void* glb_vp;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      if (i * 512 + tid < NV)
-        __builtin_amdgcn_global_load_lds((glb_vp)(wp + (size_t)(i * 512 + tid) * 4), (lds_vp)(lds + (i * 512 + wave * 64) * 4), 16, 0, 0);
+      if (i * NT + tid < NV)
+        __builtin_amdgcn_global_load_lds((glb_vp)(wp + (size_t)(i * NT + tid) * 4), (lds_vp)(lds + (i * NT + wave * 64) * 4), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
@@ -260,7 +260,7 @@ static int launch_wino1(const float* x, const float* wp, float* y, const float* 
   W1Dims d{batch, batch * nchunk * C::NCG, ppc, bias_part};
   const int grid = ((d.units + C::NWAVE - 1) / C::NWAVE + 7) / 8 * 8;
   if (bias_nparts) *bias_nparts = grid * C::NWAVE;
-  conv_k4_wino1<C, EPI><<<grid, 512, 0, s>>>(x, wp, y, aux, d);
+  conv_k4_wino1<C, EPI><<<grid, C::NWAVE * 64, 0, s>>>(x, wp, y, aux, d);
   return NVF_OK;
 }
 
@@ -269,6 +269,13 @@ int nvf_wino1_bwd(const float* dy, const float* wp, float* dx, const float* mask
                   int* bias_nparts, hipStream_t s) {
   return launch_wino1<W1Cfg<32, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 3, bias_part, bias_nparts, s);
 }
+int nvf_wino1_bwd16(const float* dy, const float* wp, float* dx, const float* mask, int batch, int ppc, float* bias_part,
+                    int* bias_nparts, hipStream_t s) {       // conv1 (16^3 -> 19^3): six waves per workgroup fit the LDS
+  return launch_wino1<W1Cfg<16, 3, 6>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 1, bias_part, bias_nparts, s);
+}
 int nvf_wino1_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int ppc, hipStream_t s) {
   return launch_wino1<W1Cfg<35, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 2, nullptr, nullptr, s);
+}
+int nvf_wino1_fwd19(const float* x, const float* wp, const float* bias, float* y, int batch, int ppc, hipStream_t s) {
+  return launch_wino1<W1Cfg<19, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 1, nullptr, nullptr, s);
 }

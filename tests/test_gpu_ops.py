@@ -1054,7 +1054,7 @@ def test_conv3d_k4_wino_backward_data(ops, B, ppc):
     _wino_bwd_case(ops, 35, B, ppc)
 
 
-@pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (3, 4), (2, 10)])
+@pytest.mark.parametrize("B,ppc", [(1, 0), (5, 0), (16, 0), (3, 4), (2, 10), (16, 2), (3, 65538)])
 def test_conv3d_k4_wino_backward_data_conv1(ops, B, ppc):
     """... and conv1's (16^3 -> 19^3: 10 x 10 tiles, three tile rows per group of sixteen)."""
     _wino_bwd_case(ops, 19, B, ppc)
@@ -1079,6 +1079,12 @@ def test_conv2_winograd_kernels_give_the_same_bits(ops):
         dx = ops.conv3d_k4_wino_bwd(dev(gy), wpb, dev(x))
         for ppc in (6, 2, 65537, 65542):
             assert torch.equal(ops.conv3d_k4_wino_bwd(dev(gy), wpb, dev(x), ppc=ppc), dx), (B, ppc)
+        # conv1's backward-data (16^3 -> 19^3): the default is the one-set kernel with six waves per workgroup
+        x1 = torch.randn(B, 8, 19, 19, 19, generator=g)
+        gy1 = torch.randn(B, 8, 16, 16, 16, generator=g)
+        dx1 = ops.conv3d_k4_wino_bwd(dev(gy1), wpb, dev(x1))
+        for ppc in (2, 4, 65537, 65539):
+            assert torch.equal(ops.conv3d_k4_wino_bwd(dev(gy1), wpb, dev(x1), ppc=ppc), dx1), (B, ppc)
 
 
 def _wino_bwd_case(ops, n, B, ppc):
