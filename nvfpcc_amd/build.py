@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnvf_hip.so")
 CODEC_LIB = os.path.join(HERE, "libnvf_codec.so")
-SOURCES = ["conv_direct.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino1.hip", "conv16_wino.hip", "conv16_mfma.hip", "wgrad16_mfma.hip", "wgrad16_wino.hip", "convt16_mfma.hip", "convt_mfma.hip", "convs2_mfma.hip", "pack_mfma.hip", "heads.hip", "heads_wgrad_mfma.hip", "wgrad.hip", "pointwise.hip", "stem.hip", "finals.hip", "preprocess.hip"]
+SOURCES = ["conv_direct.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino1.hip", "conv16_wino.hip", "conv16_wino1.hip", "conv16_mfma.hip", "wgrad16_mfma.hip", "wgrad16_wino.hip", "convt16_mfma.hip", "convt_mfma.hip", "convs2_mfma.hip", "pack_mfma.hip", "heads.hip", "heads_wgrad_mfma.hip", "wgrad.hip", "pointwise.hip", "stem.hip", "finals.hip", "preprocess.hip"]
 
 
 def _stale(lib=LIB):

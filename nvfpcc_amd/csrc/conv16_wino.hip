@@ -335,10 +335,30 @@ static int launch_wino16(const float* x, const float* wp, float* y, const float*
 // ppc: pairs of output planes per work unit (0 = default).  bias_part (optional): *bias_nparts slabs of 16 channel sums of dx
 // (the bias gradient of the layer below; a jtotal = 16 job of nvf_wgrad_reduce_multi*).  NVF_EINVAL for shapes without an
 // instantiation.
+static bool wino161_default() {          // tuning hook: NVF_WINO16_1=0 keeps the two-plane kernel for the backward-data as well
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NVF_WINO16_1"); v = e ? atoi(e) != 0 : 1; }
+  return v != 0;
+}
+
+int nvf_wino16_1_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int ppc, hipStream_t s);
+int nvf_wino16_1_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int ppc, hipStream_t s);
+
 extern "C" int nvf_conv3d_k4_wino16_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din,
                                         int ppc, float* bias_part, int* bias_nparts, void* stream) {
   if (!dy || !wp || !dx || !mask || batch <= 0 || ppc < 0 || (bias_part && !bias_nparts)) return NVF_EINVAL;
   int rc;
+  // conv2's backward-data (din 32) without bias sums: by default the kernel with one output plane in flight and two waves
+  // per SIMD (conv16_wino1.hip: the same bits, 140 -> 133 us at batch 16, 534 -> 479 at 64; the forward is faster in the
+  // two-plane kernel below: 88 vs 100 us); an explicit ppc selects the kernel below, bit 16 of ppc the other one
+  if (din == 32 && !bias_part && (ppc & 0x100ff) == 0 && wino161_default()) ppc |= 1 << 16;
+  if ((ppc >> 16) & 1) {
+    if (din != 32 || bias_part) return NVF_EINVAL;
+    rc = nvf_wino16_1_bwd(dy, wp, dx, mask, batch, ppc & 255, nvf_stream(stream));
+    if (rc != NVF_OK) return rc;
+    NVF_LAUNCH_CHECK();
+    return NVF_OK;
+  }
   if (din == 32) rc = launch_wino16<W16Cfg<32, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 6, bias_part, bias_nparts, nvf_stream(stream));
   else if (din == 16) rc = launch_wino16<W16Cfg<16, 3>, 1>(dy, wp, dx, mask, batch, ppc ? ppc : 1, bias_part, bias_nparts, nvf_stream(stream));
   else return NVF_EINVAL;
@@ -353,6 +373,13 @@ extern "C" int nvf_conv3d_k4_wino16_fwd(const float* x, const float* wp, const f
                                         int ppc, void* stream) {
   if (!x || !wp || !bias || !y || batch <= 0 || ppc < 0) return NVF_EINVAL;
   int rc;
+  if ((ppc >> 16) & 1) {
+    if (din != 35) return NVF_EINVAL;
+    rc = nvf_wino16_1_fwd(x, wp, bias, y, batch, ppc & 255, nvf_stream(stream));
+    if (rc != NVF_OK) return rc;
+    NVF_LAUNCH_CHECK();
+    return NVF_OK;
+  }
   if (din == 35) rc = launch_wino16<W16Cfg<35, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 4, nullptr, nullptr, nvf_stream(stream));
   else if (din == 19) rc = launch_wino16<W16Cfg<19, 0>, 0>(x, wp, y, bias, batch, ppc ? ppc : 1, nullptr, nullptr, nvf_stream(stream));
   else return NVF_EINVAL;

@@ -996,7 +996,8 @@ def test_conv3d_k4_wino16_forward(ops, n, B, ppc):
     assert rel_err(y, y_direct.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 1), (35, 3, 18), (19, 1, 0), (19, 5, 0), (19, 16, 5)])
+@pytest.mark.parametrize("n,B,ppc", [(35, 1, 0), (35, 5, 0), (35, 16, 0), (35, 2, 1), (35, 3, 18), (35, 16, 6), (35, 3, 65539),
+                                      (19, 1, 0), (19, 5, 0), (19, 16, 5)])
 def test_conv3d_k4_wino16_backward_data(ops, n, B, ppc):
     """... and their backward-data through the ReLU mask of the layer below, against torch's autograd on the CPU; zeros
     exactly where the mask is not positive."""
@@ -1015,6 +1016,11 @@ def test_conv3d_k4_wino16_backward_data(ops, n, B, ppc):
     assert bool(((dx.cpu() == 0) >= (mask <= 0)).all())
     dx_direct = ops.conv3d_g16_mfma(dev(gy), ops.pack_g16_mfma(wb, 16, 16, 4), None, 16, 4, 1, 3, (n, n, n), mask=dev(mask))
     assert rel_err(dx, dx_direct.cpu()) < 1e-5
+    if n == 35:      # conv2: the one-plane kernel (conv16_wino1.hip, the default without bias sums) and the two-plane kernel: same bits
+        for other in (6, 65536 + 7):
+            assert torch.equal(ops.conv3d_k4_wino16_bwd(dev(gy), ops.pack_wino16_k4(wb), dev(mask), ppc=other), dx)
+    if ppc >> 16:
+        return       # (the one-plane kernel leaves no bias sums: NVF_EINVAL with bias_part)
     # the channel sums it leaves per work unit (the bias gradient of the layer below): slabs of 16 floats
     slabs = torch.full((8192 * 16,), float("nan"), device=dx.device)
     dx2, nparts = ops.conv3d_k4_wino16_bwd(dev(gy), ops.pack_wino16_k4(wb), dev(mask), ppc=ppc, bias_part=slabs.data_ptr())

@@ -110,7 +110,7 @@ def wide_main(B, reps):
         us = timeit(lambda: ops.conv3d_g16_mfma(x, wpf, b, 16, 4, 1, 0, (no, no, no), ops.ACT_RELU, out=out), reps)
         print(f"wide fwd {n} direct:            {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
         ww = ops.pack_wino16_k4(wf)
-        for ppc in ((4, 2, 8, 16) if n == 35 else (2, 1, 4, 8)):
+        for ppc in ((4, 2, 8, 16, 65540, 65538, 65544) if n == 35 else (2, 1, 4, 8)):     # bit 16: conv16_wino1.hip
             y = ops.conv3d_k4_wino16_fwd(x, ww, b, ppc=ppc)
             err = float((y - d).abs().max() / d.abs().max())
             us = timeit(lambda: ops.conv3d_k4_wino16_fwd(x, ww, b, out=out, ppc=ppc), reps)
@@ -119,7 +119,7 @@ def wide_main(B, reps):
         us = timeit(lambda: ops.conv3d_g16_mfma(gy, wpb, None, 16, 4, 1, 3, (n, n, n), mask=x, out=dxo), reps)
         print(f"wide bwd-data {n} direct:       {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
         ww = ops.pack_wino16_k4(wb)
-        for ppc in ((6, 3, 9, 18) if n == 35 else (2, 1, 5, 10)):
+        for ppc in ((6, 3, 9, 18, 65542, 65539, 65548) if n == 35 else (2, 1, 5, 10)):
             y = ops.conv3d_k4_wino16_bwd(gy, ww, x, ppc=ppc)
             err = float((y - d).abs().max() / d.abs().max())
             us = timeit(lambda: ops.conv3d_k4_wino16_bwd(gy, ww, x, out=dxo, ppc=ppc), reps)
