@@ -61,8 +61,8 @@ def main():
         return None
     tj = {"batch": 16, "chanstr": "8,16,8,8", "source": f"profiles/{tag}_pmc_traffic_b16.csv",
           "hbm_bytes_per_launch": {
-              "conv2_bwd_data": find("conv_k4_wino<WCfg<32, 3>") or find("conv_k4_mfma<MCvFlat<8, 18") or find("conv_gather_glds<GCfg<8, 8, 4, 1, 4, 9"),
-              "conv2_fwd": find("conv_k4_wino<WCfg<35, 0>") or find("conv_k4_mfma<MCv<8, 0, 1, 16"),
+              "conv2_bwd_data": find("conv_k4_wino1<W1Cfg<32, 3") or find("conv_k4_wino<WCfg<32, 3>") or find("conv_k4_mfma<MCvFlat<8, 18") or find("conv_gather_glds<GCfg<8, 8, 4, 1, 4, 9"),
+              "conv2_fwd": find("conv_k4_wino1<W1Cfg<35, 0") or find("conv_k4_wino<WCfg<35, 0>") or find("conv_k4_mfma<MCv<8, 0, 1, 16"),
               "conv2_bwd_weight": find("wgrad_mfma3_kernel") or find("wgrad_k4_mfma<MCfg<32")},
           "note": "conv2_bwd_weight is the one-launch kernel that also holds the up2, conv1, up1 and conv0 weight gradients"}
     json.dump(tj, open(os.path.join(prof, f"{tag}_traffic.json"), "w"), indent=1)
