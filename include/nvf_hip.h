@@ -151,7 +151,10 @@ int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const float* bias, 
  * below).  wp = nvf_pack_mfma_all kind 40 (c0 = c1 = 8) of the layer's gather-form backward weights w_bwd,
  * nvf_pack_wino_k4_floats() floats.  ppc = pairs of output planes per work unit (0: default).  bias_part (optional):
  * *bias_nparts slabs of 8 floats, the channel sums of dx per work unit (the bias gradient of the layer below, a
- * jtotal = 8 job of nvf_wgrad_reduce_multi).  NVF_EINVAL = no instantiation (din 32: conv2, 16: conv1; ppc even). */
+ * jtotal = 8 job of nvf_wgrad_reduce_multi).  NVF_EINVAL = no instantiation (din 32: conv2, 16: conv1).
+ * Two kernels compute this, with the same bits: conv_wino1.hip (one accumulator set per wave, two waves per SIMD: the
+ * default, ppc = 0, or bit 16 of ppc set with the low byte = pairs per work unit) and conv_wino.hip (two sets, every plane
+ * walked once: an explicit even ppc in the low byte). */
 size_t nvf_pack_wino_k4_floats(void);
 int nvf_conv3d_k4_wino_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
                            float* bias_part, int* bias_nparts, void* stream);
@@ -167,7 +170,9 @@ int nvf_conv3d_k4_wino_fwd(const float* x, const float* wp, const float* bias, f
  * wp = nvf_pack_mfma_all kind 41 (c0 = c1 = 16) of w_bwd (backward-data) / w_fwd (forward), nvf_pack_wino16_k4_floats()
  * floats.  bwd: dy [batch, 16, din^3] (din 32 / 16), dx, mask [batch, 16, (din + 3)^3]; fwd: x [batch, 16, din^3]
  * (din 35 / 19), y [batch, 16, (din - 3)^3].  ppc = pairs of output planes per work unit (0: default).  bias_part (optional,
- * bwd): *bias_nparts slabs of 16 floats, the channel sums of dx per work unit (a jtotal = 16 job of nvf_wgrad_reduce_multi*). */
+ * bwd): *bias_nparts slabs of 16 floats, the channel sums of dx per work unit (a jtotal = 16 job of nvf_wgrad_reduce_multi*).
+ * conv2's backward-data without bias_part runs, by default (ppc 0; or bit 16 of ppc with the low byte = output planes per
+ * work unit), in conv16_wino1.hip: one output plane in flight per wave, two waves per SIMD -- the same bits. */
 size_t nvf_pack_wino16_k4_floats(void);
 int nvf_conv3d_k4_wino16_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int din, int ppc,
                              float* bias_part, int* bias_nparts, void* stream);
