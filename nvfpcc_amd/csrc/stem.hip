@@ -214,11 +214,15 @@ __global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restri
   }
 }
 
+#ifndef NVF_STEM_COG
+#define NVF_STEM_COG 4      // narrow decoder: conv0 output channels per workgroup (tuning: 2, 1)
+#endif
+
 template <int C0, int C1, bool LATENT>
 static int launch_stem_fwd(const float* x0, const float* up0_w_fwd, const float* up0_b, const float* beta_hat,
                            const float* gamma_hat, const float* conv0_w_fwd, const float* conv0_b, float* a0, float* h0,
                            float* y1, int batch, int ch, const StemLatent& L, void* stream) {
-  constexpr int COG = C0 == 16 ? 2 : 4, PARTS = C1 / (COG * (C0 / 8));   // (wide: 51 us with four channels per group, 40 with two, 48 with one)
+  constexpr int COG = C0 == 16 ? 2 : NVF_STEM_COG, PARTS = C1 / (COG * (C0 / 8));   // (wide: 51 us with four channels per group, 40 with two, 48 with one)
   stem_fwd_kernel<C0, C1, COG, LATENT><<<dim3(batch, PARTS + (LATENT ? 1 : 0)), C0 * 64, 0, nvf_stream(stream)>>>(
       x0, up0_w_fwd, up0_b, beta_hat, gamma_hat, conv0_w_fwd, conv0_b, a0, h0, y1, ch, L);
   NVF_LAUNCH_CHECK();
