@@ -1,7 +1,8 @@
 // Backward-data (and the training-step forward) of the 4x4x4 convolutions (conv2: 32^3 <-> 35^3, conv1: 16^3 <-> 19^3;
 // 8 -> 8 channels) in a reduced-multiplication form: Winograd F(2x2, 4x4) over (y, x), direct over z with the pair trick of conv_mfma.hip.
-// Reference site: the autograd backward of F.conv3d, utils/network.py:687 (NVFPCC.py:197).  Backward passes only:
-// the forward keeps the direct fixed-order form (bit-exact batch invariance, the 2e-6 occupancy contract).
+// Reference site: F.conv3d in mode 'train' and its autograd backward, utils/network.py:687 (NVFPCC.py:160, 197).  Training
+// steps only: the eval / encode / decode forward keeps the direct fixed-order form (bit-exact batch invariance, the 2e-6
+// occupancy contract).
 //
 //   out[ci, z, y, x] = sum_co sum_{tz,ty,tx} g[co, z + tz, y + ty, x + tx] w'[co][tz,ty,tx][ci]        (gather form: g is
 //   the zero-padded output gradient, w' = w_bwd, the flipped kernel).  For the 2 x 2 outputs of tile (R, X) on plane z:
@@ -19,9 +20,11 @@
 // and channel, so the transformed data never leaves the registers of the lane that computed it: raw 5 x 5 windows are
 // read from the wave's own LDS image of the plane (flattened tiles: 16 consecutive tiles of the 18 x 18 tile plane; row
 // stride 50 = 18 (mod 32) makes the window reads of 16 tiles x 2 channels conflict-free 8-byte reads), transformed by
-// 90 VALU operations per (plane, channel group) and multiplied into up to three live pairs (75 MFMAs).  A wave walks a
-// chunk of pairs down z with three rotating accumulator sets (25 frequencies x 4 registers each); a finished pair goes
-// through the inverse transform in registers and leaves as 8-byte stores behind the ReLU mask.  Planes are fetched one
+// 57 vector instructions per (plane, channel group) (wino_common.h) and multiplied into up to three live pairs (75 MFMAs).  A
+// wave walks a chunk of pairs down z with TWO accumulator sets (25 frequencies x 4 registers each; the plane that completes a
+// pair is multiplied into its set first, the pair is emitted, and the same set starts the next pair); a finished pair goes
+// through the inverse transform in registers and leaves as 8-byte stores behind the ReLU mask.  (conv_wino1.hip is the
+// one-set, two-waves-per-SIMD form of the same arithmetic and the default for conv2 and conv1's backward-data.)  Planes are fetched one
 // ahead with 16-byte buffer loads (8 rows per instruction) held in registers and committed to LDS after the current
 // plane's reads; no barrier after the prologue -- waves share only the A fragments (64 KB of LDS per workgroup).
 #include "wino_common.h"
