@@ -233,14 +233,16 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
     const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
     const bool ok = i < ITEMS && gz >= 0 && gz < S && gy >= 0 && gy < S;
     const size_t off = ok ? b * vol + ((size_t)gz * S + gy) * S + 4 * xq : 0;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // (unconditional loads from a valid address, then a select: `ok ? *p : zero` becomes a select of ADDRESSES -- a
     // private zero against the global pointer -- i.e. four flat_load_dword per element instead of one global_load_dwordx4)
     const float4 pl = *(const float4*)(f.p + off), gl = *(const float4*)(f.gt + off);
     const float4 dl4 = *(const float4*)((f.dist ? f.dist : f.p) + off);
-    pv[u] = ok ? pl : z4;
-    gv[u] = ok ? gl : z4;
-    dv[u] = ok && f.dist ? dl4 : z4;
+    // (component selects: `ok ? pl : z4` on the float4 STRUCT is a select of two memory copies -- both values went
+    // through scratch memory and came back by a flat load)
+    const bool okd = ok && f.dist;
+    pv[u] = make_float4(ok ? pl.x : 0.f, ok ? pl.y : 0.f, ok ? pl.z : 0.f, ok ? pl.w : 0.f);
+    gv[u] = make_float4(ok ? gl.x : 0.f, ok ? gl.y : 0.f, ok ? gl.z : 0.f, ok ? gl.w : 0.f);
+    dv[u] = make_float4(okd ? dl4.x : 0.f, okd ? dl4.y : 0.f, okd ? dl4.z : 0.f, okd ? dl4.w : 0.f);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
