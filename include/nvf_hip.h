@@ -57,6 +57,12 @@ int nvf_step_ctx_init(NvfStepCtx* ctx);
  * arithmetic that follows the reference's training trajectory to 1e-7 (torch's conv backward, NVFPCC.py:164-172);
  * 0 (default): the reduced-multiplication forms, statistically equivalent training. */
 int nvf_step_ctx_set_direct(NvfStepCtx* ctx, int on);
+/* Forms of the merged weight-gradient launches (nvf_wgrad_mfma3_partial / nvf_wgrad_trunk5_*) when the context does not
+ * ask for the direct ones: conv2_zsplit in 0..8 (0 = default 1): z work items of conv2's Winograd gradient; conv1_wino
+ * != 0: conv1's gradient in the Winograd form as well.  Each choice is another summation order (agreement to fp32
+ * rounding): it belongs to the caller's context, the library reads no environment variable for it.  NVF_EINVAL outside
+ * the ranges. */
+int nvf_step_ctx_set_wgrad_forms(NvfStepCtx* ctx, int conv2_zsplit, int conv1_wino);
 
 /* Adam fused into the launch that produces a gradient: an element g_base[i] written by that launch is followed by the
  * nvf_step_tail update of p_base[i], m_base[i], v_base[i] (same coefficients, same arithmetic, same non-finite rule;
@@ -320,6 +326,23 @@ int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, cons
                          float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs, void* workspace,
                          size_t workspace_bytes, int batch, int ch, int c0, int c1, const float* h0,
                          float** dw_conv0_slabs, NvfStepCtx* ctx, void* stream);
+
+/* The same work with NO launch of its own (narrow decoder, c0 = 8, c1 = 16, batch <= 32): queued in `ctx`, it runs as the
+ * first workgroups of the next five-job weight-gradient launch given that context (nvf_wgrad_trunk5_*), which must also
+ * carry a queued latent tail (nvf_latent_tail_queue: the tail is the only consumer of dx0 inside that launch; its
+ * dx_addend argument is ignored there).  The stem's backward depends on g1 alone, exactly like conv0's weight gradient
+ * in that launch (autograd backward of network.py:4759-4760, gdn_3d.py:137-159).  Needs an open finals queue
+ * (nvf_finals_begin).  Outputs as nvf_stem_bwd_partial (same sums, same order, same bits), plus *bias_slabs: `batch`
+ * slabs of c0 floats inside `workspace` whose sum is up0's bias gradient (a jtotal = c0 job of nvf_wgrad_reduce_multi*).
+ * da0 / dx0 exist once that launch has run.  flags: batch + 1 uint32 words of device memory, zero before the first use
+ * (the launch leaves them zero).  NVF_EINVAL: another shape, no open queue, or a stem backward already queued.
+ * nvf_latent_tail_cancel also drops a queued stem backward. */
+int nvf_stem_bwd_queue(NvfStepCtx* ctx, const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,
+                       const float* up0_w_bwd, const float* beta_hat, const float* gamma_hat, float* da0, float* dx0,
+                       float* dbeta_hat, float* dgamma_hat, float** dw_slabs, int* nslabs, float** bias_slabs,
+                       void* workspace, size_t workspace_bytes, uint32_t* flags, int batch, int ch, int c0, int c1,
+                       void* stream);
+int nvf_stem_bwd_pending(const NvfStepCtx* ctx);
 
 /* ---- weight gradient (autograd backward of network.py:621,687,741) --------------
  * dw[a][b][k] (+)= sum_{n,i} p[n,a,i] * q[n,b, stride*i - pad + k]      (out_mode 0)

@@ -22,6 +22,7 @@ PROTOTYPES = {
     "nvf_step_ctx_bytes": (Z, []),
     "nvf_step_ctx_init": (I, [P]),
     "nvf_step_ctx_set_direct": (I, [P, I]),
+    "nvf_step_ctx_set_wgrad_forms": (I, [P, I, I]),
     "nvf_pack_conv_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_pack_convT_weight": (I, [P, I, I, I, P, P, P]),
     "nvf_effective_params": (I, [P, P, P, P, I, P, P, P, I, I, U, U, P]),
@@ -84,6 +85,8 @@ PROTOTYPES = {
     "nvf_multi_channel_sum": (I, [P, P, P, P, I, I, P, Z, P, P]),
     "nvf_wgrad_reduce_multi_and_sums": (I, [P, P, P, P, I, P, P, P, P, I, I, P, Z, P, P]),
     "nvf_latent_tail_queue": (I, [P, P, P, P, P, P, P, P, P, P, F, I, U, U, P, P, P, P, P, P, P, P, P, P, I, I, I]),
+    "nvf_stem_bwd_queue": (I, [P] * 16 + [Z, P, I, I, I, I, P]),
+    "nvf_stem_bwd_pending": (I, [P]),
     "nvf_latent_tail_pending": (I, [P]),
     "nvf_latent_tail_cancel": (None, [P]),
     "nvf_finals_begin": (I, [P]),

@@ -335,11 +335,8 @@ static int launch_wino16(const float* x, const float* wp, float* y, const float*
 // ppc: pairs of output planes per work unit (0 = default).  bias_part (optional): *bias_nparts slabs of 16 channel sums of dx
 // (the bias gradient of the layer below; a jtotal = 16 job of nvf_wgrad_reduce_multi*).  NVF_EINVAL for shapes without an
 // instantiation.
-static bool wino161_default() {          // tuning hook: NVF_WINO16_1=0 keeps the two-plane kernel for the backward-data as well
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NVF_WINO16_1"); v = e ? atoi(e) != 0 : 1; }
-  return v != 0;
-}
+// (a caller that wants the two-plane kernel for the backward-data as well passes an explicit ppc: no process-wide switch)
+static constexpr bool wino161_default() { return true; }
 
 int nvf_wino16_1_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int ppc, hipStream_t s);
 int nvf_wino16_1_fwd(const float* x, const float* wp, const float* bias, float* y, int batch, int ppc, hipStream_t s);

@@ -509,8 +509,7 @@ extern "C" int nvf_conv3d_k4_mfma_bias(const float* x, const float* wp, const fl
   if (bias_part && (!bias_nparts || bias || act != NVF_ACT_NONE || addend || !mask)) return NVF_EINVAL;
   MDims d{din, hin, win, dout, hout, wout, pad, act, 0, 0, 0, 0, bias_part};
   if (variant >= 100) { d.dbg = variant / 100; variant %= 100; }
-  static const int a_global = getenv("NVF_A_GLOBAL") ? 4 : 0;
-  d.dbg |= a_global;
+  d.dbg |= nvf_tune_int("NVF_A_GLOBAL", 0) ? 4 : 0;
   hipStream_t s = nvf_stream(stream);
   int rc = 1;
 #define NVF_M(VAR, CI, PA, WLO, WHI, CTY, CTX, RY, RX, NWC, NWZ, NT)                                   \

@@ -356,12 +356,8 @@ static int launch_wino(const float* x, const float* wp, float* y, const float* a
 // wp = nvf_pack_mfma_all kind 40 of the layer's w_bwd (nvf_pack_wino_k4_floats() floats).  bias_part (optional):
 // *bias_nparts slabs of 8 channel sums of dx (the bias gradient of the layer below).  ppc: pairs of output planes per
 // work unit (0 = default; even).  NVF_EINVAL for shapes without an instantiation.
-// tuning hook: NVF_WINO1=0 keeps the two-set kernel of this file for conv2 as well
-static bool wino1_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NVF_WINO1"); v = e ? atoi(e) != 0 : 1; }
-  return v != 0;
-}
+// (a caller that wants the two-set kernel of this file for conv2 passes an explicit ppc: no process-wide switch)
+static constexpr bool wino1_default() { return true; }
 
 int nvf_wino1_bwd(const float* dy, const float* wp, float* dx, const float* mask, int batch, int ppc, float* bias_part,
                   int* bias_nparts, hipStream_t s);

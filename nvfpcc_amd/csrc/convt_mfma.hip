@@ -270,9 +270,8 @@ extern "C" int nvf_pack_convT_mfma(const float* w_fwd, int cin, int cout, float*
 // workgroups per launch: 512 = two resident per CU, each walking items with a stride; NVF_CT_CAP (tuning) raises it so
 // that the dispatcher hands the items out one workgroup each
 static int convT_cap() {
-  static int cap = 0;
-  if (!cap) { const char* e = getenv("NVF_CT_CAP"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
-  return cap;
+  const int cap = nvf_tune_int("NVF_CT_CAP", 512);
+  return cap < 1 ? 512 : cap;
 }
 
 extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const float* bias, float* y, int batch, int cin,

@@ -91,11 +91,22 @@ extern "C" int nvf_step_ctx_init(NvfStepCtx* ctx) {
 }
 
 // on != 0: every launch that takes this context keeps the DIRECT arithmetic (no Winograd form of a weight gradient,
-// whatever NVF_WGRAD_WINO says) -- the summation order that reproduces the reference's training trajectory to 1e-7
+// whatever nvf_step_ctx_set_wgrad_forms asked for) -- the summation order that reproduces the reference's training trajectory to 1e-7
 // (tests/test_gpu_engine.py, the trajectory golden); 0 (the state after nvf_step_ctx_init): the faster forms.
 extern "C" int nvf_step_ctx_set_direct(NvfStepCtx* ctx, int on) {
   if (!nvf_ctx_ok(ctx)) return NVF_EINVAL;
   ctx->direct_forms = on ? 1 : 0;
+  return NVF_OK;
+}
+
+// Which reduced-multiplication forms the merged weight-gradient launches use when this context does NOT ask for the
+// direct forms: conv2_zsplit (1..8, 0 = the default 1) z work items per conv2 plane range; conv1_wino != 0: conv1's gradient
+// in the Winograd form too.  Both change the summation order (results agree to fp32 rounding), which is why they are the
+// caller's per-context choice and not an environment switch of the library.
+extern "C" int nvf_step_ctx_set_wgrad_forms(NvfStepCtx* ctx, int conv2_zsplit, int conv1_wino) {
+  if (!nvf_ctx_ok(ctx) || conv2_zsplit < 0 || conv2_zsplit > 8) return NVF_EINVAL;
+  ctx->wg_conv2_zsplit = conv2_zsplit;
+  ctx->wg_conv1_wino = conv1_wino ? 1 : 0;
   return NVF_OK;
 }
 

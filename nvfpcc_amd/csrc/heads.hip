@@ -732,7 +732,7 @@ extern "C" int nvf_heads3_wgrad_partial(const float* const* dls, const float* co
   if (!dls || !xs || !slabs || !cs || !ss || !nslabs || batch <= 0 || max_slabs <= 0) return NVF_EINVAL;
   const int t = heads3_tuple(cs, ss);
   // on the matrix cores (heads_wgrad_mfma.hip; NVF_HEADS_WG_VALU=1 keeps the VALU kernels: tuning)
-  static const bool valu = getenv("NVF_HEADS_WG_VALU") != nullptr;
+  const bool valu = nvf_tune_int("NVF_HEADS_WG_VALU", 0) != 0;
   if ((t == 0 || t == 1) && !valu) {
     const int rc = nvf_heads3_wgrad_mfma_launch(dls, xs, slabs, t == 0, batch, max_slabs, nslabs, nvf_stream(stream));
     if (rc != 1) {

@@ -518,9 +518,10 @@ __device__ __forceinline__ void gdn_bwd_one_workgroup(const float* __restrict__ 
 // one CU, so the stores only have to be complete -- a device-scope __threadfence() writes the XCD's L2 back (the L2s of
 // the eight XCDs are not coherent with each other), and with the host kernel's stores in flight each of the two cost
 // about 20 us (measured with s_memrealtime stamps: rate 23, GDN 20, weight gradient 8 us in the wide step).
-__device__ __forceinline__ void latent_tail_body(const LatentTail& t, float* lds) {
+// dx_addend: the decoder's gradient at the rounded latents (t.dx_addend, or the carrier launch's own copy of it)
+__device__ __forceinline__ void latent_tail_body(const LatentTail& t, float* lds, const float* dx_addend) {
   float* red = lds + kTailLds - 48;
-  latent_rate_body(t.lat, nullptr, t.block_ids, t.sigma, t.mu, nullptr, nullptr, t.dlat, t.dx_addend, t.dsigma, t.dmu,
+  latent_rate_body(t.lat, nullptr, t.block_ids, t.sigma, t.mu, nullptr, nullptr, t.dlat, dx_addend, t.dsigma, t.dmu,
                    t.g_dev, t.g_host, t.batch, t.c, t.spatial, t.mode, t.seed, t.step, t.step_dev, red, lds,
                    kTailLds - 48);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

@@ -12,6 +12,18 @@
 
 static inline hipStream_t nvf_stream(void* s) { return (hipStream_t)s; }
 
+// Tuning knobs.  A default build has NO environment reads and no mutable process-wide state ("no hidden
+// global state"): nvf_tune_int is the compile-time default.  A throw-away build with -DNVF_TUNING (tools/ab_build.py)
+// reads the knob from the environment on every call -- launch geometry only, never a choice of arithmetic: the forms
+// that change bits are selected by the caller through NvfStepCtx (nvf_step_ctx_set_direct / _set_wgrad_forms) or by an
+// explicit argument of the entry point.
+#ifdef NVF_TUNING
+#include <stdlib.h>
+static inline int nvf_tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr int nvf_tune_int(const char*, int dflt) { return dflt; }
+#endif
+
 __device__ __forceinline__ float nvf_act(float v, int act) {
   if (act == NVF_ACT_RELU) return fmaxf(v, 0.f);
   if (act == NVF_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));

@@ -914,8 +914,13 @@ __global__ void step_tail_kernel(NvfStepTail a) {
   if (a.sched_rows) {
     // thread 0's statistics read 1/n_pts from the step buffer (word batch + 1); the copy below overwrites that word from
     // another wave once the per-rank batch exceeds 62: order them (is_last is uniform over the workgroup)
+    // ... and the cursor is read ONCE, by thread 0, and broadcast: thread 0 advances it as soon as its own words are
+    // copied, so a wave that fetched it late would copy part of the NEXT row (mixed block ids / Adam coefficients once a
+    // row spans more than one wave: per-rank batches of 62 and more)
+    __shared__ unsigned long long cur_s;
+    if (threadIdx.x == 0) cur_s = a.sched_cursor[0];
     __syncthreads();
-    const unsigned long long c = a.sched_cursor[0];
+    const unsigned long long c = cur_s;
     const int64_t* row = a.sched_rows + c * (unsigned long long)a.sched_words;
     for (int w = threadIdx.x; w < a.sched_words; w += blockDim.x) a.sched_buf[w] = row[w];
     if (threadIdx.x == 0) a.sched_cursor[0] = c + 1;

@@ -15,6 +15,7 @@
 #include "nvf_common.h"
 #include "step_ctx.h"
 #include "latent_tail.h"
+#include "stem_bwd.h"
 
 namespace {
 constexpr int MAXCH = 8;
@@ -284,72 +285,8 @@ __global__ __launch_bounds__(C0 * 32) void stem_bwd_dh_kernel(const float* __res
                                                               const float* __restrict__ w1b /* [co][125][ci] */,
                                                               float* __restrict__ part, const float* __restrict__ h0,
                                                               float* __restrict__ slab0) {
-  constexpr int NT = C0 * 32;
-  __shared__ float s_g[2 * 1331];                                   // [cc][11][11][11], index q + 2
-  __shared__ __attribute__((aligned(16))) float s_w[2 * 125 * C0];  // [cc][k][ci]
-  const int b = blockIdx.x, cp = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < 2 * 1331; e += NT) s_g[e] = 0.f;
-  stem_copy<NT, 8>(s_w, w1b + (size_t)cp * 2 * 125 * C0, 2 * 125 * C0, tid, [](int e) { return e; });
-  __syncthreads();
-  for (int e = tid; e < 2 * 512; e += NT) {
-    const int cc = e >> 9, q = e & 511;
-    s_g[cc * 1331 + (((q >> 6) + 2) * 11 + ((q >> 3) & 7) + 2) * 11 + (q & 7) + 2] =
-        g1[((size_t)b * C1 + 2 * cp) * 512 + e];
-  }
-  __syncthreads();
-  const int iz = lane >> 4, iy = (lane >> 2) & 3, ix = lane & 3;
-  float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 1
-  for (int cc = 0; cc < 2; ++cc) {
-    const float* gp = s_g + cc * 1331 + ((2 * iz) * 11 + 2 * iy) * 11 + 2 * ix;   // q + 2 = 2 i + k
-    const float* wp = s_w + cc * 125 * C0 + 2 * wv;
-#pragma unroll 1
-    for (int kz = 0; kz < 5; ++kz)
-#pragma unroll
-      for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-          const float gv = gp[(kz * 11 + ky) * 11 + kx];
-          const float2 w = *(const float2*)(wp + ((kz * 5 + ky) * 5 + kx) * C0);
-          acc0 = fmaf(gv, w.x, acc0);
-          acc1 = fmaf(gv, w.y, acc1);
-        }
-  }
-  float* o = part + (((size_t)b * (C1 / 2) + cp) * C0 + 2 * wv) * 64 + lane;
-  o[0] = acc0;
-  o[64] = acc1;
-  if (WG0) {
-    __syncthreads();                                   // the weights are no longer read: their LDS holds h0[b] now
-    float* s_h = s_w;
-    for (int e = tid; e < C0 * 64; e += NT) s_h[e] = h0[(size_t)b * C0 * 64 + e];
-    __syncthreads();
-    // thread = (input channel, kz, ky): ten sums (two output channels x five kx) share every h0 read
-    for (int jj = tid; jj < C0 * 25; jj += NT) {
-      const int ci = jj / 25, r = jj % 25, kz = r / 5, ky = r % 5;
-      const float* gp = s_g + (kz * 11 + ky) * 11;
-      const float* hp = s_h + ci * 64;
-      float a[2][5];
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx) a[cc][kx] = 0.f;
-#pragma unroll 4
-      for (int i = 0; i < 64; ++i) {
-        const float hv = hp[i];
-        const int base = ((2 * (i >> 4)) * 11 + 2 * ((i >> 2) & 3)) * 11 + 2 * (i & 3);
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-          for (int kx = 0; kx < 5; ++kx) a[cc][kx] = fmaf(hv, gp[cc * 1331 + base + kx], a[cc][kx]);
-      }
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx)
-          slab0[((size_t)b * C0 + ci) * C1 * 125 + (2 * cp + cc) * 125 + r * 5 + kx] = a[cc][kx];
-    }
-  }
+  __shared__ __attribute__((aligned(16))) float lds[StemDhLds<C0, C1>::FLOATS];
+  stem_bwd_dh_body<C0, C1, WG0, false>(g1, w1b, part, h0, slab0, blockIdx.x, blockIdx.y, lds, StemCoop{});
 }
 
 template <int C0, int C1>
@@ -360,133 +297,9 @@ __global__ __launch_bounds__(C0 * 64) void stem_bwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma_hat, float* __restrict__ da0,
                                                            float* __restrict__ dx0, float* __restrict__ slab_gdn,
                                                            float* __restrict__ slab_w, int batch, int ch, int want_w) {
-  constexpr int NT = C0 * 64, NCOL = stem_ncol(C0), NPAIR = (C0 * 125 + NT - 1) / NT;   // (co, k) pairs per thread
-  constexpr int LS = 65;                // row stride of the [channel][64] tiles: the parameter sums below read one column k of
-                                        // every row at once -- at a stride of 64 words that was ONE bank for the whole wave
-  __shared__ float s_dh[NT], s_a[C0 * LS], s_n[NT], s_t[C0 * LS];
-  __shared__ float s_da[C0 * 343];      // da0 with a two-voxel halo: [co][7][7][7], index q + 2
-  __shared__ float s_x[MAXCH * 8];
-  __shared__ float s_w0[C0 * 125 * MAXCH];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int c = tid >> 6, v = lane, iz = v >> 4, iy = (v >> 2) & 3, ix = v & 3;
-  __shared__ float s_bet[C0], s_gam[C0 * C0];            // re-parametrised IGDN parameters (were scalar-load chains)
-  for (int e = tid; e < C0 * 343; e += NT) s_da[e] = 0.f;
-  stem_copy<NT, 16>(s_w0, w0b, C0 * 125 * ch, tid, [](int e) { return e; });
-  for (int e = tid; e < C0 * C0; e += NT) s_gam[e] = st_gamma(gamma_hat[e]);
-  if (tid < C0) s_bet[tid] = st_beta(beta_hat[tid]);
-  float own_gdn = 0.f;                  // thread p < NCOL owns IGDN partial p
-  float own_w[NPAIR][MAXCH];            // up0 weight gradient: thread owns pairs p = tid + NT r = (co, k), all ch inputs
-#pragma unroll
-  for (int r = 0; r < NPAIR; ++r)
-#pragma unroll
-    for (int ci = 0; ci < MAXCH; ++ci) own_w[r][ci] = 0.f;
-  const int jtotal = ch * C0 * 125;
-  __syncthreads();
-
-  for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-    s_a[c * LS + v] = a0[(size_t)b * NT + tid];
-    if (tid < ch * 8) s_x[tid] = x0[(size_t)b * ch * 8 + tid];
-    {
-      // dh0 = the channel-pair partials of conv0's backward-data, added in ascending order
-      float dh = 0.f;
-#pragma unroll
-      for (int w = 0; w < C1 / 2; ++w) dh += part[((size_t)b * (C1 / 2) + w) * NT + tid];
-      s_dh[tid] = dh;
-    }
-    __syncthreads();
-    {
-      const float dh = s_dh[tid];
-      // IGDN forward quantities of this voxel/channel: n_c, t_c = dh_c a_c / n_c
-      float nrm = s_bet[c];
-#pragma unroll
-      for (int j = 0; j < C0; ++j) {
-        const float xj = s_a[j * LS + v];
-        nrm = fmaf(s_gam[c * C0 + j], xj * xj, nrm);
-      }
-      nrm = sqrtf(nrm);
-      s_n[tid] = nrm;
-      s_t[c * LS + v] = dh * s_a[c * LS + v] / nrm;
-    }
-    __syncthreads();
-    {  // da0_i = dh_i n_i + a_i sum_c t_c gamma_ci  (i = this thread's channel)
-      float mix = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < C0; ++cc) mix = fmaf(s_t[cc * LS + v], s_gam[cc * C0 + c], mix);
-      const float d = s_dh[tid] * s_n[tid] + s_a[c * LS + v] * mix;
-      da0[(size_t)b * NT + tid] = d;
-      s_da[c * 343 + ((iz + 2) * 7 + iy + 2) * 7 + ix + 2] = d;
-      if (want_w && tid < NCOL) {   // parameter partials: p < C0: d beta_p ; else d gamma_{cc,j}
-        float sum = 0.f;
-        if (tid < C0) {
-          for (int k = 0; k < 64; ++k) sum += s_t[tid * LS + k];
-        } else {
-          const int cc = (tid - C0) / C0, j = (tid - C0) % C0;
-          for (int k = 0; k < 64; ++k) {
-            const float xj = s_a[j * LS + k];
-            sum = fmaf(s_t[cc * LS + k], xj * xj, sum);
-          }
-        }
-        own_gdn += 0.5f * sum;
-      }
-    }
-    __syncthreads();
-    // ---- up0 backward-data: dx0[ci, i] = sum_co sum_k da0[co, 2 i - 2 + k] w0[ci][co][k]; C0 lanes (co) per output
-    if (tid < ch * 8 * C0) {
-      const int out = tid / C0, co = tid % C0, ci = out >> 3, i = out & 7;
-      const int jz = i >> 2, jy = (i >> 1) & 1, jx = i & 1;
-      const float* dp = s_da + co * 343 + ((2 * jz) * 7 + 2 * jy) * 7 + 2 * jx;
-      const float* wp = s_w0 + co * 125 * ch + ci;
-      float acc = 0.f;
-#pragma unroll 1
-      for (int kz = 0; kz < 5; ++kz)
-#pragma unroll
-        for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 5; ++kx)
-            acc = fmaf(dp[(kz * 7 + ky) * 7 + kx], wp[((kz * 5 + ky) * 5 + kx) * ch], acc);
-#pragma unroll
-      for (int m = 1; m < C0; m <<= 1) acc += __shfl_xor(acc, m, 64);
-      if (co == 0) dx0[(size_t)b * ch * 8 + out] = acc;
-    }
-    // ---- up0 weight gradient: dW0[ci][co][k] += sum_i x0[ci, i] da0[co, 2 i - 2 + k].  A thread owns (co, k) pairs and
-    // all ch input channels: the eight da0 values of a pair are read once for the ch sums (one thread per (ci, co, k)
-    // re-read them ch times and decoded its index 16 times: 11 of the wide launch's 26 us)
-    if (want_w) {
-#pragma unroll
-      for (int r = 0; r < NPAIR; ++r) {
-        const int p = tid + NT * r;
-        if (p < C0 * 125) {
-          const int kk = p % 125, co = p / 125;
-          const int kz = kk / 25, ky = (kk / 5) % 5, kx = kk % 5;
-          const float* dp = s_da + co * 343 + (kz * 7 + ky) * 7 + kx;
-          float dv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) dv[i] = dp[((2 * (i >> 2)) * 7 + 2 * ((i >> 1) & 1)) * 7 + 2 * (i & 1)];
-#pragma unroll
-          for (int ci = 0; ci < MAXCH; ++ci)
-            if (ci < ch) {
-              float acc = own_w[r][ci];
-#pragma unroll
-              for (int i = 0; i < 8; ++i) acc = fmaf(s_x[ci * 8 + i], dv[i], acc);
-              own_w[r][ci] = acc;
-            }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (want_w) {
-    if (tid < NCOL) slab_gdn[(size_t)blockIdx.x * NCOL + tid] = own_gdn;
-#pragma unroll
-    for (int r = 0; r < NPAIR; ++r) {
-      const int p = tid + NT * r;
-      if (p < C0 * 125) {
-#pragma unroll
-        for (int ci = 0; ci < MAXCH; ++ci)
-          if (ci < ch) slab_w[(size_t)blockIdx.x * jtotal + (size_t)ci * C0 * 125 + p] = own_w[r][ci];
-      }
-    }
-  }
+  __shared__ __attribute__((aligned(16))) float lds[StemBwdLds<C0>::FLOATS];
+  stem_bwd_body<C0, C1, C0 * 64, false>(part, x0, a0, w0b, beta_hat, gamma_hat, da0, dx0, slab_gdn, slab_w, batch, ch,
+                                        want_w, blockIdx.x, gridDim.x, lds, StemCoop{});
 }
 
 // Both finals of the stem backward in one launch: the last workgroup turns the IGDN slabs into parameter gradients
@@ -508,7 +321,8 @@ __global__ __launch_bounds__(256) void stem_finals(StemGdnFinal f, const float* 
 static size_t stem_ws_floats(int batch, int ch, int c0, int c1) {
   const size_t nb = batch > 0 ? batch : 0;
   return (size_t)kStemMaxSlabs * (stem_ncol(c0) + (size_t)ch * c0 * 125) + nb * (c1 / 2) * c0 * 64 +
-         nb * c0 * c1 * 125;                            // + conv0's weight-gradient slabs (one per block)
+         nb * c0 * c1 * 125 +                           // + conv0's weight-gradient slabs (one per block)
+         nb * c0;                                       // + up0's bias-gradient slabs (nvf_stem_bwd_queue)
 }
 extern "C" size_t nvf_stem_bwd_workspace(int batch, int ch) { return stem_ws_floats(batch, ch, 8, 16) * sizeof(float); }
 extern "C" size_t nvf_stem_bwd_workspace_for(int batch, int ch, int c0, int c1) {
@@ -593,3 +407,41 @@ extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const floa
   StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, nslab, c0};
   return nvf_finals_run_stem_gdn(ctx, f, stream);
 }
+
+// The stem's backward as the FIRST workgroups of the next five-gradient launch given this context
+// (nvf_wgrad_trunk5_heads_sums_partial and its siblings with five jobs) instead of two launches of its own: stem_bwd.h.
+// Needs a queued latent tail in the same context by the time of that launch (the tail consumes dx0 inside it) and an open
+// finals queue (nvf_finals_begin: the IGDN parameter gradients are a deferred final pass, as in nvf_stem_bwd_partial).
+// Narrow decoder only (c0 = 8, c1 = 16), batch <= kStemCoopMaxBatch.  Outputs as nvf_stem_bwd_partial, plus
+// *bias_slabs = `batch` slabs of c0 channel sums of da0 (up0's bias gradient: a jtotal = c0 job of the slab reduction).
+// da0 / dx0 exist after that launch.  flags: batch + 1 uint32 words, zero before the first use; the launch leaves them zero.
+extern "C" int nvf_stem_bwd_queue(NvfStepCtx* ctx, const float* g1, const float* x0, const float* a0,
+                                  const float* conv0_w_bwd, const float* up0_w_bwd, const float* beta_hat,
+                                  const float* gamma_hat, float* da0, float* dx0, float* dbeta_hat, float* dgamma_hat,
+                                  float** dw_slabs, int* nslabs, float** bias_slabs, void* workspace,
+                                  size_t workspace_bytes, uint32_t* flags, int batch, int ch, int c0, int c1,
+                                  void* stream) {
+  if (!g1 || !x0 || !a0 || !conv0_w_bwd || !up0_w_bwd || !beta_hat || !gamma_hat || !da0 || !dx0 || !dbeta_hat ||
+      !dgamma_hat || !dw_slabs || !nslabs || !bias_slabs || !flags)
+    return NVF_EINVAL;
+  if (!nvf_ctx_ok(ctx) || !ctx->deferring || ctx->stem_pending) return NVF_EINVAL;
+  if (batch <= 0 || batch > kStemCoopMaxBatch || ch <= 0 || ch > MAXCH || c0 != 8 || c1 != 16) return NVF_EINVAL;
+  if (!workspace || workspace_bytes < stem_ws_floats(batch, ch, c0, c1) * sizeof(float)) return NVF_EWORKSPACE;
+  float* slab_gdn = (float*)workspace;
+  float* slab_w = slab_gdn + (size_t)kStemMaxSlabs * stem_ncol(c0);
+  float* part = slab_w + (size_t)kStemMaxSlabs * ch * c0 * 125;
+  float* slab0 = part + (size_t)batch * (c1 / 2) * c0 * 64;
+  float* bias = slab0 + (size_t)batch * c0 * c1 * 125;
+  StemBwdJob j{};
+  j.g1 = g1; j.w1b = conv0_w_bwd; j.x0 = x0; j.a0 = a0; j.w0b = up0_w_bwd; j.beta_hat = beta_hat; j.gamma_hat = gamma_hat;
+  j.part = part; j.da0 = da0; j.dx0 = dx0; j.slab_gdn = slab_gdn; j.slab_w = slab_w;
+  j.coop.dh_done = flags; j.coop.stem_done = flags + batch; j.coop.bias_slab = bias;
+  j.batch = batch; j.ch = ch; j.nwg = batch;
+  ctx->stem = j;
+  ctx->stem_pending = 1;
+  *dw_slabs = slab_w; *nslabs = batch; *bias_slabs = bias;
+  StemGdnFinal f{slab_gdn, beta_hat, gamma_hat, dbeta_hat, dgamma_hat, batch, c0};
+  return nvf_finals_run_stem_gdn(ctx, f, stream);
+}
+
+extern "C" int nvf_stem_bwd_pending(const NvfStepCtx* ctx) { return nvf_ctx_ok(ctx) && ctx->stem_pending ? 1 : 0; }

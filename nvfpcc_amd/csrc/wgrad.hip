@@ -796,21 +796,56 @@ struct WgMfma3 {                 // jobs 0-2: conv2, up2, conv1; job 3 (n[3] may
 using WgUp1 = TWCfg<2, 2, 8, 2>;
 constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
-template <class C0, class T1, class C2, class U0, class U1, bool TAIL>
+// floats of LDS the latent tail needs when the stem's backward rides in the same launch: + its copy of dx0
+constexpr int kTailStemLds = kTailLds + kStemCoopMaxBatch * kStemMaxCh * 8;
+
+template <class C0, class T1, class C2, class U0, class U1, bool TAIL, bool STEM>
 __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u, LatentTail tail, HeadsW3 hw,
                                                           MultiSumDesc sums, float* __restrict__ sum_part,
-                                                          const float* __restrict__ coef_src, float* coef_live) {
+                                                          const float* __restrict__ coef_src, float* coef_live,
+                                                          StemBwdJob sj) {
   static_assert(U0::NT == 256 && U1::NT == 256, "one workgroup size");
+  static_assert(TAIL || !STEM, "the stem's backward feeds the latent tail of the same launch");
   __shared__ __attribute__((aligned(16))) float lds[wg_max3(wg_max3(C0::LDSF, T1::LDSF, C2::LDSF), kWgEpiFloats,
-                                                            wg_max3(wg_max3(kTailLds, U0::LDSF, U1::LDSF),
+                                                            wg_max3(wg_max3(kTailStemLds, U0::LDSF, U1::LDSF),
                                                                     wg_max3(HeadW0::SMEM, HeadW1::SMEM, HeadW2::SMEM),
-                                                                    WgUp1::LDSF))];
+                                                                    wg_max3(WgUp1::LDSF, StemBwdLds<8>::FLOATS,
+                                                                            StemDhLds<8, 16>::FLOATS)))];
 #ifndef NVF_WG_SKIP
 #define NVF_WG_SKIP 0                  // tuning builds: bit j set = job j does nothing (results are then meaningless)
 #endif
   int bid = blockIdx.x;
+  if (STEM) {
+    // the stem's backward (stem_bwd.h): conv0's backward-data partials over (block, channel pair) workgroups, then one
+    // workgroup per block for IGDN / up0 -- producers first (lowest ids), each stage signals the next through arrival
+    // counters; they need only g1 and feed only the tail below, and are hidden behind the gradients like it
+    const int ndh = sj.batch * 8;
+    if (bid < ndh) {
+      stem_bwd_dh_body<8, 16, false, true>(sj.g1, sj.w1b, sj.part, nullptr, nullptr, bid >> 3, bid & 7, lds, sj.coop);
+      return;
+    }
+    bid -= ndh;
+    if (bid < sj.nwg) {
+      stem_bwd_body<8, 16, 256, true>(sj.part, sj.x0, sj.a0, sj.w0b, sj.beta_hat, sj.gamma_hat, sj.da0, sj.dx0,
+                                      sj.slab_gdn, sj.slab_w, sj.batch, sj.ch, 1, bid, sj.nwg, lds, sj.coop);
+      return;
+    }
+    bid -= sj.nwg;
+  }
   if (TAIL) {                          // the latent tail: one workgroup, dispatched first, hidden behind the gradients
-    if (bid == 0) { if (!(NVF_WG_SKIP & 32)) latent_tail_body(tail, lds); return; }
+    if (bid == 0) {
+      if (NVF_WG_SKIP & 32) return;
+      if (STEM) {                      // dx0 comes out of this launch: wait for the per-block workgroups, fetch it with
+        nvf_coop_wait(sj.coop.stem_done, (unsigned)sj.nwg);      // device-scope loads into LDS and run the tail on that copy
+        float* s_dx = lds + kTailLds;
+        for (int e = threadIdx.x; e < sj.batch * sj.ch * 8; e += 256) s_dx[e] = nvf_load_dev(sj.dx0 + e);
+        __syncthreads();
+        latent_tail_body(tail, lds, s_dx);
+      } else {
+        latent_tail_body(tail, lds, tail.dx_addend);
+      }
+      return;
+    }
     --bid;
   }
   if (bid < m.n[0]) {                  // conv2: the Winograd (y, x) form when the job says so (tiles_z = its z split)
@@ -913,32 +948,29 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     d.batch = batch; d.bc = 8; d.items = items[j];
     // slabs (= workgroups) per job: two workgroups share a CU, so conv2 (the longest) gets one per CU and the other
     // two half of that -- fewer slabs to add up afterwards, same launch time
-    static int caps[3] = {0, 0, 0};
-    if (!caps[0]) {                                          // tuning hook: NVF_WG_CAPS=a,b,c (each <= 512)
-      int c[3] = {256, 128, 64};     // conv1: 64 (with up1 at 64: 86.9 us for the launch against 92-93 with 128 / 128)
-      if (const char* e = getenv("NVF_WG_CAPS")) sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
-      for (int i = 0; i < 3; ++i) caps[i] = c[i] < 1 ? 1 : (c[i] > 512 ? 512 : c[i]);
-    }
-    const int cap = caps[j];
+    // conv1: 64 (with up1 at 64: 86.9 us for the launch against 92-93 with 128 / 128); tuning builds: NVF_WG_CAP0..2
+    const int caps[3] = {nvf_tune_int("NVF_WG_CAP0", 256), nvf_tune_int("NVF_WG_CAP1", 128), nvf_tune_int("NVF_WG_CAP2", 64)};
+    const int cap = caps[j] < 1 ? 1 : (caps[j] > 512 ? 512 : caps[j]);
     int n = items[j] < cap ? items[j] : cap;
     d.items_per_wg = (items[j] + n - 1) / n;
     n = (items[j] + d.items_per_wg - 1) / d.items_per_wg;
-    // conv2 in the Winograd (y, x) form (wgrad_wino.h): NVF_WGRAD_WINO=0 keeps the direct form; =z: z steps split over z
-    // work items (default 1 = 256 workgroups at batch 16: step 0.375 ms against 0.3825 with 2 and 0.3886 for the direct form)
-    static int wino = -1;
-    if (wino < 0) { const char* e = getenv("NVF_WGRAD_WINO"); wino = e ? atoi(e) : 1; if (wino > 8) wino = 8; }
-    const bool direct = nvf_ctx_ok(ctx) && ctx->direct_forms;   // nvf_step_ctx_set_direct: the caller's choice wins
-    if (j == 0 && wino > 0 && !direct) {
-      static int wcap = 0;
-      if (!wcap) { const char* e = getenv("NVF_WGRAD_WINO_CAP"); wcap = e ? atoi(e) : 512; if (wcap < 1 || wcap > 512) wcap = 512; }
+    // conv2 in the Winograd (y, x) form (wgrad_wino.h) unless the caller's context asks for the direct forms
+    // (nvf_step_ctx_set_direct); nvf_step_ctx_set_wgrad_forms: z steps split over `conv2_zsplit` work items (default 1 =
+    // 256 workgroups at batch 16: step 0.375 ms against 0.3825 with 2 and 0.3886 for the direct form).  The choice of
+    // arithmetic is the CALLER's, carried by its context -- no environment read, no process-wide state.
+    const bool direct = nvf_ctx_ok(ctx) && ctx->direct_forms;
+    int wino = nvf_ctx_ok(ctx) && ctx->wg_conv2_zsplit > 0 ? ctx->wg_conv2_zsplit : 1;
+    if (wino > 8) wino = 8;
+    if (j == 0 && !direct) {
+      int wcap = nvf_tune_int("NVF_WGRAD_WINO_CAP", 512);
+      if (wcap < 1 || wcap > 512) wcap = 512;
       n = wino_items(d, batch, wino, wcap);
     }
-    // conv1's gradient in the same form is opt-in (NVF_WGRAD_WINO1=1): 0.3485 against 0.3517 ms per step, but with it the
-    // three-epoch trajectory golden holds 98.9 % instead of >= 99 % of the sampled parameters within 2e-5 of the
-    // reference's (entries whose gradient is rounding noise take Adam's first steps with the other sign)
-    static int wino1 = -1;
-    if (wino1 < 0) { const char* e = getenv("NVF_WGRAD_WINO1"); wino1 = e ? atoi(e) : 0; }
-    if (j == 2 && wino1 > 0 && !direct) n = wino_items(d, batch, 1, cap, WgWino1::NGRP);
+    // conv1's gradient in the same form is opt-in (nvf_step_ctx_set_wgrad_forms(ctx, z, 1)): 0.3485 against 0.3517 ms per
+    // step, but with it the three-epoch trajectory golden holds 98.9 % instead of >= 99 % of the sampled parameters within
+    // 2e-5 of the reference's (entries whose gradient is rounding noise take Adam's first steps with the other sign)
+    const bool wino1 = nvf_ctx_ok(ctx) && ctx->wg_conv1_wino;
+    if (j == 2 && wino1 && !direct) n = wino_items(d, batch, 1, cap, WgWino1::NGRP);
     if (bias_slabs && j != 1) d.bias_slab = bias_slabs[j];     // conv2 (job 0) and conv1 (job 2): p = dY
     m.d[j] = d; m.n[j] = n; nslabs[j] = n;
   }
@@ -950,8 +982,8 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     {
       WgDims d{};
       d.batch = batch; d.bc = 8; d.items = batch * (WgUp1::W / WgUp1::TZ) * (WgUp1::W / WgUp1::TY);
-      static int up1_cap = 0;
-      if (!up1_cap) { const char* e = getenv("NVF_UP1_CAP"); up1_cap = e ? atoi(e) : 64; if (up1_cap < 1) up1_cap = 64; }
+      int up1_cap = nvf_tune_int("NVF_UP1_CAP", 64);
+      if (up1_cap < 1) up1_cap = 64;
       int n = d.items < up1_cap ? d.items : up1_cap;
       d.items_per_wg = (d.items + n - 1) / n;
       n = (d.items + d.items_per_wg - 1) / d.items_per_wg;
@@ -981,11 +1013,20 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
     grid += sd.total_channels * sd.nchunk;
     csrc = sums->coef_src; clive = sums->coef_live;
   }
-  if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
+  if (nvf_ctx_ok(ctx) && ctx->stem_pending) {
+    // a queued stem backward (nvf_stem_bwd_queue) rides in front of the tail it feeds: both or neither
+    if (!ctx->tail_pending || njobs != 5 || ctx->stem.batch != batch ||
+        ctx->tail.batch * ctx->tail.c * ctx->tail.spatial != batch * ctx->stem.ch * 8)
+      return NVF_EINVAL;
+    ctx->stem_pending = ctx->tail_pending = 0;
+    const int nstem = ctx->stem.batch * 8 + ctx->stem.nwg;
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true, true><<<nstem + 1 + grid, 256, 0, nvf_stream(stream)>>>(
+        m, u, ctx->tail, hw, sd, spart, csrc, clive, ctx->stem);
+  } else if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
     ctx->tail_pending = 0;
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail, hw, sd, spart, csrc, clive);
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true, false><<<1 + grid, 256, 0, nvf_stream(stream)>>>(m, u, ctx->tail, hw, sd, spart, csrc, clive, StemBwdJob{});
   } else {
-    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{}, hw, sd, spart, csrc, clive);
+    wgrad_mfma3_kernel<C0, T1, C2, U0, U1, false, false><<<grid, 256, 0, nvf_stream(stream)>>>(m, u, LatentTail{}, hw, sd, spart, csrc, clive, StemBwdJob{});
   }
   NVF_LAUNCH_CHECK();
   return NVF_OK;
@@ -1420,7 +1461,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_and_sums(WgReduceMulti r, i
 __global__ __launch_bounds__(1024, 8) void wgrad_reduce_sums_tail(WgReduceMulti r, int r_blocks, MultiSumDesc m,
                                                                float* __restrict__ part, LatentTail t) {
   __shared__ float sm[kTailLds > 16 * 64 ? kTailLds : 16 * 64];
-  if (blockIdx.x == 0) { latent_tail_body(t, sm); return; }
+  if (blockIdx.x == 0) { latent_tail_body(t, sm, t.dx_addend); return; }
   const int bid = blockIdx.x - 1;
   if (bid < r_blocks) { wgrad_reduce_multi_body(r, bid, (float(*)[64])sm); return; }
   const int q = bid - r_blocks;
@@ -1556,7 +1597,7 @@ extern "C" int nvf_latent_tail_queue(NvfStepCtx* ctx, const float* lat, const in
 
 extern "C" int nvf_latent_tail_pending(const NvfStepCtx* ctx) { return nvf_ctx_ok(ctx) && ctx->tail_pending ? 1 : 0; }
 extern "C" void nvf_latent_tail_cancel(NvfStepCtx* ctx) {
-  if (nvf_ctx_ok(ctx)) ctx->tail_pending = 0;
+  if (nvf_ctx_ok(ctx)) ctx->tail_pending = ctx->stem_pending = 0;      // (and a stem backward queued beside it)
 }
 
 __global__ void multi_channel_sum_final(MultiSumDesc d, const float* __restrict__ part) {

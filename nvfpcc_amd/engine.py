@@ -44,6 +44,9 @@ _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
 _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
+# the stem's backward (conv0^T -> IGDN' -> up0^T, up0's gradients) as the first workgroups of the five-gradient launch
+# instead of two launches in front of it (csrc/stem_bwd.h): it needs g1 only and feeds the latent tail only
+_STEM_IN_TRUNK5 = os.environ.get("NVF_STEM_IN_TRUNK5", "1") != "0"
 
 
 def _NAIVE_OFF():
@@ -224,9 +227,12 @@ class TrainEngine:
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, 16, 4)), device=self.dev)
                 if self.winograd and _WINO16:
                     # the Winograd (y, x) form with the 16 output channels as MFMA rows (conv16_wino.hip), training steps
-                    # only: conv2 backward-data 257 -> 140 us, forward 170 -> 95, conv1 59 -> 33 / 27 -> 25 at batch 16
+                    # only: conv2 backward-data 257 -> 140 us, forward 170 -> 95, conv1 backward-data 59 -> 33 at batch 16.
+                    # conv1's FORWARD stays direct (27 -> 25 us would cost the engine == operator-path agreement its 2e-5:
+                    # measured 2.004e-5), so only conv2 gets a forward packing -- and a pack-job slot stays free
                     L.wp_w = torch.empty(int(lib().nvf_pack_wino16_k4_floats()), device=self.dev)
-                    L.wp_wf = torch.empty(int(lib().nvf_pack_wino16_k4_floats()), device=self.dev)
+                    if name == "conv2":
+                        L.wp_wf = torch.empty(int(lib().nvf_pack_wino16_k4_floats()), device=self.dev)
             if _G16 and self.wide and L.k == 5 and L.cout == 16 and L.cin in (16, 32) and L.pad == 0 and name in ("up1", "up2"):
                 L.wp_gb = torch.empty(int(lib().nvf_pack_g16_mfma_floats(16, L.cin, 5)), device=self.dev)
             if _G16 and self.wide and L.k == 5 and (name, L.cin, L.cout, L.pad) in (("up1", 32, 16, 0), ("up2", 16, 16, 0),
@@ -636,7 +642,16 @@ class TrainEngine:
         gview = (lambda n: self._g(n)) if want_w else (lambda n: None)
         gamma_view = None if not want_w else self._g("reconstructor.activation.gamma").view(ig.gamma.shape)
         self._stem_gdn_in_finals = bool(self.fused_stem and defer and want_w)
-        if self.fused_stem and defer:        # its final launch is shared with the slab reduction / the final passes
+        tail = _TAIL and defer and not want_emb and a["e"].shape[1] <= 8 and _NAIVE_OFF()
+        stem_coop = (_STEM_IN_TRUNK5 and tail and wg3 and self.fused_stem and want_w and a["e"].shape[0] <= 32
+                     and heads_job is not None)
+        if stem_coop:
+            # no launch here: queued in the context, it runs inside add_trunk5's launch below (with the latent tail that
+            # consumes dx0); up0's bias gradient comes from per-block channel sums the stage leaves, not from da0
+            da0, dx0 = ops.stem_bwd_queue(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta, ig.gamma,
+                                          gview("reconstructor.activation.beta"), gamma_view, Ls["up0"].gk,
+                                          Ls["up0"].gb, self._wg, self.ctx)
+        elif self.fused_stem and defer:        # its final launch is shared with the slab reduction / the final passes
             da0, dx0 = ops.stem_bwd_partial(g1, a["x0"], a["a0"], Ls["conv0"].w_bwd, Ls["up0"].w_bwd, ig.beta,
                                             ig.gamma, gview("reconstructor.activation.beta"), gamma_view,
                                             Ls["up0"].gk, self._wg, ctx=ctx, h0=a["h0"] if stem_wg0 else None,
@@ -659,7 +674,6 @@ class TrainEngine:
         sd = self._step_dev
         g_lat = self.lmbda * self.w1 / n_pts if self._g_lat_dev is None else 1.0
         g2m = net.latent_gen.gdn_2
-        tail = _TAIL and defer and not want_emb and a["e"].shape[1] <= 8 and _NAIVE_OFF()
         if tail:
             # three dependent launches on [B, ch, 2^3] tensors -> one workgroup of the next weight-gradient launch
             # (or of the slab reduction); dlat / dh / dx0 stay referenced until that launch has been enqueued
@@ -974,7 +988,8 @@ class GraphedTrainStep:
     Data parallelism: ``collective`` = "graph" captures the all-reduce of the gradient buffer as a node of the graph
     (the hand-over between the compute stream and RCCL's stream is then a graph edge instead of two event waits per
     step); "host" ends the graph after the backward pass and launches the all-reduce hook and the optimiser node from
-    the host.  dist.attach picks "graph" for RCCL and falls back to "host" in-process if the capture fails."""
+    the host.  The default is "host" (dist.attach leaves it there; NVF_GRAPH_COLLECTIVE=graph or collective="graph" opts in,
+    falling back to "host" in-process if the capture fails)."""
 
     CAP = 4096       # rows of the device-resident schedule (longer schedules are loaded in pieces)
     # steps per replay of the unrolled graphs, largest first (a run of n loaded steps is replayed greedily: 57 = 3 x 16 + 8
@@ -1002,6 +1017,7 @@ class GraphedTrainStep:
         self.pins = [torch.zeros(self.sched.numel(), dtype=torch.int64).pin_memory() for _ in range(max(int(ring), 1))]
         self.pin_np = [p.numpy() for p in self.pins]                    # the same memory, for the NumPy row fill
         self.pin_events = [None] * len(self.pins)
+        self.pin_gen = [0] * len(self.pins)          # generation of each slot's contents (stale handles are refused)
         self.loads = 0
         self.pending = []            # (n_pts) of the loaded steps not replayed yet
         self.idx = self.buf[:batch]
@@ -1090,8 +1106,14 @@ class GraphedTrainStep:
         eng, B, nw = self.eng, self.batch, self.nw
         # the arrays form is recognised by its first member being a 2-D ndarray (a tuple of two (ids, n_pts) pairs is a
         # two-step list, not the arrays form)
-        arrays = (len(steps) == 2 and isinstance(steps[0], np.ndarray) and steps[0].ndim == 2
-                  and isinstance(steps[1], np.ndarray))
+        def is2d(x):          # ndarray / tensor [n, B], or a sequence of 1-D rows ((ids, n_pts) has a scalar / None second member)
+            if isinstance(x, np.ndarray) or torch.is_tensor(x):
+                return x.ndim == 2
+            return (isinstance(x, (list, tuple)) and len(x) > 0 and
+                    all(isinstance(r, (list, tuple, np.ndarray)) and np.ndim(r) == 1 for r in x))
+        arrays = len(steps) == 2 and is2d(steps[0])
+        if arrays and torch.is_tensor(steps[0]):
+            steps = (steps[0].cpu().numpy(), steps[1].cpu().numpy() if torch.is_tensor(steps[1]) else steps[1])
         if arrays:
             ids_all, npts = np.asarray(steps[0], np.int64), np.asarray(steps[1], np.float64)
         else:
@@ -1120,8 +1142,9 @@ class GraphedTrainStep:
         rows[n] = rows[n - 1]                     # what the last step's tail copies (never used)
         host[:nw] = rows[0]                       # the step buffer starts as row 0 ...
         host[nw], host[nw + 1] = 1, 0             # ... and the cursor at 1: the tail of the first step fetches row 1
-        return {"_staged": True, "slot": slot, "n": n, "npts": npts.tolist(), "words": nw + 2 + (n + 1) * nw,
-                "state": (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1)}
+        self.pin_gen[slot] += 1                   # a handle owns its slot only until the slot is staged again
+        return {"_staged": True, "slot": slot, "gen": self.pin_gen[slot], "n": n, "npts": npts.tolist(),
+                "words": nw + 2 + (n + 1) * nw, "state": (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1)}
 
     def load_schedule(self, steps):
         """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
@@ -1135,6 +1158,9 @@ class GraphedTrainStep:
         if h["state"] != (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1):
             raise ValueError("load_schedule: the staged schedule was made for other step counters / coefficients")
         slot, m = h["slot"], h["words"]
+        if h.get("gen") != self.pin_gen[slot]:
+            raise ValueError("load_schedule: stale handle -- its staging slot has been filled again since (ring=%d)"
+                             % len(self.pins))
         self.pending.extend(h["npts"])
         self.sched[:m].copy_(self.pins[slot][:m], non_blocking=True)
         ev = self.pin_events[slot]

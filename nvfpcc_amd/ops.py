@@ -69,6 +69,12 @@ class StepCtx:
         """Launches given this context keep the direct summation order (nvf_step_ctx_set_direct)."""
         check(lib().nvf_step_ctx_set_direct(self.ptr, int(bool(on))), "nvf_step_ctx_set_direct")
 
+    def set_wgrad_forms(self, conv2_zsplit=1, conv1_wino=False):
+        """Forms of the merged weight-gradient launches given this context (nvf_step_ctx_set_wgrad_forms): z work items of
+        conv2's Winograd gradient, and whether conv1's gradient takes the Winograd form too (another summation order)."""
+        check(lib().nvf_step_ctx_set_wgrad_forms(self.ptr, int(conv2_zsplit), int(bool(conv1_wino))),
+              "nvf_step_ctx_set_wgrad_forms")
+
     def begin(self):
         """Queue the final passes of focal_loss_multi / heads3_loss_bwd_data / WgradBatch.finish_with_sums /
         weight_rate_batch / metrics issued with this context (their outputs exist only after flush())."""
@@ -94,6 +100,9 @@ class StepCtx:
 
     def tail_pending(self):
         return bool(lib().nvf_latent_tail_pending(self.ptr))
+
+    def stem_pending(self):
+        return bool(lib().nvf_stem_bwd_pending(self.ptr))
 
 
 def _ctx(ctx):
@@ -545,6 +554,33 @@ def stem_bwd_partial(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, db
     wg.jobs.append((slabs.value, dw_up0.data_ptr(), nsl.value, dw_up0.numel()))
     if h0 is not None:
         wg.jobs.append((slabs0.value, dw_conv0.data_ptr(), B, dw_conv0.numel()))
+    return da0, dx0
+
+
+def stem_bwd_queue(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, db_up0, wg, ctx):
+    """stem_bwd_partial with NO launch of its own (nvf_stem_bwd_queue): the work is queued in ``ctx`` and runs as the first
+    workgroups of the next WgradBatch.add_trunk5 launch of ``wg`` (which must carry the queued latent tail that consumes
+    dx0).  up0's weight gradient and -- from per-block channel sums the stage leaves -- its bias gradient ``db_up0`` become
+    reduction jobs of ``wg``.  Returns (da0, dx0): they exist after that launch."""
+    import ctypes
+    _f32(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbeta_out, dgamma_out, dw_up0, db_up0)
+    B, ch = x0.shape[0], x0.shape[1]
+    da0 = torch.empty_like(a0)
+    dx0 = torch.empty_like(x0)
+    c0, c1 = a0.shape[1], g1.shape[1]
+    ws = workspace(lib().nvf_stem_bwd_workspace_for(B, ch, c0, c1), x0.device, "stem", ctx)
+    flags = ctx._ws.get("stem_flags")
+    if flags is None or flags.numel() < B + 1:
+        if flags is not None:
+            ctx._retired.append(flags)
+        flags = ctx._ws["stem_flags"] = torch.zeros(64, dtype=torch.int32, device=x0.device)
+    slabs, nsl, bias = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_void_p()
+    check(lib().nvf_stem_bwd_queue(ctx.ptr, _ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd),
+                                   _ptr(beta_hat), _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out),
+                                   _ptr(dgamma_out), ctypes.byref(slabs), ctypes.byref(nsl), ctypes.byref(bias), _ptr(ws),
+                                   ws.numel(), _ptr(flags), B, ch, c0, c1, _stream()), "nvf_stem_bwd_queue")
+    wg.jobs.append((slabs.value, dw_up0.data_ptr(), nsl.value, dw_up0.numel()))
+    wg.jobs.append((bias.value, db_up0.data_ptr(), B, c0))
     return da0, dx0
 
 

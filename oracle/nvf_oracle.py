@@ -219,11 +219,16 @@ def entropy_coder(P, latent, mode, u=None):
     return rounded, bits
 
 
-def decoder(P, x, q, u_w=None, keep=None):
+def decoder(P, x, q, u_w=None, keep=None, relu_masks=None):
     """CompDecoder.forward, live definition (network.py:4758-4779).
 
     ``u_w``: optional dict layer-name -> uniform sample for the q=1 weight noise.
     ``keep``: optional dict that receives every intermediate activation.
+    ``relu_masks`` (checker only; None = the reference's F.relu): dict layer-name -> bool tensor; that layer's ReLU becomes
+    ``pre_activation * mask`` -- the subgradient choice of ANOTHER fp32 evaluation imposed on this one.  ReLU is
+    discontinuous in its derivative at 0: a pre-activation that two correctly rounded evaluations place on either side of
+    zero (|x| ~ 1e-7 of the layer's range) switches a whole gradient entry on or off, which no tolerance on rounding
+    covers.  With the masks imposed, what is compared is arithmetic; the masks themselves are compared separately.
     """
     r = "reconstructor."
     u_w = u_w or {}
@@ -241,21 +246,28 @@ def decoder(P, x, q, u_w=None, keep=None):
             keep[n] = t
         return t
 
+    def relu(n, t):
+        if keep is not None:
+            keep[n + ".pre"] = t
+        if relu_masks is not None and n in relu_masks:
+            return t * relu_masks[n].to(t.dtype)
+        return F.relu(t)
+
     w, b = eff("up0")
     t = note("up0", F.conv_transpose3d(x, w, b, 2, 2, 1))
     t = note("igdn", gdn3d(t, P[r + "activation.beta"], P[r + "activation.gamma"], inverse=True))
     w, b = eff("conv0")
-    t = note("conv0", F.relu(F.conv_transpose3d(t, w, b, 2, 2, 1)))
+    t = note("conv0", relu("conv0", F.conv_transpose3d(t, w, b, 2, 2, 1)))
     cls0 = note("cls0", head("conv0_cls", t))
     w, b = eff("up1")
-    t = note("up1", F.relu(F.conv_transpose3d(t, w, b, 2, 0, 0)))
+    t = note("up1", relu("up1", F.conv_transpose3d(t, w, b, 2, 0, 0)))
     w, b = eff("conv1")
-    t = note("conv1", F.relu(F.conv3d(t, w, b, 1, 0)))
+    t = note("conv1", relu("conv1", F.conv3d(t, w, b, 1, 0)))
     cls1 = note("cls1", head("conv1_cls", t))
     w, b = eff("up2")
-    t = note("up2", F.relu(F.conv_transpose3d(t, w, b, 2, 0, 0)))
+    t = note("up2", relu("up2", F.conv_transpose3d(t, w, b, 2, 0, 0)))
     w, b = eff("conv2")
-    t = note("conv2", F.relu(F.conv3d(t, w, b, 1, 0)))
+    t = note("conv2", relu("conv2", F.conv3d(t, w, b, 1, 0)))
     w, b = eff("conv2_cls")
     out = note("out", torch.sigmoid(F.conv3d(t, w, b, 1, 1)))
     return out, [cls0, cls1, out], weight_bits(P)
@@ -271,13 +283,13 @@ def weight_bits(P):
         for n in TRUNK])
 
 
-def net_forward(P, emb, mode, q, u_latent=None, u_w=None, keep=None):
-    """Net.forward (NVFPCC.py:41-45)."""
+def net_forward(P, emb, mode, q, u_latent=None, u_w=None, keep=None, relu_masks=None):
+    """Net.forward (NVFPCC.py:41-45).  ``relu_masks``: see decoder (checker only)."""
     lat = latent_gen(P, emb)
     rounded, lbits = entropy_coder(P, lat, mode, u_latent)
     if keep is not None:
         keep["latent"], keep["latent_rounded"] = lat, rounded
-    out, cls, nbits = decoder(P, rounded, q, u_w, keep)
+    out, cls, nbits = decoder(P, rounded, q, u_w, keep, relu_masks)
     return out, cls, nbits, lbits
 
 

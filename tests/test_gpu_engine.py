@@ -426,6 +426,15 @@ def test_step_tail_is_torch_adam_and_keeps_the_epoch_sums(gpu):
         ops.step_tail(p_c, g, m_c, v_c, None, ops.adam_coefficients(2e-3, 6 + k), done=done,
                       sched=(buf, rows, cursor, 8))
         assert buf.tolist() == list(range(8 * (2 + k), 8 * (3 + k))) and cursor.item() == 3 + k
+    # rows wider than one wave (per-rank batches of 62 and more: nw = batch + 3) and wider than the workgroup: the cursor is
+    # read once and broadcast, so no wave can copy part of the next row; checked row by row over many hand-overs
+    for nw in (67, 131, 300):
+        rows = torch.arange(nw * 40, dtype=torch.int64, device=gpu)
+        buf, cursor = torch.zeros(nw, dtype=torch.int64, device=gpu), torch.tensor([1], dtype=torch.int64, device=gpu)
+        for k in range(30):
+            ops.step_tail(p_c, g, m_c, v_c, None, ops.adam_coefficients(2e-3, 8 + k), done=done,
+                          sched=(buf, rows, cursor, nw))
+            assert torch.equal(buf, rows[nw * (1 + k):nw * (2 + k)]) and cursor.item() == 2 + k
 
 
 def test_epoch_driver_graph_and_host_paths_agree_and_nan_guard_raises(gpu):
@@ -721,3 +730,81 @@ def test_schedule_rows_are_the_same_from_a_list_and_from_arrays(gpu):
     f = rows.view(torch.float32)
     np.testing.assert_allclose(f[:3, 2 * 5].numpy(), eng.lmbda * eng.w1 / npts, rtol=1e-7)
     np.testing.assert_allclose(f[:3, 2 * 5 + 1].numpy(), 1.0 / npts, rtol=1e-7)
+    # array-likes are the arrays form too (tensors, nested lists); a two-step LIST of (ids, n_pts) pairs is not
+    for form in ((torch.from_numpy(ids), torch.from_numpy(npts)), (ids.tolist(), npts.tolist())):
+        g.load_schedule(form)
+        torch.cuda.synchronize()
+        g.pending.clear()
+        assert torch.equal(g.sched[:g.nw + 2 + 4 * g.nw].cpu(), b)
+    g.load_schedule([(ids[0].tolist(), None), (ids[1].tolist(), None)])
+    assert len(g.pending) == 2
+    g.pending.clear()
+    # a handle owns its staging slot only until the ring comes round to it again (ring = 2): stale handles are refused
+    h0 = g.stage_schedule((ids, npts))
+    g.stage_schedule((ids, npts))
+    g.stage_schedule((ids[:2], npts[:2]))           # takes h0's slot
+    with pytest.raises(ValueError, match="stale"):
+        g.load_schedule(h0)
+    assert not g.pending
+
+
+@pytest.mark.parametrize("collective", ["none", "host"])
+def test_graph_replay_hands_over_wide_schedule_rows(gpu, collective):
+    """Per-rank batch 64: a schedule row (batch + 3 words) spans more than one wave of the kernel that copies it over the
+    step buffer at the end of every step.  After each replay the step buffer must be EXACTLY the next row -- the fused tail
+    (single GPU) and nvf_step_tail (host-launched behind a data-parallel all-reduce hook) both (a wave that
+    re-read an already advanced cursor would mix two rows)."""
+    from nvfpcc_amd.engine import GraphedTrainStep
+    net, eng, gt, dist, emb = make("S", gpu, nblk=70)
+    if collective == "host":
+        eng.grad_hook = lambda flat: None          # an all-reduce over one rank
+        eng.collective_mode = "host"
+    g = GraphedTrainStep(eng, 64, 1, unroll=1)
+    assert g.nw == 67 and g.collective == collective
+    rng = np.random.default_rng(11)
+    ids = np.stack([rng.permutation(70)[:64] for _ in range(5)]).astype(np.int64)
+    g.load_schedule((ids, eng.counts[ids].sum(axis=1)))
+    torch.cuda.synchronize()
+    rows = g.rows[:6 * g.nw].view(6, g.nw).cpu().clone()
+    assert torch.equal(g.buf.cpu(), rows[0])
+    for k in range(5):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g.buf.cpu(), rows[k + 1]), k
+        assert int(g.cursor.item()) == k + 2
+    assert torch.isfinite(eng.flat_p).all()
+
+
+@pytest.mark.parametrize("batch", [16, 5, 32])
+def test_stem_backward_inside_the_five_gradient_launch(gpu, monkeypatch, batch):
+    """Round 5: the stem's backward (conv0^T -> IGDN' -> up0^T and up0's gradients) has no launch of its own -- queued in the
+    step context (nvf_stem_bwd_queue), it runs as the first workgroups of the five-gradient launch and hands dx0 to the
+    latent tail of the same launch through device-scope stores and arrival counters (csrc/stem_bwd.h).  Same arithmetic in
+    the same order: against the two-launch form every gradient is the same BITS, except up0's bias gradient, which is now a
+    per-block wave sum added over the blocks (another summation order: to rounding).  Repeated steps must leave the arrival
+    counters at zero."""
+    from nvfpcc_amd import engine as E
+    got = {}
+    for coop in (True, False):
+        monkeypatch.setattr(E, "_STEM_IN_TRUNK5", coop)
+        net, eng, gt, dist, emb = make("S", gpu, nblk=40)
+        ids = np.random.default_rng(2).permutation(40)[:batch]
+        for rep in range(3):
+            eng.noise_step = 0
+            eng.train_step(ids, 1, update=False)
+            assert not eng.ctx.stem_pending() and not eng.ctx.tail_pending()
+        torch.cuda.synchronize()
+        flags = eng.ctx._ws.get("stem_flags")
+        assert (flags is not None) == coop
+        if coop:
+            assert int(flags.abs().sum().item()) == 0
+        got[coop] = (eng.flat_g.clone(), eng.loss_value())
+    (g1, l1), (g0, l0) = got[True], got[False]
+    assert l1 == l0
+    off, n = eng.slices["reconstructor.up0.b"]
+    for name, (o, m) in eng.slices.items():
+        if name == "reconstructor.up0.b":
+            ref = g0[o:o + m]
+            assert float((g1[o:o + m] - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), name
+        else:
+            assert torch.equal(g1[o:o + m], g0[o:o + m]), name

@@ -10,7 +10,6 @@ from nvfpcc_amd.seeds import synthetic_seed
 from nvfpcc_amd.synth import make_blocks
 from tests.golden_inputs import perturb_state_, make_emb
 from tests.philox_np import latent_noise, weight_noise
-from tests.test_gpu_net import grad_close
 
 pytestmark = pytest.mark.gpu
 H = dict(lmbda=200.0, w1=10.0, w2=57.0, lr=1e-3, wemb=5.0)
@@ -86,7 +85,7 @@ def test_unrolled_schedule_replay_equals_host_steps(gpu):
     assert float(eng.epoch_acc[7]) == K
 
 
-def _oracle_step(P, emb, gt, dist, ids, q, n_pts, noise_step, seed=0, layer_ids=None):
+def _oracle_step(P, emb, gt, dist, ids, q, n_pts, noise_step, seed=0, layer_ids=None, relu_masks=None, keep=None):
     """The oracle's objective and gradients for the mini-batch `ids` with the engine's own noise draws."""
     from oracle import nvf_oracle as O
     P = {k: v.clone() for k, v in P.items()}
@@ -100,7 +99,7 @@ def _oracle_step(P, emb, gt, dist, ids, q, n_pts, noise_step, seed=0, layer_ids=
     if q == 1:
         u_w = {n: torch.from_numpy(weight_noise(seed, noise_step, layer_ids[n], tuple(P["reconstructor." + n + ".kernel"].shape)))
                for n in TRUNK}
-    out, cls, nbits, lbits = O.net_forward(P, e, "train", q, u_latent, u_w)
+    out, cls, nbits, lbits = O.net_forward(P, e, "train", q, u_latent, u_w, keep=keep, relu_masks=relu_masks)
     g = gt[ids]
     pyr = O.gt_pyramid(g)
     loss = (O.surf_focal_dense(out, g, dist[ids], beta=1, alpha=0.9) + O.focal_dense(cls[0], pyr[0], alpha=0.85)
@@ -115,11 +114,48 @@ def _layer_ids(net):
     return {n: getattr(rec, n).layer_id for n in TRUNK}
 
 
-def _check_against_oracle(eng, net, P, gt, dist, emb, ids, q, tol=2e-4, rtol=1e-2, conditioned=False):
-    """One mini-batch step of the engine (loss, probabilities, every weight-gradient slice) against the oracle.
-    ``conditioned``: the reference is the oracle in FLOAT64 and a slice may be off by max(tol, 10 x the fp32 oracle's own
-    distance from float64) of its largest entry -- for parameters behind the latent rate term, whose gradient is a ratio of
-    differences of Gaussian CDFs and as ill-conditioned as the latents' (profiles/r04_latent_grad_conditioning.md)."""
+# ReLU layers of the decoder (oracle name -> the engine's saved activation)
+RELU_LAYERS = {"conv0": "y1", "up1": "y2", "conv1": "y3", "up2": "y4", "conv2": "y5"}
+# Gradient bounds of the engine (default = Winograd forms included) against the oracle evaluated in FLOAT64 with the
+# engine's own ReLU masks imposed (oracle/nvf_oracle.py decoder(relu_masks=)): max |difference| / max |slice|.  3 x the
+# worst case measured on MI355X over both decoders of BASELINE.json at batch 16, q = 1 and 2 (tools/diag_masks.py,
+# profiles/r05_relu_mask_parity.md: 1.9e-6 over the data-term slices, 2.4e-6 on a head bias, 1.05e-5 on the weight
+# likelihood's mu -- a signed sum over 2e5 weights).  Why masks: a ReLU's derivative is discontinuous at 0; one
+# pre-activation in ten million that two correctly rounded evaluations put on either side of zero (|x| < 1e-7 of the
+# layer's range: measured, asserted below) switches a gradient entry on or off and moves slices by 1e-4 .. 8e-4 -- the
+# fp32 oracle (oneDNN) is itself 2e-4 from float64 on the wide decoder for that reason.  With the masks imposed the
+# comparison is about arithmetic, and holds 100 x tighter than SURVEY 8(c)'s 1e-4.
+GRAD_TOL = 8e-6
+GRAD_TOL_BY_SLICE = {"reconstructor.likelihood_model.mu": 3.5e-5}
+MASK_FLIP_MAX_FRACTION = 1e-5        # of a layer's entries (measured: <= 5 of 8.4e6)
+MASK_FLIP_MAX_ACTIVATION = 1e-6      # |activation| of a disagreeing entry / the layer's largest (measured: <= 1.2e-7)
+
+
+def _oracle64_with_masks(eng, net, P, gt, dist, emb, ids, q, n_pts, a, tag):
+    """(gradients, latent gradient) of the float64 oracle with the engine's ReLU masks imposed; asserts that the masks
+    themselves disagree with the float64 pre-activations only where those are zero to rounding."""
+    masks = {n: (a[k] > 0).cpu() for n, k in RELU_LAYERS.items()}
+    keep = {}
+    out = _oracle_step({k: v.double() for k, v in P.items()}, emb.double(), gt.double(), dist.double(), ids, q, n_pts,
+                       eng.noise_step, layer_ids=_layer_ids(net), relu_masks=masks, keep=keep)
+    nflip, worst = 0, 0.0
+    for n, k in RELU_LAYERS.items():
+        pre = keep[n + ".pre"].detach()
+        flip = (pre > 0) != masks[n]
+        big = float(pre.abs().max())
+        if flip.any():
+            nflip += int(flip.sum())
+            w = float(torch.maximum(pre.abs(), a[k].cpu().double().abs())[flip].max()) / big
+            worst = max(worst, w)
+            assert int(flip.sum()) <= max(1, MASK_FLIP_MAX_FRACTION * flip.numel()), (tag, n, int(flip.sum()))
+            assert w <= MASK_FLIP_MAX_ACTIVATION, (tag, n, w)
+    print(f"[relu masks {tag}] {nflip} entries differ from the float64 oracle's; largest |activation| among them / layer max = {worst:.1e}")
+    return out[3], out[4]
+
+
+def _check_against_oracle(eng, net, P, gt, dist, emb, ids, q, tag=None):
+    """One mini-batch step of the engine against the oracle: probabilities and loss against the oracle as the reference
+    runs it (float32), every weight-gradient slice against the oracle in float64 with the engine's ReLU masks imposed."""
     ids = np.asarray(ids, np.int64)
     n_pts = float(eng.counts[ids].sum())
     lids = _layer_ids(net)
@@ -128,37 +164,48 @@ def _check_against_oracle(eng, net, P, gt, dist, emb, ids, q, tol=2e-4, rtol=1e-
     assert float((a["p2"].cpu() - out_ref).abs().max()) < 1e-5
     assert float((a["p0"].cpu() - cls_ref[0]).abs().max()) < 1e-5 and float((a["p1"].cpu() - cls_ref[1]).abs().max()) < 1e-5
     assert abs(eng.loss_value() - loss_ref) < 2e-5 * abs(loss_ref), (eng.loss_value(), loss_ref)
-    if conditioned:
-        g64 = _oracle_step({k: v.double() for k, v in P.items()}, emb.double(), gt.double(), dist.double(), ids, q, n_pts,
-                           eng.noise_step, layer_ids=lids)[3]
+    g64, _ = _oracle64_with_masks(eng, net, P, gt, dist, emb, ids, q, n_pts, a, tag)
+    worst = (0.0, None)
     for name, (off, n) in eng.slices.items():
-        mine = eng.flat_g[off:off + n].cpu().numpy()
-        if not conditioned:
-            grad_close(mine, g_ref[name].numpy(), tol=tol, rtol=rtol)
-            continue
-        r64 = g64[name].numpy().reshape(-1)
-        scale = max(np.abs(r64).max(), 1e-9)
-        cond = np.abs(g_ref[name].double().numpy().reshape(-1) - r64).max() / scale
-        err = np.abs(mine.astype(np.float64).reshape(-1) - r64).max() / scale
-        assert err < max(tol, 10 * cond), (name, err, cond)
+        mine = eng.flat_g[off:off + n].cpu().numpy().astype(np.float64)
+        r = g64[name].numpy().reshape(-1)
+        err = np.abs(mine - r).max() / max(np.abs(r).max(), 1e-30)
+        if name not in GRAD_TOL_BY_SLICE:
+            worst = max(worst, (err, name))
+        assert err < GRAD_TOL_BY_SLICE.get(name, GRAD_TOL), (tag, name, err)
+    print(f"[grad vs float64 oracle, masks imposed: {tag} q={q}] worst slice {worst[1]}: {worst[0]:.2e} (bound {GRAD_TOL:.0e})")
     return loss_ref
 
 
+def _check_latent_gradient(eng, net, P, gt, dist, emb, q, tag):
+    """The full-batch latent pass (n_pts = all resident blocks, NVFPCC.py:233-250) against the float64 oracle with the
+    pass's own ReLU masks imposed."""
+    a, de = eng.latent_step(q, update=False)
+    ids = np.arange(eng.N_leaf)
+    _, de64 = _oracle64_with_masks(eng, net, P, gt, dist, emb, ids, q, float(eng.counts.sum()), a, tag + "/latent")
+    err = float((de.cpu().double() - de64).abs().max()) / float(de64.abs().max())
+    print(f"[latent gradient vs float64 oracle, masks imposed: {tag} q={q}] {err:.2e} (bound {GRAD_TOL:.0e})")
+    assert err < GRAD_TOL, (tag, err)
+
+
 @pytest.mark.parametrize("q", [2, 1])
-def test_batch16_train_step_matches_the_oracle(q, gpu):
+@pytest.mark.parametrize("dec", ["S", "W"])
+def test_batch16_train_step_matches_the_oracle(dec, q, gpu):
     """The bench configuration's batch (16 blocks of 917 resident): loss, probabilities, all 28 gradient slices against the
     CPU oracle on the same 16 blocks -- slab counts, workgroup caps and the eight-wave kernel variants depend on the
     batch, and the golden vectors stop at batch 4.  q = 1 feeds the oracle the engine's counter-RNG draws (Philox
-    restated in NumPy, tests/philox_np.py).  The latent gradient comes from a 16-block latent pass."""
-    net, eng, P, gt, dist, emb = make(gpu, 3, (8, 16, 8, 8), 40)
+    restated in NumPy, tests/philox_np.py).  The latent gradient comes from a 16-block latent pass.  Both decoders of
+    BASELINE.json (S: ch 3, 8,16,8,8; W: ch 8, 16,32,16,16 = configs[4]) through the DEFAULT engine -- the Winograd forms of
+    the 4^3 layers included -- so the wide decoder's batch-16 launches are held to the oracle too, not only to its own
+    direct forms."""
+    ch, chans = (3, (8, 16, 8, 8)) if dec == "S" else (8, (16, 32, 16, 16))
+    net, eng, P, gt, dist, emb = make(gpu, ch, chans, 40)
+    assert eng.winograd and (eng.narrow if dec == "S" else eng.wide)
     ids = np.random.default_rng(3).permutation(40)[:16]
-    _check_against_oracle(eng, net, P, gt, dist, emb, ids, q)
-    # latent gradient: the full-batch latent pass over 16 resident blocks (n_pts = all of them, NVFPCC.py:233-250)
-    net2, eng2, P2, gt2, dist2, emb2 = make(gpu, 3, (8, 16, 8, 8), 16)
-    a, de = eng2.latent_step(q, update=False)
-    n_all = float(eng2.counts.sum())
-    _, _, _, _, de_ref = _oracle_step(P2, emb2, gt2, dist2, np.arange(16), q, n_all, eng2.noise_step, layer_ids=_layer_ids(net2))
-    grad_close(de.cpu().numpy(), de_ref.numpy())
+    _check_against_oracle(eng, net, P, gt, dist, emb, ids, q, tag="B16/" + dec)
+    # latent gradient: the full-batch latent pass over 16 resident blocks
+    net2, eng2, P2, gt2, dist2, emb2 = make(gpu, ch, chans, 16)
+    _check_latent_gradient(eng2, net2, P2, gt2, dist2, emb2, q, "B16/" + dec)
 
 
 # the decoders the engine has fused / matrix-core launches for; anything else must either run (generic kernels) and
@@ -178,23 +225,13 @@ def test_other_channel_strings_match_the_oracle_or_refuse(ch, channels, gpu):
     except NotImplementedError as e:
         assert "8,16,8,8" in str(e) and "16,32,16,16" in str(e), str(e)
         return
+    tag = "ch%d/%s" % (ch, ",".join(str(c) for c in channels))
     for q in (2, 1):
-        _check_against_oracle(eng, net, P, gt, dist, emb, [4, 1, 3, 0], q, conditioned=True)
-    # latent gradient: against the oracle in FLOAT64.  The rate term's gradient is a ratio of differences of Gaussian CDFs
-    # (network.py:145-161); where a latent sits in a tail, one ulp of erf is a %-level change of it, and with these
-    # perturbed parameters the fp32 ORACLE itself is off by 4e-5 (ch = 8) to 2e-3 (chanstr 8,8,8,8) of the largest entry
-    # (measured: profiles/r04_latent_grad_conditioning.md).  Allowance: 2e-4 of the largest entry, or ten times the fp32
-    # oracle's own distance from float64 where that is larger
-    a, de = eng.latent_step(2, update=False)
-    args = (np.arange(6), 2, float(eng.counts.sum()), eng.noise_step)
-    de32 = _oracle_step(P, emb, gt, dist, *args, layer_ids=_layer_ids(net))[4].double()
-    de64 = _oracle_step({k: v.double() for k, v in P.items()}, emb.double(), gt.double(), dist.double(), *args,
-                        layer_ids=_layer_ids(net))[4]
-    scale = float(de64.abs().max())
-    cond = float((de32 - de64).abs().max()) / scale
-    err = float((de.cpu().double() - de64).abs().max()) / scale
-    print(f"latent gradient ch={ch} {channels}: HIP vs fp64 {err:.2e}, fp32 oracle vs fp64 {cond:.2e}")
-    assert err < max(2e-4, 10 * cond), (err, cond)
+        _check_against_oracle(eng, net, P, gt, dist, emb, [4, 1, 3, 0], q, tag=tag)
+    # latent gradient: round 4 allowed max(2e-4, 10 x the fp32 oracle's own distance from float64) here and blamed the
+    # Gaussian-CDF ratio of the rate term; tools/diag_latent2.py (profiles/r05_relu_mask_parity.md) shows every stage of the
+    # latent backward accurate to 1e-7 -- the 3.6e-4 at ch = 8 was ONE ReLU mask entry -- so the same bound as everywhere
+    _check_latent_gradient(eng, net, P, gt, dist, emb, 2, tag)
     # eval forward is batch-invariant bit for bit here as well (rc_enc.ply == rc_dec.ply)
     p_all = eng.eval_forward(q=2)["p2"]
     one = eng.eval_forward(lo=3, hi=4, q=2)["p2"]
@@ -206,8 +243,8 @@ def test_winograd_step_equals_the_direct_step(gpu, monkeypatch):
     switch off (NVF_WINO=0: conv2's forward and backward-data and conv1's backward-data through the direct fixed-order
     kernels of rounds 1-3) the same step must give the same probabilities, loss and gradients to rounding -- and the EVAL
     forward must not depend on the switch at all, bit for bit (it never uses the Winograd kernels).  (conv2's weight
-    gradient inside the five-gradient launch is switched by NVF_WGRAD_WINO, read once per process by the library: its two
-    forms are compared by tests/test_gpu_ops.py::test_wgrad_k4_wino and ::test_three_mfma_weight_gradients_in_one_launch.)"""
+    gradient inside the five-gradient launch follows the engine's context -- nvf_step_ctx_set_direct -- too; its two
+    forms are also compared by tests/test_gpu_ops.py::test_wgrad_k4_wino and ::test_three_mfma_weight_gradients_in_one_launch.)"""
     from nvfpcc_amd import engine as E
     got = {}
     for wino in (True, False):
@@ -239,7 +276,7 @@ def test_wide_winograd_step_equals_the_direct_step(gpu, monkeypatch):
     for wino in (True, False):
         monkeypatch.setattr(E, "_WINO", wino)
         net, eng, P, gt, dist, emb = make(gpu, 8, (16, 32, 16, 16), 20)
-        assert eng.wide and (eng.layers["conv2"].wp_w is not None) == wino and (eng.layers["conv1"].wp_wf is not None) == wino
+        assert eng.wide and (eng.layers["conv2"].wp_w is not None) == wino and (eng.layers["conv2"].wp_wf is not None) == wino and eng.layers["conv1"].wp_wf is None
         ids = np.arange(16)
         a = eng.train_step(ids, 1, update=False)
         ev = eng.eval_forward(lo=0, hi=5, q=2)["p2"].clone()

@@ -2,8 +2,9 @@
 generated from the real reference (tests/golden/net_*.npz).
 
 Stated tolerances: probabilities <= 1e-5 abs; occupancy identical on every voxel with
-|p - thh| > 2e-6; scalar rates/loss <= 2e-5 relative; gradients <= 2e-4 of the tensor's max
-magnitude (fp32 sums in a different, fixed order than oneDNN's).
+|p - thh| > 2e-6; scalar rates/loss <= 2e-5 relative; gradients: per decoder and golden, 3 x the
+worst case measured on MI355X (TOLS below: <= 1.1e-4 of the tensor's max magnitude; fp32 sums in a
+different, fixed order than oneDNN's).
 """
 import os
 
@@ -21,6 +22,15 @@ TRUNK_ORDER = ["up0", "conv0", "up1", "conv1", "up2", "conv2", "conv2_cls"]
 # MI355X: 1.1e-4 narrow decoder, all entries; 3.2e-3 wide decoder, 256 sampled entries per tensor)
 REL_TOL = 1e-2
 REL_SEEN = []
+# per decoder and comparison: (tensor-max-relative bound, element-wise relative bound) = 3 x the worst case measured on
+# MI355X (printed by every run as "[grad_close <tag>]"; SURVEY 8(c) asks for <= 1e-4 relative on gradients: the fp32
+# sums of up to 5e5 products run in another fixed order than oneDNN's, measured below)
+# measured (r05, GPUTEST log): S/golden_q2 (3.35e-5, 1.09e-4), W/golden_q2 (3.52e-5, 3.16e-3 on 256 sampled entries per tensor),
+# S/golden_q1 (3.35e-5, 3.35e-5), W/golden_q1 (1.26e-5, 1.82e-5).  These goldens are float32 numbers of the real reference
+# (oneDNN), ReLU-mask disagreements included; the arithmetic itself is held to 8e-6 against the float64 oracle with the
+# masks imposed in tests/test_gpu_measured_path.py
+TOLS = {"S/golden_q2": (1e-4, 3.3e-4), "W/golden_q2": (1.1e-4, 1e-2), "S/golden_q1": (1e-4, 1e-4),
+        "W/golden_q1": (4e-5, 6e-5)}
 
 
 def summary(t, n=64):
@@ -67,7 +77,10 @@ def full_loss(net, emb, gt, dist, mode, q, **kw):
     return loss, out, cls, nbits, lbits
 
 
-def grad_close(mine, ref, tol=2e-4, rtol=REL_TOL):
+SEEN = {}       # tag -> [worst err / tensor max, worst element-wise relative error]: printed by the tests (drift is visible)
+
+
+def grad_close(mine, ref, tol=2e-4, rtol=REL_TOL, tag=None):
     """Two statements: (1) every entry within `tol` of the tensor's largest magnitude; (2) element by element, every
     entry above 1e-3 of that magnitude within `rtol` of ITS OWN value -- so small-but-significant entries are checked
     too (fp32 sums of up to 5e5 products in another order than oneDNN's; measured worst case in the comment at REL_TOL)."""
@@ -75,12 +88,20 @@ def grad_close(mine, ref, tol=2e-4, rtol=REL_TOL):
     ref = np.asarray(ref, np.float64).reshape(-1)
     scale = max(np.abs(ref).max(), 1e-9)
     err = np.abs(mine - ref).max() / scale
-    assert err < tol, err
+    seen = SEEN.setdefault(tag, [0.0, 0.0])
+    seen[0] = max(seen[0], err)
+    assert err < tol, (tag, err, tol)
     big = np.abs(ref) > 1e-3 * scale
     if big.any():
         rel = (np.abs(mine - ref)[big] / np.abs(ref)[big]).max()
         REL_SEEN.append(rel)
-        assert rel < rtol, rel
+        seen[1] = max(seen[1], rel)
+        assert rel < rtol, (tag, rel, rtol)
+
+
+def report(tag):
+    e, r = SEEN.get(tag, (0.0, 0.0))
+    print(f"[grad_close {tag}] worst |err| / tensor max = {e:.2e}, worst element-wise relative (entries > 1e-3 max) = {r:.2e}")
 
 
 @pytest.mark.parametrize("tag", ["S", "W"])
@@ -123,14 +144,16 @@ def test_gradients_match_reference(tag, gpu, golden_dir):
     loss, *_ = full_loss(net, emb, gt, dist, "eval", 2)
     loss.backward()
     assert abs(loss.item() - float(G["grad_q2/loss"])) < 2e-5 * abs(float(G["grad_q2/loss"]))
-    grad_close(emb.grad.cpu().numpy(), G["grad_q2/emb"])
+    t = tag + "/golden_q2"
+    grad_close(emb.grad.cpu().numpy(), G["grad_q2/emb"], *TOLS[t], tag=t)
     for k, p in net.named_parameters():
         ref = G["grad_q2/" + k]
         assert p.grad is not None, k
         if tag == "S":
-            grad_close(p.grad.cpu().numpy(), ref)
+            grad_close(p.grad.cpu().numpy(), ref, *TOLS[t], tag=t)
         else:
-            grad_close(summary(p.grad, 256)[2:], ref[2:])
+            grad_close(summary(p.grad, 256)[2:], ref[2:], *TOLS[t], tag=t)
+    report(t)
     print(f"[{tag}] worst element-wise relative gradient error (entries > 1e-3 max): {max(REL_SEEN):.2e}")
 
 
@@ -147,9 +170,11 @@ def test_train_step_with_seeded_noise_and_adam(tag, gpu, golden_dir):
     np.testing.assert_allclose(summary(out), G["train_q1/out"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(lbits.detach().cpu().numpy(), G["train_q1/latent_bits"], rtol=2e-5)
     np.testing.assert_allclose(nbits.detach().cpu().numpy(), G["train_q1/net_bits"], rtol=2e-5)
-    grad_close(emb.grad.cpu().numpy(), G["train_q1/grad_emb"])
+    t = tag + "/golden_q1"
+    grad_close(emb.grad.cpu().numpy(), G["train_q1/grad_emb"], *TOLS[t], tag=t)
     for k, p in net.named_parameters():
-        grad_close(summary(p.grad, 48)[2:], G["train_q1/grad/" + k][2:])
+        grad_close(summary(p.grad, 48)[2:], G["train_q1/grad/" + k][2:], *TOLS[t], tag=t)
+    report(t)
     # fused Adam (step 1) on every tensor, then compare with torch.optim.Adam run by the reference
     with torch.no_grad():
         for p in list(net.parameters()) + [emb]:

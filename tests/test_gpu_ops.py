@@ -179,12 +179,33 @@ def test_three_mfma_weight_gradients_in_one_launch(ops):
     wg.add_mfma3([g5, y3, g3], [y4, g4, y2], outs)
     wg.finish()
     # conv2's gradient runs in the Winograd (y, x) form inside the merged launches (wgrad_wino.h): another arithmetic,
-    # agreement to rounding (NVF_WGRAD_WINO=0 restores the direct form and bit-equality)
+    # agreement to rounding (a context with set_direct restores the direct form and bit-equality, below)
     ref0 = ops.wgrad(g5, y4, 4, 1, 0, out_mode=0)
     assert (outs[0] - ref0).abs().max().item() < 2e-5 * ref0.abs().max().item()
     assert torch.equal(outs[1], ops.wgrad(y3, g4, 5, 2, 0, out_mode=0))
-    ref2 = ops.wgrad(g3, y2, 4, 1, 0, out_mode=0)                  # conv1: direct form by default (NVF_WGRAD_WINO1=1: Winograd)
-    assert (outs[2] - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+    ref2 = ops.wgrad(g3, y2, 4, 1, 0, out_mode=0)                  # conv1: direct form by default
+    assert torch.equal(outs[2], ref2)
+    # the forms are the CALLER's choice, carried by its context (nvf_step_ctx_set_direct / _set_wgrad_forms): the library
+    # reads no environment variable.  direct: all three bit-equal to the per-layer kernels; (z split 2, conv1 Winograd):
+    # both 4^3 gradients to rounding, up2 untouched
+    cd = ops.StepCtx()
+    cd.set_direct(True)
+    outs_d = [torch.empty_like(o) for o in outs]
+    wgd = ops.WgradBatch(g5.device, nbytes=128 << 20, ctx=cd)
+    wgd.add_mfma3([g5, y3, g3], [y4, g4, y2], outs_d)
+    wgd.finish()
+    assert torch.equal(outs_d[0], ref0) and torch.equal(outs_d[1], outs[1]) and torch.equal(outs_d[2], ref2)
+    cw = ops.StepCtx()
+    cw.set_wgrad_forms(2, True)
+    outs_w = [torch.empty_like(o) for o in outs]
+    wgw = ops.WgradBatch(g5.device, nbytes=128 << 20, ctx=cw)
+    wgw.add_mfma3([g5, y3, g3], [y4, g4, y2], outs_w)
+    wgw.finish()
+    assert (outs_w[0] - ref0).abs().max().item() < 2e-5 * ref0.abs().max().item()
+    assert torch.equal(outs_w[1], outs[1])
+    assert not torch.equal(outs_w[2], ref2) and (outs_w[2] - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+    with pytest.raises(RuntimeError):
+        cw.set_wgrad_forms(9, False)
     # ... and so do up1 + conv0
     y1, g2 = R(B, 16, 8, 8, 8), R(B, 8, 19, 19, 19)
     h0, g1 = R(B, 8, 4, 4, 4), R(B, 16, 8, 8, 8)
