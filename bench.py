@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each (value = the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic")
+    ap.add_argument("--no-direct", action="store_true", help="skip the `direct_form` object (the same region with TrainEngine(winograd=False))")
+    ap.add_argument("--sustained-s", type=float, default=5.5, help="length of the `sustained` region in seconds (0: skip)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the `sweep` object (batch 256 per GPU, full-batch latent step, 4096-block latent step + eval)")
     ap.add_argument("--sweep-blocks", type=int, default=4096, help="blocks of the sweep's big latent step / eval (all ranks together)")
@@ -482,6 +484,83 @@ def run(args):
     if args.pmc_child:
         return 0
 
+    # ---- `sustained`: ONE region of >= --sustained-s seconds of the same steps through the same unrolled graphs (the
+    # headline region is a few milliseconds: the reference trains 501 epochs, NVFPCC.py:128).  Ten equal parts separated
+    # by HIP events on the compute stream (no host synchronisation inside the region); ms / step of the first and the
+    # last tenth show whether the clock holds.
+    sustained_obj = None
+    if args.mode == "step" and graphed is not None and graphed.graphs_u and args.sustained_s > 0 and region_ms:
+        per_part = max(int(args.sustained_s / 10 / (region_ms[0] * 1e-3)) // 16 * 16, 16)
+        per_part = min(per_part, graphed.CAP // 16 * 16)
+        srng = np.random.default_rng(77)
+        W = B * world
+
+        def part_schedule():
+            need = per_part * W
+            o = np.concatenate([srng.permutation(args.blocks) for _ in range(need // args.blocks + 1)])[:need]
+            whole = o.reshape(per_part, W).astype(np.int64)
+            return graphed.stage_schedule((whole[:, rank::world], counts[whole].sum(axis=1).astype(np.float64)))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+        barrier()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for part in range(10):
+            graphed.load_schedule(part_schedule())       # (a handle is staged while the previous part still runs)
+            graphed.replay_all()
+            evs[part + 1].record()
+        barrier()
+        wall = timed_max(time.perf_counter() - t0)
+        parts_ms = [evs[i].elapsed_time(evs[i + 1]) / per_part for i in range(10)]
+        nsteps = 10 * per_part
+        sustained_obj = {"seconds": round(wall, 3), "steps": nsteps, "ms_per_step": round(wall / nsteps * 1e3, 4),
+                         "blocks_per_s": round(nsteps * W / wall, 1),
+                         "ms_per_step_first_tenth": round(parts_ms[0], 4), "ms_per_step_last_tenth": round(parts_ms[-1], 4),
+                         "ms_per_step_tenths": [round(x, 4) for x in parts_ms],
+                         "loss_last_step": round(eng.loss_value(), 3),
+                         "parameters_finite": bool(torch.isfinite(eng.flat_p).all().item()),
+                         "note": "one timed region, wall clock between two barriers (max over ranks); the tenths are HIP-event "
+                                 "intervals on the compute stream of this rank; %d-step schedules uploaded between the parts "
+                                 "without synchronising" % per_part}
+
+    # ---- `direct_form`: the same K-step region with TrainEngine(winograd=False) -- every 4^3 layer of the training step in the
+    # direct summation order, the form that follows the reference's own three-epoch trajectory to 2e-6
+    # (tests/test_gpu_engine.py::test_direct_forms_follow_the_reference_trajectory_to_rounding); the headline runs the
+    # reduced-multiplication (Winograd) forms, whose trajectory parity is statistical
+    direct_obj = None
+    if args.mode == "step" and graphed is not None and not args.no_direct:
+        from nvfpcc_amd import engine as _E
+        saved = _E._WINO
+        _E._WINO = False
+        try:
+            eng_d = build_engine(args, device, world)
+        finally:
+            _E._WINO = saved
+        assert not eng_d.winograd
+        g_d = GraphedTrainStep(eng_d, B, args.q)
+        g_d.prime()
+        W = B * world
+        drng = np.random.default_rng(55)
+
+        def direct_region(n):
+            o = np.concatenate([drng.permutation(args.blocks) for _ in range(n * W // args.blocks + 1)])[:n * W]
+            whole = o.reshape(n, W).astype(np.int64)
+            h = g_d.stage_schedule((whole[:, rank::world], counts[whole].sum(axis=1).astype(np.float64)))
+            barrier()
+            t1 = time.perf_counter()
+            g_d.load_schedule(h)
+            g_d.replay_all()
+            barrier()
+            return timed_max(time.perf_counter() - t1) / n
+        direct_region(args.warmup if args.warmup > 0 else 1)
+        d_ms = [direct_region(args.steps) * 1e3 for _ in range(nreg)]
+        direct_obj = {"ms_per_step": round(d_ms[0], 4), "blocks_per_s": round(W / (d_ms[0] * 1e-3), 1),
+                      "repeats_ms_per_step": [round(x, 4) for x in d_ms], "steps": args.steps,
+                      "engine": "TrainEngine(winograd=False): conv2 / conv1 forward, backward-data and weight gradients in the "
+                                "direct fixed summation order (rounds 1-3 kernels); same launch path as the headline",
+                      "parity": "reference trajectory golden to 2e-6 (strict); the headline engine: statistical (5 seeds)"}
+        del eng_d, g_d
+        torch.cuda.empty_cache()
+
     # ---- whole epochs of NVFPCC.py train: mini-batches (graph replay; the short last batch replays a graph of its own size), the
     # full-batch latent step on this rank's shard, the device-side sums of the log line, eval on every 10th epoch
     epoch_obj = None
@@ -717,6 +796,10 @@ def run(args):
                                      blocks_per_s / world * BYTES_PER_BLOCK[args.chanstr] / (PEAK_HBM_GBS * 1e9), 4)}
         if roofline:
             out["roofline"] = roofline
+        if direct_obj:
+            out["direct_form"] = direct_obj
+        if sustained_obj:
+            out["sustained"] = sustained_obj
         if epoch_obj:
             out["epoch"] = epoch_obj
         if extra:

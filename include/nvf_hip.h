@@ -672,6 +672,35 @@ int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t seed, uint
                   float* const* dsts, const int* widths, int n, const int64_t* idx, int rows,
                   const NvfRateJob* rate /* may be NULL: see nvf_weight_rate_batch_final */, void* stream);
 
+/* nvf_step_head AND nvf_stem_latent_fwd (latent generator + quantiser + up0 / IGDN / conv0 of the mini-batch) in ONE
+ * launch, narrow decoder (c0 = 8, c1 = 16, ch <= 8, rows <= 32): the stem's workgroups derive their effective weights
+ * from the raw parameters of layer-table rows lat_row / up0_row / conv0_row themselves (network.py:611-620, 735-740:
+ * the arithmetic of nvf_prepare_weights, element by element) and fetch their latents as emb[idx[b]], so nothing in the
+ * launch waits for anything else.  Same results as the two calls, bit for bit.  block ids of the latent noise = idx. */
+typedef struct NvfStemHead {
+  const float* emb;            /* latent table [N, ch, 2, 2, 2] */
+  const float* lat_beta_hat;   /* GDN of the latent generator */
+  const float* lat_gamma_hat;
+  const float* sigma;          /* entropy coder [ch] */
+  const float* mu;
+  const float* beta_hat;       /* IGDN of the decoder */
+  const float* gamma_hat;
+  float* h;                    /* outputs of nvf_stem_latent_fwd */
+  float* lat;
+  float* x_rounded;
+  float* bits;
+  float* a0;
+  float* h0;
+  float* y1;
+  int32_t lat_row, up0_row, conv0_row;
+  int32_t mode, ch, c0, c1, reserved;
+} NvfStemHead;
+int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
+                       const uint64_t* step_dev, float* const* pack_dsts, const int* pack_kinds, const int* pack_c0s,
+                       const int* pack_c1s, const int* pack_layers, const int* pack_bwd, int npack,
+                       const float* const* srcs, float* const* dsts, const int* widths, int n, const int64_t* idx,
+                       int rows, const NvfRateJob* rate /* may be NULL */, const NvfStemHead* stem, void* stream);
+
 /* U[0,1) floats, Philox4x32-10 keyed by (seed, stream_id), counter = element index */
 int nvf_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

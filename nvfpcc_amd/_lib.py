@@ -118,6 +118,7 @@ PROTOTYPES = {
     "nvf_scatter_add_rows": (I, [P, P, P, I, I, P]),
     "nvf_gather_rows_multi": (I, [P, P, P, I, P, I, P]),
     "nvf_step_head": (I, [P, I, I, U, U, P, P, P, P, P, P, P, I, P, P, P, I, P, I, P, P]),
+    "nvf_step_head_stem": (I, [P, I, I, U, U, P, P, P, P, P, P, P, I, P, P, P, I, P, I, P, P, P]),
     "nvf_weight_rate_batch_final": (I, [P, P, P, P, P, P]),
     "nvf_wgrad_reduce_multi_and_sums_fused": (I, [P, P, P, P, I, P, P, P, P, P, P, I, I, P, Z, P, P]),
     "nvf_finals_flush_tail": (I, [P, P, P, I, P]),
@@ -143,6 +144,13 @@ class NvfRateJob(C.Structure):
     """include/nvf_hip.h: typedef struct NvfRateJob."""
     _fields_ = [("kernel", P * 8), ("dk", P * 8), ("n", C.c_int32 * 8), ("nlayers", C.c_int32), ("reserved", C.c_int32),
                 ("sigma", P), ("mu", P), ("part", P), ("g", F), ("reserved2", F)]
+
+
+class NvfStemHead(C.Structure):
+    """include/nvf_hip.h: typedef struct NvfStemHead."""
+    _fields_ = [(n, P) for n in ("emb", "lat_beta_hat", "lat_gamma_hat", "sigma", "mu", "beta_hat", "gamma_hat", "h", "lat",
+                                 "x_rounded", "bits", "a0", "h0", "y1")] + \
+               [(n, C.c_int32) for n in ("lat_row", "up0_row", "conv0_row", "mode", "ch", "c0", "c1", "reserved")]
 
 
 class NvfAdamFuse(C.Structure):

@@ -32,6 +32,7 @@ __device__ __forceinline__ float nvf_act(float v, int act) {
 
 // two floats at any 4-byte phase (rows of 35 or 19 floats): the compiler may use one 8-byte access, not an aligned one
 struct __attribute__((packed, aligned(4))) nvf_f2u { float a, b; };
+struct __attribute__((packed, aligned(4))) nvf_f4u { float a, b, c, d; };   // four, likewise (parameter slices of a flat buffer)
 
 // ---- Philox4x32-10 counter RNG ------------------------------------------------
 // key = seed (64 bit), counter = (index lo, index hi, stream lo, stream hi).

@@ -7,6 +7,7 @@
 #include "step_ctx.h"
 #include "pack_mfma.h"
 #include "latent_tail.h"
+#include "stem_fwd.h"
 
 #define NVF_GRID(n, bs) ((unsigned)(((n) + (bs)-1) / (bs)))
 
@@ -450,7 +451,10 @@ extern "C" int nvf_weight_rate(const float* kernel, int n, const float* sigma, c
 // is ADDED to (accumulate) or overwritten with g * dbits/dk
 __device__ __forceinline__ void weight_rate_partial_body(const WeightRateBatch& b, const float* __restrict__ sigma,
                                                          const float* __restrict__ mu, float* __restrict__ part, float g,
-                                                         int wg, int accumulate, float* red) {
+                                                         int wg, int accumulate, float* red, int nthreads = 0) {
+  // nthreads (0 = blockDim.x): the threads that walk the chunk -- a carrier launch with larger workgroups keeps the
+  // 256-thread arithmetic (the others add zeros to the block sums: the same bits)
+  if (nthreads <= 0) nthreads = blockDim.x;
   const float gsign = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
   const float sabs = fabsf(sigma[0]), m = mu[0];
   int l = 0;
@@ -460,7 +464,7 @@ __device__ __forceinline__ void weight_rate_partial_body(const WeightRateBatch& 
   const float* k = b.kernel[l];
   float* dk = b.dk[l];
   float sb = 0.f, ss = 0.f, sm_ = 0.f;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+  for (int i = lo + threadIdx.x; i < hi && (int)threadIdx.x < nthreads; i += nthreads) {
     float v = rintf(k[i] * 16.f) / 16.f;
     RateTerm r = rate_term(v, m, sabs, 0.03125f, gsign);
     sb += r.bits;
@@ -1144,6 +1148,169 @@ extern "C" int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t
   }
   step_head_kernel<<<rate.nwg + wpl * nlayers + wpl * npack + (unsigned)(wg * n), 256, 0, nvf_stream(stream)>>>(
       (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl, rate);
+  NVF_LAUNCH_CHECK();
+  return NVF_OK;
+}
+
+// ---- the step head AND the stem's forward (with the latent generator + quantiser) in one launch --------------------------
+// The stem's workgroups derive their weights from the raw parameters (effective_weight: the arithmetic of the weight
+// preparation, element by element) and fetch their latent rows through idx, so they depend on nothing the rest of the
+// launch writes: two latency-bound launches (9.4 + 11.5 us at batch 16) become one.  Workgroups have C0 * 64 threads (the
+// stem's); the head's jobs are blockDim-agnostic, the weight-rate partial pass keeps its 256-thread arithmetic.
+struct StemRawW {
+  NvfLayerDesc lat, up0l, conv0l;
+  const float* emb;
+  const int64_t* idx;
+  uint64_t seed, st;
+  int32_t ch, q;
+  __device__ __forceinline__ float weight(const NvfLayerDesc& d, int e) const {
+    return effective_weight(d, layout_to_kernel_index(d, 0, e), d.quantised ? q : 0, seed, (st << 8) | (uint64_t)d.layer_id);
+  }
+  // Four consecutive RAW elements i0 .. i0 + 3 (i0 a multiple of 4) per call: two 16-byte loads and ONE Philox block --
+  // effective_weight's arithmetic per element (nvf_uniform01(i) = word i & 3 of block i >> 2).  A transposed conv's raw
+  // layout is [ci][co][k]: walking it in order is coalesced; the forward layout is a scatter into LDS.
+  __device__ __forceinline__ void weight4(const NvfLayerDesc& d, int i0, float (&w)[4]) const {
+    const nvf_f4u k4 = *(const nvf_f4u*)(d.kernel + i0), n4 = *(const nvf_f4u*)(d.kernel_init + i0);
+    const float kk[4] = {k4.a, k4.b, k4.c, k4.d}, nn[4] = {n4.a, n4.b, n4.c, n4.d};
+    const int qq = d.quantised ? q : 0;
+    uint32_t r[4] = {0, 0, 0, 0};
+    if (qq == 1) nvf_philox(seed, (st << 8) | (uint64_t)d.layer_id, (uint64_t)(i0 >> 2), r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float k = kk[j];
+      if (qq == 1) k = k + ((float)(r[j] >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.0625f;
+      else if (qq == 2) k = rintf(k * 16.f) / 16.f;
+      w[j] = k + nn[j];
+    }
+  }
+  template <int NT, int C0>
+  __device__ __forceinline__ void fill_up0(float* s_w0, int nch, int tid) const {
+    // raw [ci][co = C0][125]: all of it, in order
+    for (int i0 = 4 * tid; i0 < nch * C0 * 125; i0 += 4 * NT) {
+      float w[4];
+      weight4(up0l, i0, w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j, k = i % 125, cc = i / 125, co = cc % C0, ci = cc / C0;
+        s_w0[(ci * 125 + k) * C0 + co] = w[j];
+      }
+    }
+  }
+  template <int NT, int C0, int C1, int COG>
+  __device__ __forceinline__ void fill_conv0(float* s_w1, int part, int tid) const {
+    // raw [ci = C0][co = C1][125]: per input channel the run of this part's NCG * COG output channels (a multiple of 4
+    // elements long and starting at one: 125 * COG * k with COG = 4)
+    constexpr int NCG = C0 / 8, RUN = NCG * COG * 125;
+    static_assert(RUN % 4 == 0 && (COG * 125) % 4 == 0, "16-byte pieces");
+    for (int t = tid; t < C0 * (RUN / 4); t += NT) {
+      const int ci = t / (RUN / 4), r0 = 4 * (t - ci * (RUN / 4));
+      float w[4];
+      weight4(conv0l, (ci * C1 + part * NCG * COG) * 125 + r0, w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + j, k = r % 125, cl = r / 125, cg = cl / COG, c = cl % COG;
+        s_w1[cg * (C0 * 125 * COG) + (ci * 125 + k) * COG + c] = w[j];
+      }
+    }
+  }
+  __device__ __forceinline__ float up0_b(int co) const { return up0l.b[co] + up0l.b_init[co]; }
+  __device__ __forceinline__ float conv0_b(int co) const { return conv0l.b[co] + conv0l.b_init[co]; }
+  __device__ __forceinline__ float lat_w(int i) const { return weight(lat, i); }
+  __device__ __forceinline__ float lat_b(int j) const { return lat.b[j] + lat.b_init[j]; }
+  __device__ __forceinline__ float e(int b, int i, int sp) const { return emb[((size_t)idx[b] * ch + i) * 8 + sp]; }
+};
+
+template <int C0, int C1, int COG>
+__global__ __launch_bounds__(C0 * 64) void step_head_stem_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q,
+                                                                 uint64_t seed, uint64_t step,
+                                                                 const uint64_t* __restrict__ step_dev, PackJobs pk,
+                                                                 GatherMulti g, const int64_t* __restrict__ idx, int rows,
+                                                                 int gwg, int wpl, RateInHead rate, NvfStemHead sj) {
+  __shared__ __attribute__((aligned(16))) float lds[StemFwdLds<C0, C1, COG>::FLOATS];
+  constexpr int PARTS = C1 / (COG * (C0 / 8));
+  int bid = blockIdx.x;
+  const int nstem = 1 + rows * PARTS;        // the latent workgroup (the longest chain) first, then (block, part)
+#ifndef NVF_HS_SKIP
+#define NVF_HS_SKIP 0                        // tuning builds: 1 = the stem's workgroups do nothing, 2 = the head's (results meaningless)
+#endif
+  if ((NVF_HS_SKIP & 1) && bid < nstem) return;
+  if ((NVF_HS_SKIP & 2) && bid >= nstem) return;
+  if (bid < nstem) {
+    const uint64_t st = step + (step_dev ? step_dev[0] : 0ull);
+    const StemRawW wp{table[sj.lat_row], table[sj.up0_row], table[sj.conv0_row], sj.emb, idx, seed, st, sj.ch, q};
+    const StemLatent L{nullptr, nullptr, nullptr, sj.lat_beta_hat, sj.lat_gamma_hat, idx, sj.sigma, sj.mu, sj.h, sj.lat,
+                       sj.x_rounded, sj.bits, step_dev, seed, step, sj.mode, rows};
+    const int b = bid == 0 ? 0 : (bid - 1) / PARTS, part = bid == 0 ? PARTS : (bid - 1) % PARTS;
+    stem_fwd_body<C0, C1, COG, true, true>(nullptr, wp, sj.beta_hat, sj.gamma_hat, sj.a0, sj.h0, sj.y1, sj.ch, L, b, part,
+                                           lds);
+    return;
+  }
+  bid -= nstem;
+  if (bid < rate.nwg) {        // the weight-rate term's partial sums: parameters only, nothing of the mini-batch
+    weight_rate_partial_body(rate.b, rate.sigma, rate.mu, rate.part, rate.g, bid, 0, lds, 256);
+    return;
+  }
+  bid -= rate.nwg;
+  if (bid < wpl * nlayers) { prepare_weights_body(table, q, seed, step, step_dev, bid / wpl, bid % wpl, wpl); return; }
+  bid -= wpl * nlayers;
+  if (bid < wpl * pk.n) {
+    const int job = bid / wpl;
+    const NvfLayerDesc d = table[pk.layer[job]];
+    const int qq = d.quantised ? q : 0, bwd = pk.bwd[job];
+    const uint64_t st = step + (step_dev ? step_dev[0] : 0ull);
+    const uint64_t sid = (st << 8) | (uint64_t)d.layer_id;
+    pack_mfma_body(pk, job, bid % wpl, wpl, [&](int, int si) {
+      return effective_weight(d, layout_to_kernel_index(d, bwd, si), qq, seed, sid);
+    });
+    return;
+  }
+  bid -= wpl * pk.n;
+  gather_rows_multi_body(g, idx, rows, bid / gwg, bid % gwg, gwg);
+}
+
+extern "C" int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uint64_t seed, uint64_t step,
+                                  const uint64_t* step_dev, float* const* pack_dsts, const int* pack_kinds,
+                                  const int* pack_c0s, const int* pack_c1s, const int* pack_layers, const int* pack_bwd,
+                                  int npack, const float* const* srcs, float* const* dsts, const int* widths, int n,
+                                  const int64_t* idx, int rows, const NvfRateJob* rate_job, const NvfStemHead* stem,
+                                  void* stream) {
+  if (!table_dev || nlayers <= 0 || !idx || npack < 0 || !stem) return NVF_EINVAL;
+  const NvfStemHead sj = *stem;
+  if (sj.c0 != 8 || sj.c1 != 16 || sj.ch <= 0 || sj.ch > kStemFwdMaxCh || rows <= 0 || rows > 32) return NVF_EINVAL;
+  if (sj.lat_row < 0 || sj.lat_row >= nlayers || sj.up0_row < 0 || sj.up0_row >= nlayers || sj.conv0_row < 0 ||
+      sj.conv0_row >= nlayers || (sj.mode != 0 && sj.mode != 1))
+    return NVF_EINVAL;
+  if (!sj.emb || !sj.lat_beta_hat || !sj.lat_gamma_hat || !sj.sigma || !sj.mu || !sj.beta_hat || !sj.gamma_hat || !sj.h ||
+      !sj.lat || !sj.x_rounded || !sj.bits || !sj.a0 || !sj.h0 || !sj.y1)
+    return NVF_EINVAL;
+  PackJobs pk{};
+  if (npack > 0) {
+    if (!pack_layers || !pack_bwd) return NVF_EINVAL;
+    const int rc = pack_jobs_desc(nullptr, pack_dsts, pack_kinds, pack_c0s, pack_c1s, npack, pk);
+    if (rc != NVF_OK) return rc;
+    for (int j = 0; j < npack; ++j) {
+      if (pack_layers[j] < 0 || pack_layers[j] >= nlayers) return NVF_EINVAL;
+      pk.layer[j] = pack_layers[j]; pk.bwd[j] = pack_bwd[j] ? 1 : 0;
+    }
+  }
+  GatherMulti g{};
+  long wg = 0;
+  const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
+  if (rc != NVF_OK) return rc;
+  wg = (wg + 1) / 2;                   // 512-thread workgroups: half as many as nvf_step_head's for the same threads
+  const int wpl = 32;
+  RateInHead rate{};
+  if (rate_job) {
+    if (!rate_job->sigma || !rate_job->mu || !rate_job->part) return NVF_EINVAL;
+    const int rrc = weight_rate_batch_desc(rate_job->kernel, rate_job->dk, rate_job->n, rate_job->nlayers, rate.b);
+    if (rrc != NVF_OK) return rrc;
+    rate.sigma = rate_job->sigma; rate.mu = rate_job->mu; rate.part = rate_job->part; rate.g = rate_job->g;
+    rate.nwg = rate.b.first_wg[rate.b.nlayers];
+  }
+  constexpr int COG = 4, PARTS = 16 / COG;
+  const unsigned grid = 1 + rows * PARTS + rate.nwg + wpl * nlayers + wpl * npack + (unsigned)(wg * n);
+  step_head_stem_kernel<8, 16, COG><<<grid, 512, 0, nvf_stream(stream)>>>(
+      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl, rate, sj);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

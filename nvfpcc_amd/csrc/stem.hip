@@ -16,92 +16,12 @@
 #include "step_ctx.h"
 #include "latent_tail.h"
 #include "stem_bwd.h"
+#include "stem_fwd.h"
 
 namespace {
 constexpr int MAXCH = 8;
 
-__device__ __forceinline__ float st_beta(float bh) {
-  float m = fmaxf(bh, NVF_BETA_BOUND);
-  return m * m - NVF_PEDESTAL;
-}
-__device__ __forceinline__ float st_gamma(float gh) {
-  float m = fmaxf(gh, NVF_GAMMA_BOUND);
-  return m * m - NVF_PEDESTAL;
-}
-// dst[e] = src[index(e)] for e < n with U loads of a thread in flight before the first store (a plain copy loop is a
-// chain of load -> wait -> store round trips: 16 of them for the wide stem's 64 KB of weights)
-template <int NT, int U, class Index>
-__device__ __forceinline__ void stem_copy(float* dst, const float* __restrict__ src, int n, int tid, Index index) {
-#pragma unroll 1
-  for (int e0 = tid; e0 < n; e0 += NT * U) {
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * NT;
-      v[u] = e < n ? src[index(e)] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * NT;
-      if (e < n) dst[e] = v[u];
-    }
-  }
-}
 }  // namespace
-
-// conv0 for one output parity class (EZ,EY,EX): lane = cell, COG output channels in registers, taps unrolled so
-// the LDS reads of a whole input channel are in flight together.  Weights come from the LDS copy s_w[ci*125+tap][COG].
-template <int C0, int C1, int EZ, int EY, int EX, int COG>
-__device__ __forceinline__ void stem_conv0_class(const float* s_h, const float* s_w, const float* __restrict__ b1,
-                                                 float* __restrict__ y1, int b, int co0, int v) {
-  const int mz = (v >> 4) + 1, my = ((v >> 2) & 3) + 1, mx = (v & 3) + 1;   // cells 1..4 (pad 2)
-  float acc[COG];
-#pragma unroll
-  for (int co = 0; co < COG; ++co) acc[co] = 0.f;
-#pragma unroll 2
-  for (int ci = 0; ci < C0; ++ci) {
-#pragma unroll
-    for (int jz = 0; jz < 3 - EZ; ++jz)
-#pragma unroll
-      for (int jy = 0; jy < 3 - EY; ++jy)
-#pragma unroll
-        for (int jx = 0; jx < 3 - EX; ++jx) {
-          const float hv = s_h[ci * 216 + ((mz - jz + 1) * 6 + (my - jy + 1)) * 6 + (mx - jx + 1)];
-          const float* wr = s_w + (ci * 125 + ((EZ + 2 * jz) * 5 + (EY + 2 * jy)) * 5 + EX + 2 * jx) * COG;
-#pragma unroll
-          for (int co = 0; co < COG; ++co) acc[co] = fmaf(hv, wr[co], acc[co]);
-        }
-  }
-  const int qz = 2 * mz + EZ - 2, qy = 2 * my + EY - 2, qx = 2 * mx + EX - 2;   // in [0, 8)
-#pragma unroll
-  for (int co = 0; co < COG; ++co)
-    y1[((size_t)b * C1 + co0 + co) * 512 + (qz * 8 + qy) * 8 + qx] = fmaxf(acc[co] + b1[co0 + co], 0.f);
-}
-
-// grid = (batch, C1 / COG): every workgroup recomputes the (tiny) up0 + IGDN of its block and produces COG of
-// conv0's 16 output channels, so a batch of 16 blocks runs on 64 CUs instead of 16.  All weights are copied to
-// LDS with coalesced vector loads first: scalar loads in the tap loops were a chain of cache misses.
-// The latent generator + quantiser (nvf_latent_fwd) for the launch that also runs the stem: the stem's workgroups
-// compute the 8 ch rounded latents of their own block themselves (latent_x_rounded: the same arithmetic), so they do
-// not wait for the one workgroup (blockIdx = (0, C1 / COG)) that produces h, lat, x_rounded and the rate for the
-// whole batch.
-struct StemLatent {
-  const float* e;
-  const float* w;          // latent generator's w_fwd [ci][co], bias
-  const float* bw;
-  const float* beta_hat;   // its GDN
-  const float* gamma_hat;
-  const int64_t* block_ids;
-  const float* sigma;
-  const float* mu;
-  float* h_out;
-  float* lat_out;
-  float* x_rounded;
-  float* bits;
-  const uint64_t* step_dev;
-  uint64_t seed, step;
-  int32_t mode, batch;
-};
 
 template <int C0, int C1, int COG, bool LATENT>
 __global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w0,
@@ -111,108 +31,9 @@ __global__ __launch_bounds__(C0 * 64) void stem_fwd_kernel(const float* __restri
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            float* __restrict__ a0, float* __restrict__ h0,
                                                            float* __restrict__ y1, int ch, StemLatent L) {
-  constexpr int NT = C0 * 64, NCG = C0 / 8;      // NCG groups of eight waves (one per parity class) in the conv0 phase,
-  constexpr int PARTS = C1 / (COG * NCG);        //  each with its own COG output channels
-  __shared__ float s_x[MAXCH * 8];
-  __shared__ float s_a[C0 * 64];
-  __shared__ __attribute__((aligned(16))) float s_w0[MAXCH * 125 * C0];
-  if (LATENT && blockIdx.y == PARTS) {
-    if (blockIdx.x == 0)
-      latent_fwd_body(L.e, L.w, L.bw, L.beta_hat, L.gamma_hat, L.block_ids, L.sigma, L.mu, L.h_out, L.lat_out,
-                      L.x_rounded, L.bits, L.batch, ch, 8, L.mode, L.seed, L.step, L.step_dev, s_a, s_w0,
-                      MAXCH * 125 * C0);
-    return;
-  }
-  __shared__ float s_h[C0 * 216];     // h0 with a one-voxel zero halo: [c][6][6][6], index i + 1
-  __shared__ __attribute__((aligned(16))) float s_w1[NCG * C0 * 125 * COG];
-  __shared__ float s_beta[C0], s_gamma[C0 * C0];
-  __shared__ float s_lat[2 * MAXCH * MAXCH + 2 * MAXCH];   // latent generator: w [ci][co], gamma_hat, bias, beta_hat
-  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  float ev[MAXCH];                                           // this thread's latent element: its ch inputs, fetched together
-  if (LATENT) {
-    // (parameters through LDS and the inputs up front: as loads inside the fmaf chains they were ch^2 dependent round trips)
-    if (tid < ch * ch) { s_lat[tid] = L.w[tid]; s_lat[MAXCH * MAXCH + tid] = L.gamma_hat[tid]; }
-    if (tid >= 64 && tid < 64 + ch) {
-      s_lat[2 * MAXCH * MAXCH + tid - 64] = L.bw[tid - 64];
-      s_lat[2 * MAXCH * MAXCH + MAXCH + tid - 64] = L.beta_hat[tid - 64];
-    }
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) ev[i] = (tid < ch * 8 && i < ch) ? L.e[((size_t)b * ch + i) * 8 + (tid & 7)] : 0.f;
-  } else if (tid < ch * 8) {
-    s_x[tid] = x0[(size_t)b * ch * 8 + tid];
-  }
-  if (tid >= 64 && tid < 64 + C0) s_beta[tid - 64] = st_beta(beta_hat[tid - 64]);
-  if (tid >= 128 && tid < 128 + C0 * C0) s_gamma[tid - 128] = st_gamma(gamma_hat[tid - 128]);
-  for (int e = tid; e < C0 * 216; e += NT) s_h[e] = 0.f;
-  stem_copy<NT, 16>(s_w0, w0, ch * 125 * C0, tid, [](int e) { return e; });
-  stem_copy<NT, 16>(s_w1, w1, NCG * C0 * 125 * COG, tid, [&](int e) {
-    const int cg = e / (C0 * 125 * COG), r = e - cg * (C0 * 125 * COG);
-    return (r / COG) * C1 + (part * NCG + cg) * COG + r % COG;
-  });
-  if (LATENT) {
-    __syncthreads();
-    if (tid < ch * 8)
-      s_x[tid] = latent_x_rounded_from(ev, s_lat, s_lat + 2 * MAXCH * MAXCH, s_lat + 2 * MAXCH * MAXCH + MAXCH,
-                                       s_lat + MAXCH * MAXCH, tid >> 3, ch);
-  }
-  __syncthreads();
-  {  // up0: a0[co, o] = b0 + sum_ci sum_{k : o + 2 - k = 2 i} x0[ci, i] w0[ci][k][co]
-    // per axis the valid taps are k = o (input i = 1) and k = o + 2 (i = 0, if o <= 2): ascending k, the order of
-    // the per-layer kernel, without walking the 125 taps.  Lanes run over the output CHANNEL here (the weight row of a
-    // tap is C0 consecutive words): with lanes over positions every lane read another tap's row at a stride of C0
-    // words -- 2 (C0 = 16) or 4 banks for the whole wave, 11 us of this launch for the wide decoder.
-    const int co = tid % C0, vo = tid / C0, oz = vo >> 4, oy = (vo >> 2) & 3, ox = vo & 3;
-    float acc = 0.f;
-    for (int ci = 0; ci < ch; ++ci)
-#pragma unroll
-      for (int az = 0; az < 2; ++az) {
-        const int kz = oz + 2 * az;
-        if (kz > 4) continue;
-#pragma unroll
-        for (int ay = 0; ay < 2; ++ay) {
-          const int ky = oy + 2 * ay;
-          if (ky > 4) continue;
-#pragma unroll
-          for (int ax = 0; ax < 2; ++ax) {
-            const int kx = ox + 2 * ax;
-            if (kx > 4) continue;
-            acc = fmaf(s_x[ci * 8 + (1 - az) * 4 + (1 - ay) * 2 + (1 - ax)],
-                       s_w0[(ci * 125 + (kz * 5 + ky) * 5 + kx) * C0 + co], acc);
-          }
-        }
-      }
-    const float val = acc + b0[co];
-    s_a[co * 64 + vo] = val;
-    if (part == 0) a0[(size_t)b * C0 * 64 + co * 64 + vo] = val;
-  }
-  const int c = tid >> 6, v = tid & 63, oz = v >> 4, oy = (v >> 2) & 3, ox = v & 3;
-  __syncthreads();
-  {  // IGDN: h0 = a0 * sqrt(beta_c + sum_j gamma_cj a0_j^2)
-    float nrm = s_beta[c];
-#pragma unroll
-    for (int j = 0; j < C0; ++j) {
-      const float xj = s_a[j * 64 + v];
-      nrm = fmaf(s_gamma[c * C0 + j], xj * xj, nrm);
-    }
-    const float hv = s_a[tid] * sqrtf(nrm);
-    if (part == 0) h0[(size_t)b * C0 * 64 + tid] = hv;
-    s_h[c * 216 + ((oz + 1) * 6 + (oy + 1)) * 6 + ox + 1] = hv;
-  }
-  __syncthreads();
-  // conv0: one wave per output parity class (and channel group), one lane per cell
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wv >> 3, co0 = (part * NCG + cg) * COG;
-  const float* sw = s_w1 + cg * (C0 * 125 * COG);
-  switch (wv & 7) {
-    case 0: stem_conv0_class<C0, C1, 0, 0, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    case 1: stem_conv0_class<C0, C1, 0, 0, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    case 2: stem_conv0_class<C0, C1, 0, 1, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    case 3: stem_conv0_class<C0, C1, 0, 1, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    case 4: stem_conv0_class<C0, C1, 1, 0, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    case 5: stem_conv0_class<C0, C1, 1, 0, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    case 6: stem_conv0_class<C0, C1, 1, 1, 0, COG>(s_h, sw, b1, y1, b, co0, v); break;
-    default: stem_conv0_class<C0, C1, 1, 1, 1, COG>(s_h, sw, b1, y1, b, co0, v); break;
-  }
+  __shared__ __attribute__((aligned(16))) float lds[StemFwdLds<C0, C1, COG>::FLOATS];
+  const StemPreparedW wp{w0, b0, w1, b1, L.w, L.bw, L.e, ch};
+  stem_fwd_body<C0, C1, COG, LATENT, false>(x0, wp, beta_hat, gamma_hat, a0, h0, y1, ch, L, blockIdx.x, blockIdx.y, lds);
 }
 
 #ifndef NVF_STEM_COG

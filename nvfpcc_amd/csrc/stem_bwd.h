@@ -74,6 +74,24 @@ __device__ __forceinline__ void copy(float* dst, const float* __restrict__ src, 
     }
   }
 }
+// dst[e] = gen(e) for e < n, U values of a thread in flight before the first store
+template <int NT, int U, class Gen>
+__device__ __forceinline__ void copy_from(float* dst, int n, int tid, Gen gen) {
+#pragma unroll 1
+  for (int e0 = tid; e0 < n; e0 += NT * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * NT;
+      v[u] = e < n ? gen(e) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * NT;
+      if (e < n) dst[e] = v[u];
+    }
+  }
+}
 }  // namespace stem_detail
 
 constexpr int stem_ncol_of(int c0) { return c0 + c0 * c0; }          // IGDN parameter partials per slab

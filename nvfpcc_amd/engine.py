@@ -35,6 +35,8 @@ _CONV2_BWD_VAR = int(os.environ.get("NVF_CONV2_BWD_VAR", "0"))
 _WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's / conv1's backward-data in the Winograd (y, x) form (conv_wino.hip)
 _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forward in TRAINING steps (never in eval)
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
+# (conv1's training FORWARD in that form: measured slower at batch 16 -- 19.1 us two-set / 16.7 us one-set kernel against
+# 12.2 us for the direct kernel, r05 A/B -- 16^3 outputs do not amortise the transforms; not wired)
 _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
 # ... bias sums of the layer below from its backward-data epilogue: measured neutral (the reduction launch 48.9 -> 44.0 us
 # without its 51 MB of re-reads, the two epilogues + 2.7 / + 2.1 us): off by default
@@ -47,6 +49,9 @@ _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' 
 # the stem's backward (conv0^T -> IGDN' -> up0^T, up0's gradients) as the first workgroups of the five-gradient launch
 # instead of two launches in front of it (csrc/stem_bwd.h): it needs g1 only and feeds the latent tail only
 _STEM_IN_TRUNK5 = os.environ.get("NVF_STEM_IN_TRUNK5", "1") != "0"
+# the stem's FORWARD (latent generator + quantiser + up0 / IGDN / conv0) inside the step head's launch: its workgroups
+# derive their weights from the raw parameters, so the two latency-bound launches have nothing to wait for in each other
+_STEM_IN_HEAD = os.environ.get("NVF_STEM_IN_HEAD", "1") != "0"
 
 
 def _NAIVE_OFF():
@@ -146,6 +151,7 @@ class TrainEngine:
         self._graphs_captured = 0  # GraphedTrainStep instances that baked this engine's buffers into a graph
         self.tail_done = False    # the last backward pass applied the optimiser itself (fused tail)
         self._stem_gdn_in_finals = False
+        self._stem_pre = None     # (idx pointer, mode, tensors) of a stem forward the step head's launch already ran
         self._tail_ranges = {}    # gradient index ranges no fused launch covers, per set of covered intervals
         self.collective_mode = None   # "graph" / "host": where GraphedTrainStep puts the all-reduce (dist.attach)
         # the three classifier heads go through the one-launch kernels (instantiated for the two decoders of BASELINE.json);
@@ -253,6 +259,7 @@ class TrainEngine:
             t["layer_id"] = m.layer_id
             t["nbias"] = m.b.numel()
         row = {name: i for i, (name, _, _) in enumerate(mods)}
+        self._rows = row
         named = list(self.layers.items())
         jobs = [(L.w_fwd, L.wp_f, 0, L.cin, 8) for _, L in named if L.wp_f is not None]
         meta = [(row[nm], 0) for nm, L in named if L.wp_f is not None]
@@ -307,9 +314,11 @@ class TrainEngine:
             self._rate = (job, add, key, dk, part)
         return self._rate
 
-    def batch_and_prepare(self, idx_dev, q, with_rate=False):
+    def batch_and_prepare(self, idx_dev, q, with_rate=False, stem_mode=None):
         """_batch(idx_dev) and prepare_weights(q) -- row gather, effective weights, MFMA packings -- as ONE launch
-        (``with_rate``: + the weight-rate term's partial sums, consumed by the backward pass of the same step)."""
+        (``with_rate``: + the weight-rate term's partial sums, consumed by the backward pass of the same step;
+        ``stem_mode`` = 'train' / 'eval': + the stem's forward of forward(e, stem_mode, idx_dev), which must be the next
+        call -- narrow decoder, nvf_step_head_stem)."""
         import ctypes
         srcs = [self.gt, self.dist, self.gt16, self.gt8, self.emb]
         n, rows = len(srcs), idx_dev.numel()
@@ -318,15 +327,38 @@ class TrainEngine:
         jobs, meta = self._mfma_jobs, self._mfma_job_layers
         npk = len(jobs)
         iarr = lambda xs: (ctypes.c_int * max(len(xs), 1))(*xs)
-        check(lib().nvf_step_head(
-            self.table.data_ptr(), self.nlayers, int(q), self.seed, 0 if sd is not None else self.noise_step,
-            None if sd is None else sd.data_ptr(),
-            (ctypes.c_void_p * max(npk, 1))(*[j[1].data_ptr() for j in jobs]), iarr([j[2] for j in jobs]),
-            iarr([j[3] for j in jobs]), iarr([j[4] for j in jobs]), iarr([m[0] for m in meta]),
-            iarr([m[1] for m in meta]), npk, (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
-            (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_int * n)(*[s[0].numel() for s in srcs]), n,
-            idx_dev.data_ptr(), rows, ctypes.byref(self._rate_job()[0]) if with_rate else None,
-            torch.cuda.current_stream().cuda_stream), "nvf_step_head")
+        args = (self.table.data_ptr(), self.nlayers, int(q), self.seed, 0 if sd is not None else self.noise_step,
+                None if sd is None else sd.data_ptr(),
+                (ctypes.c_void_p * max(npk, 1))(*[j[1].data_ptr() for j in jobs]), iarr([j[2] for j in jobs]),
+                iarr([j[3] for j in jobs]), iarr([j[4] for j in jobs]), iarr([m[0] for m in meta]),
+                iarr([m[1] for m in meta]), npk, (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
+                (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_int * n)(*[s[0].numel() for s in srcs]), n,
+                idx_dev.data_ptr(), rows, ctypes.byref(self._rate_job()[0]) if with_rate else None)
+        self._stem_pre = None
+        if (stem_mode is not None and _STEM_IN_HEAD and self.narrow and self.fused_stem and self.fused_latent_stem
+                and self.ch <= 8 and rows <= 32 and _NAIVE_OFF()):
+            # ... and the stem's forward of this mini-batch (forward() picks the tensors up instead of launching it)
+            from ._lib import NvfStemHead
+            net = self.net
+            g2, ec, ig = net.latent_gen.gdn_2, net.entropy_coder, net.reconstructor.activation
+            dev, ch = self.dev, self.ch
+            o = {"h": torch.empty(rows, ch, 2, 2, 2, device=dev), "lat": torch.empty(rows, ch, 2, 2, 2, device=dev),
+                 "x0": torch.empty(rows, ch, 2, 2, 2, device=dev), "lbits": torch.empty(1, device=dev),
+                 "a0": torch.empty(rows, 8, 4, 4, 4, device=dev), "h0": torch.empty(rows, 8, 4, 4, 4, device=dev),
+                 "y1": torch.empty(rows, 16, 8, 8, 8, device=dev)}
+            sj = NvfStemHead()
+            sj.emb, sj.lat_beta_hat, sj.lat_gamma_hat = self.emb.data_ptr(), g2.beta.data_ptr(), g2.gamma.data_ptr()
+            sj.sigma, sj.mu = ec.sigma.data_ptr(), ec.mu.data_ptr()
+            sj.beta_hat, sj.gamma_hat = ig.beta.data_ptr(), ig.gamma.data_ptr()
+            sj.h, sj.lat, sj.x_rounded, sj.bits = (o[k].data_ptr() for k in ("h", "lat", "x0", "lbits"))
+            sj.a0, sj.h0, sj.y1 = (o[k].data_ptr() for k in ("a0", "h0", "y1"))
+            sj.lat_row, sj.up0_row, sj.conv0_row = self._rows["latent"], self._rows["up0"], self._rows["conv0"]
+            sj.mode, sj.ch, sj.c0, sj.c1 = (0 if stem_mode == "train" else 1), ch, 8, 16
+            check(lib().nvf_step_head_stem(*args, ctypes.byref(sj), torch.cuda.current_stream().cuda_stream),
+                  "nvf_step_head_stem")
+            self._stem_pre = (idx_dev.data_ptr(), stem_mode, o)
+        else:
+            check(lib().nvf_step_head(*args, torch.cuda.current_stream().cuda_stream), "nvf_step_head")
         self._rate_ready = bool(with_rate)
         return dsts
 
@@ -378,7 +410,11 @@ class TrainEngine:
         sd = self._step_dev
         ig = net.reconstructor.activation
         stem_done = False
-        if e.shape[1] <= 8 and _NAIVE_OFF() and self.fused_stem and self.fused_latent_stem:   # latent generator,
+        pre, self._stem_pre = getattr(self, "_stem_pre", None), None
+        if pre is not None and pre[0] == block_ids.data_ptr() and pre[1] == mode:
+            a.update(pre[2])                  # the step head's launch ran the latent generator, quantiser and stem
+            stem_done = True
+        elif e.shape[1] <= 8 and _NAIVE_OFF() and self.fused_stem and self.fused_latent_stem:   # latent generator,
             # quantiser and stem in one launch
             (a["h"], a["lat"], a["x0"], a["lbits"], a["a0"], a["h0"], a["y1"]) = ops.stem_latent_fwd(
                 e, Ls["latent"].w_fwd, Ls["latent"].b_eff, g2.beta, g2.gamma, ec.sigma.reshape(-1), ec.mu.reshape(-1),
@@ -901,7 +937,8 @@ class TrainEngine:
                 idx_dev = torch.from_numpy(idx_host).to(self.dev)
             if n_pts is None:
                 n_pts = float(self.counts[idx_host].sum())
-            gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q, with_rate=not self.allow_overlap)
+            gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q, with_rate=not self.allow_overlap,
+                                                            stem_mode="train")
             a = self.forward(e, "train", idx_dev)
             tail = None
             if update and self.grad_hook is None and not self.allow_overlap:
@@ -1075,7 +1112,8 @@ class GraphedTrainStep:
 
     def _body(self, tail):
         eng = self.eng
-        gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q, with_rate=not eng.allow_overlap)
+        gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q, with_rate=not eng.allow_overlap,
+                                                       stem_mode="train")
         a = eng.forward(e, "train", self.idx)
         spec = None
         if tail and eng.grad_hook is None and not eng.allow_overlap:      # single GPU: no launch of its own for the tail

@@ -808,3 +808,27 @@ def test_stem_backward_inside_the_five_gradient_launch(gpu, monkeypatch, batch):
             assert float((g1[o:o + m] - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), name
         else:
             assert torch.equal(g1[o:o + m], g0[o:o + m]), name
+
+
+@pytest.mark.parametrize("q", [1, 2])
+@pytest.mark.parametrize("batch", [16, 5])
+def test_stem_forward_inside_the_step_head_launch(gpu, monkeypatch, batch, q):
+    """Round 5: the step head (effective weights, MFMA packings, row gather, weight-rate partials) and the stem's forward
+    (latent generator + quantiser + up0 / IGDN / conv0) are ONE launch (nvf_step_head_stem): the stem's workgroups derive
+    their weights from the raw parameters with the arithmetic of the weight preparation and fetch their latents through
+    the index vector, so they wait for nothing.  Against the two-launch form: every saved activation, the latent bits, the
+    loss and every gradient are the same BITS (q = 1: the same counter-RNG draws)."""
+    from nvfpcc_amd import engine as E
+    got = {}
+    for merged in (True, False):
+        monkeypatch.setattr(E, "_STEM_IN_HEAD", merged)
+        net, eng, gt, dist, emb = make("S", gpu, nblk=40)
+        ids = np.random.default_rng(7).permutation(40)[:batch]
+        a = eng.train_step(ids, q, update=False)
+        torch.cuda.synchronize()
+        got[merged] = ({k: a[k].clone() for k in ("h", "lat", "x0", "lbits", "a0", "h0", "y1", "p2")},
+                       eng.flat_g.clone(), eng.loss_value())
+    (a1, g1, l1), (a0, g0, l0) = got[True], got[False]
+    for k in a1:
+        assert torch.equal(a1[k], a0[k]), k
+    assert l1 == l0 and torch.equal(g1, g0)

@@ -15,8 +15,8 @@ for spec in "$@"; do
   (
     if [ "$lib" != base ]; then export NVF_LIB=$PWD/nvfpcc_amd/ab/libnvf_hip_$lib.so; fi
     for kv in "${parts[@]:1}"; do export "$kv"; done
-    timeout -k 10 150 python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --steps 200 --warmup 20 > "$out/$v.json" 2> "$out/$v.err" || { echo "bench $v failed"; tail -5 "$out/$v.err"; exit 1; }
-    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/$v" -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --steps 50 > "$out/$v.prof.log" 2>&1 || { echo "prof $v failed"; tail -5 "$out/$v.prof.log"; exit 1; }
+    timeout -k 10 150 python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --no-direct --sustained-s 0 --steps 200 --warmup 20 > "$out/$v.json" 2> "$out/$v.err" || { echo "bench $v failed"; tail -5 "$out/$v.err"; exit 1; }
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/$v" -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --no-direct --sustained-s 0 --steps 50 > "$out/$v.prof.log" 2>&1 || { echo "prof $v failed"; tail -5 "$out/$v.prof.log"; exit 1; }
     rm -f "$out/$v/p_kernel_trace.csv"
   ) || exit 1
 done

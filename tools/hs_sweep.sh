@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 run() {  # name, env...
   name=$1; shift
-  env "$@" rocprofv3 --kernel-trace --stats -d gpurun_out/ab_$name -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --steps 30 --warmup 5 --repeats 1 > gpurun_out/ab_$name.log 2>&1 || { tail -5 gpurun_out/ab_$name.log; return 1; }
+  env "$@" rocprofv3 --kernel-trace --stats -d gpurun_out/ab_$name -o k --output-format csv -- python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --no-direct --sustained-s 0 --steps 30 --warmup 5 --repeats 1 > gpurun_out/ab_$name.log 2>&1 || { tail -5 gpurun_out/ab_$name.log; return 1; }
   python3 - "$name" <<'P'
 import csv,glob,sys
 name=sys.argv[1]

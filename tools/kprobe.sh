@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/kp; mkdir -p $O
 cd $R
 for cfg in "s:" "w:--chanstr 16,32,16,16 --ch 8"; do
   tag=${cfg%%:*}; extra=${cfg#*:}
-  rocprofv3 --kernel-trace --stats -d $O/$tag -o k --output-format csv -- python3 bench.py $extra --no-cpu-baseline --no-pmc --no-epoch --no-sweep --steps 30 --warmup 5 --repeats 1 > $O/$tag.log 2>&1 || { tail -5 $O/$tag.log; exit 1; }
+  rocprofv3 --kernel-trace --stats -d $O/$tag -o k --output-format csv -- python3 bench.py $extra --no-cpu-baseline --no-pmc --no-epoch --no-sweep --no-direct --sustained-s 0 --steps 30 --warmup 5 --repeats 1 > $O/$tag.log 2>&1 || { tail -5 $O/$tag.log; exit 1; }
   cp "$(find $O/$tag -name '*kernel_stats.csv')" $O/$tag.csv
   find $O/$tag -name "*kernel_trace.csv" -delete
 done

@@ -5,7 +5,7 @@ set -o pipefail
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; D=$R/gpurun_out/prof_round; rm -rf $D; mkdir -p $D
 cd $R
-B="python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --repeats 1"
+B="python3 bench.py --no-cpu-baseline --no-pmc --no-epoch --no-sweep --no-direct --sustained-s 0 --repeats 1"
 rocprofv3 --kernel-trace --stats -d $D/stats -o b16 --output-format csv -- $B --steps 50 > $D/stats.log 2>&1 || { tail -5 $D/stats.log; exit 1; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $D/fetch -o b16 --output-format csv -- $B --steps 20 --no-graph > $D/fetch.log 2>&1 || { tail -5 $D/fetch.log; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $D/write -o b16 --output-format csv -- $B --steps 20 --no-graph > $D/write.log 2>&1 || { tail -5 $D/write.log; exit 1; }
