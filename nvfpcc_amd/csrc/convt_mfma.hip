@@ -195,13 +195,23 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[c][e >> 1][e & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
     int colbase[NCT];
+    // YM: bit jy set = some cell of one of this wave's column tiles reads an input row that exists (cy - jy in [0, NIN)).
+    // The first / last tiles of a cell plane lie in the rows cy = 0, 1 / NIN, NIN + 1, where one or two of the three jy taps
+    // read only the zero margin: those MFMAs are skipped (2 of 21 tiles' worth for up2, 1.3 of 7 for up1) -- exact zeros,
+    // so the sums keep their bits and their order, like the plane mask below.  Wave-uniform.
+    int ym = 0;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
       const int tl = split * T::CPW + c * T::NW + wave;          // wave-uniform
       // cell p = 16 tl + j reads plane word (cy - jy + 2) NCELL + cx - jx + 2 = p + 2 NCELL + 2 - jy NCELL - jx
       // (a column slot past the last tile of the plane computes on the last tile's data and stores nothing)
       colbase[c] = kq * CS + 16 * min(tl, NPT - 1) + j + 2 * NCELL + 2;
+      const int tt = min(tl, NPT - 1), cy_lo = (16 * tt) / NCELL, cy_hi = min(16 * tt + 15, NCELL * NCELL - 1) / NCELL;
+#pragma unroll
+      for (int jy = 0; jy < 3; ++jy)
+        if (cy_hi - jy >= 0 && cy_lo - jy <= NIN - 1) ym |= 1 << jy;
     }
+    ym = __builtin_amdgcn_readfirstlane(ym);
     // MASK: bit jz set = input plane cz - jz exists.  A skipped block would have added exact zeros, so the sums are the
     // same bits as the unmasked loop's; the order of the remaining terms is unchanged
     auto mfma_phase = [&](auto maskc) {
@@ -211,7 +221,8 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
         const float* xg = xs + g * 4 * CS;
         const float* ag = as + g * kAPerGroup * 64 + lane;
 #pragma unroll
-        for (int jy = 0; jy < 3; ++jy)
+        for (int jy = 0; jy < 3; ++jy) {
+          if (!((ym >> jy) & 1)) continue;                     // (scalar branch around 9 - 27 MFMAs)
 #pragma unroll
           for (int jx = 0; jx < 3; ++jx)
 #pragma unroll
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
                       acc[c][ez][ey] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ez][ey], bv, acc[c][ez][ey], 0, 0, 0);
               }
             }
+        }
       }
     };
     {
