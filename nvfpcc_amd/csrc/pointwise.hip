@@ -1220,8 +1220,11 @@ struct StemRawW {
   __device__ __forceinline__ float e(int b, int i, int sp) const { return emb[((size_t)idx[b] * ch + i) * 8 + sp]; }
 };
 
+// (launch bounds ask for four waves per SIMD = two workgroups per CU: the stem's body wants 131 registers, three more than
+// let a second 8-wave workgroup in -- the head's ~2000 short workgroups then queued behind 256 slots instead of 512, 65 of
+// them held by the stem: 20.0 us for the launch against 15.2 with 128 registers and three spilled values)
 template <int C0, int C1, int COG>
-__global__ __launch_bounds__(C0 * 64) void step_head_stem_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q,
+__global__ __launch_bounds__(C0 * 64, 4) void step_head_stem_kernel(const NvfLayerDesc* __restrict__ table, int nlayers, int q,
                                                                  uint64_t seed, uint64_t step,
                                                                  const uint64_t* __restrict__ step_dev, PackJobs pk,
                                                                  GatherMulti g, const int64_t* __restrict__ idx, int rows,
