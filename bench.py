@@ -286,9 +286,10 @@ def measure_traffic(args, label):
 
 
 def measure_in_step_us(args, labels):
-    """Duration of the launches behind `labels` AS THE STEP ISSUES THEM (the five-gradient launch with its bias-sum
-    workgroups, coefficient copy and the queued latent tail): one child run of this script -- host-launched steps, a marker
-    dispatch in front of each probed launch -- under `rocprofv3 --kernel-trace` (no counters: kernels are not serialised
+    """Duration of the launches behind `labels` AS THE STEP ISSUES THEM (the five-gradient launch with the stem's backward,
+    its bias-sum workgroups, coefficient copy and the queued latent tail): one child run of this script -- the step graphs
+    replayed as in the timed region, a marker dispatch captured in front of each probed launch (host-launched steps with
+    --no-graph) -- under `rocprofv3 --kernel-trace` (no counters: kernels are not serialised
     beyond the stream's own order); per label the median End - Start of the dispatch that follows its marker.
     Returns ({label: us}, {label: kernel name}, note)."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -297,9 +298,9 @@ def measure_in_step_us(args, labels):
     base = tempfile.mkdtemp(prefix="nvf_trace_", dir="/tmp")
     cmd = [rocprof, "--kernel-trace", "-d", base, "-o", "kt", "--output-format", "csv", "--",
            "python3", os.path.abspath(__file__), "--pmc-child", "--pmc-mark", ",".join(labels), "--no-cpu-baseline",
-           "--no-pmc", "--no-graph", "--no-sweep", "--no-epoch", "--steps", "12", "--warmup", "3", "--repeats", "1",
+           "--no-pmc", "--no-sweep", "--no-epoch", "--steps", "48", "--warmup", "4", "--repeats", "1",
            "--batch", str(args.batch), "--blocks", str(args.blocks), "--distinct", str(args.distinct), "--ch", str(args.ch),
-           "--chanstr", args.chanstr, "--q", str(args.q)]
+           "--chanstr", args.chanstr, "--q", str(args.q)] + (["--no-graph"] if args.no_graph else [])
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=240)
@@ -323,8 +324,9 @@ def measure_in_step_us(args, labels):
                 names[lab] = row["Kernel_Name"]
     shutil.rmtree(base, ignore_errors=True)
     return ({lab: statistics.median(v) for lab, v in per.items() if v}, names,
-            "in-step: rocprofv3 --kernel-trace child pass of this command (host-launched steps), median duration of the "
-            "dispatch behind a marker dispatch")
+            "in-step: rocprofv3 --kernel-trace child pass of this command (%s), median duration of the dispatch behind a "
+            "marker dispatch" % ("host-launched steps" if args.no_graph else
+                                 "the same unrolled step graphs replayed, marker dispatches captured into them"))
 
 
 def run(args):
@@ -363,6 +365,40 @@ def run(args):
         (args.steps * nreg + args.warmup + 12) * B * world // args.blocks + 2)])
     counts = eng.counts
 
+    probe = KernelProbe()
+    c3 = int(args.chanstr.split(",")[3])
+    # conv2 forward, backward-data (batch <= 64; VALU gather kernel above that) and weight gradient (partial-sum
+    # launch of nvf_wgrad_partial) all run on the matrix cores
+    probe.wrap(ops, "conv3d_k4_mfma", "conv2_fwd",
+               lambda x, wp, b, pad, pair, *a, **kw: pad == 0 and x.shape[-1] == 35 and x.shape[1] == c3)
+    probe.wrap(ops, "conv3d_k4_mfma", "conv2_bwd_data",
+               lambda x, wp, b, pad, pair, *a, **kw: pad == 3 and x.shape[-1] == 32 and x.shape[1] == c3)
+    # ... in the Winograd (y, x) form since round 4 (conv_wino.hip): training-step forward and backward-data
+    probe.wrap(ops, "conv3d_k4_wino_fwd", "conv2_fwd", lambda x, wp, b, *a, **kw: x.shape[-1] == 35)
+    probe.wrap(ops, "conv3d_k4_wino_bwd", "conv2_bwd_data", lambda dy, wp, m, *a, **kw: dy.shape[-1] == 32)
+    probe.wrap(ops, "conv3d_gather", "conv2_fwd",
+               lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
+    probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",
+               lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 35 and x.shape[1] == c3)
+    # wide decoder: 16 output channels are the MFMA rows (conv16_mfma.hip)
+    probe.wrap(ops, "conv3d_g16_mfma", "conv2_fwd",
+               lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 0 and x.shape[-1] == 35)
+    probe.wrap(ops, "conv3d_g16_mfma", "conv2_bwd_data",
+               lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 3 and x.shape[-1] == 32)
+    # ... in the Winograd (y, x) form since round 4 (conv16_wino.hip, wgrad16_wino.hip)
+    probe.wrap(ops, "conv3d_k4_wino16_fwd", "conv2_fwd", lambda x, wp, b, *a, **kw: x.shape[-1] == 35)
+    probe.wrap(ops, "conv3d_k4_wino16_bwd", "conv2_bwd_data", lambda dy, wp, m, *a, **kw: dy.shape[-1] == 32)
+    probe.wrap(ops, "wgrad16_k4_wino_partial", "conv2_bwd_weight", lambda dy, x, slabs, *a, **kw: dy.shape[-1] == 32)
+    probe.wrap(ops.WgradBatch, "add", "conv2_bwd_weight",
+               lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
+    # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
+    probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
+    # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
+    probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs, **kw: True)
+    if args.pmc_child and args.pmc_mark and not args.no_graph:
+        # kernel-trace child pass: the marker dispatches are CAPTURED into the step graphs, so the probed launches are timed
+        # exactly where the headline runs them -- inside replayed graphs
+        probe.mark = args.pmc_mark
     graphed = None
     primed_steps = 0
     if not args.no_graph and args.mode == "step":
@@ -412,36 +448,6 @@ def run(args):
             graphed.replay_all()
             i = e
 
-    probe = KernelProbe()
-    c3 = int(args.chanstr.split(",")[3])
-    # conv2 forward, backward-data (batch <= 64; VALU gather kernel above that) and weight gradient (partial-sum
-    # launch of nvf_wgrad_partial) all run on the matrix cores
-    probe.wrap(ops, "conv3d_k4_mfma", "conv2_fwd",
-               lambda x, wp, b, pad, pair, *a, **kw: pad == 0 and x.shape[-1] == 35 and x.shape[1] == c3)
-    probe.wrap(ops, "conv3d_k4_mfma", "conv2_bwd_data",
-               lambda x, wp, b, pad, pair, *a, **kw: pad == 3 and x.shape[-1] == 32 and x.shape[1] == c3)
-    # ... in the Winograd (y, x) form since round 4 (conv_wino.hip): training-step forward and backward-data
-    probe.wrap(ops, "conv3d_k4_wino_fwd", "conv2_fwd", lambda x, wp, b, *a, **kw: x.shape[-1] == 35)
-    probe.wrap(ops, "conv3d_k4_wino_bwd", "conv2_bwd_data", lambda dy, wp, m, *a, **kw: dy.shape[-1] == 32)
-    probe.wrap(ops, "conv3d_gather", "conv2_fwd",
-               lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 32 and x.shape[1] == c3)
-    probe.wrap(ops, "conv3d_gather", "conv2_bwd_data",
-               lambda x, w, b, cout, k, s, p, osz, *a, **kw: k == 4 and osz[0] == 35 and x.shape[1] == c3)
-    # wide decoder: 16 output channels are the MFMA rows (conv16_mfma.hip)
-    probe.wrap(ops, "conv3d_g16_mfma", "conv2_fwd",
-               lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 0 and x.shape[-1] == 35)
-    probe.wrap(ops, "conv3d_g16_mfma", "conv2_bwd_data",
-               lambda x, wp, b, cout, k, s, pad, osz, *a, **kw: k == 4 and pad == 3 and x.shape[-1] == 32)
-    # ... in the Winograd (y, x) form since round 4 (conv16_wino.hip, wgrad16_wino.hip)
-    probe.wrap(ops, "conv3d_k4_wino16_fwd", "conv2_fwd", lambda x, wp, b, *a, **kw: x.shape[-1] == 35)
-    probe.wrap(ops, "conv3d_k4_wino16_bwd", "conv2_bwd_data", lambda dy, wp, m, *a, **kw: dy.shape[-1] == 32)
-    probe.wrap(ops, "wgrad16_k4_wino_partial", "conv2_bwd_weight", lambda dy, x, slabs, *a, **kw: dy.shape[-1] == 32)
-    probe.wrap(ops.WgradBatch, "add", "conv2_bwd_weight",
-               lambda self_, p_, q_, k, s, pad, *a, **kw: k == 4 and s == 1 and p_.shape[-1] == 32)
-    # narrow decoder: the conv2, up2 and conv1 weight gradients are ONE launch (nvf_wgrad_mfma3_partial)
-    probe.wrap(ops.WgradBatch, "add_mfma3", "wgrad_conv2_up2_conv1", lambda self_, ps, qs, outs: True)
-    # ... and since the five-gradient launch (nvf_wgrad_trunk5_partial) up1's and conv0's ride in it as well
-    probe.wrap(ops.WgradBatch, "add_trunk5", "wgrad_trunk5", lambda self_, ps, qs, outs, **kw: True)
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -474,12 +480,13 @@ def run(args):
                 dt = d
         # kernels inside a replayed graph cannot be bracketed by events: time the dominant kernels on the same stream
         # in the same process right after the timed region, same shapes and operands, launched from the host
-        probe.enabled = not args.pmc_child
-        probe.mark = args.pmc_mark or None
-        for i in range(nxt, nxt + min(args.steps, 10)):
-            step(i, use_graph=False)
-        torch.cuda.synchronize()
-        probe.enabled = False
+        if not (args.pmc_child and graphed is not None):        # (a graph-mode child pass has its markers in the graphs)
+            probe.enabled = not args.pmc_child
+            probe.mark = args.pmc_mark or None
+            for i in range(nxt, nxt + min(args.steps, 10)):
+                step(i, use_graph=False)
+            torch.cuda.synchronize()
+            probe.enabled = False
         loss = eng.loss_value()
     if args.pmc_child:
         return 0
@@ -489,7 +496,7 @@ def run(args):
     # by HIP events on the compute stream (no host synchronisation inside the region); ms / step of the first and the
     # last tenth show whether the clock holds.
     sustained_obj = None
-    if args.mode == "step" and graphed is not None and graphed.graphs_u and args.sustained_s > 0 and region_ms:
+    if args.mode == "step" and graphed is not None and args.sustained_s > 0 and region_ms:
         per_part = max(int(args.sustained_s / 10 / (region_ms[0] * 1e-3)) // 16 * 16, 16)
         per_part = min(per_part, graphed.CAP // 16 * 16)
         srng = np.random.default_rng(77)
@@ -637,6 +644,28 @@ def run(args):
             barrier()
             return timed_max(time.perf_counter() - t1) / n
 
+        # strong scaling of the reference's own optimisation problem: the GLOBAL mini-batch stays at --batch (16) and is split
+        # over the ranks (position j -> rank j mod W); at N = 1 this is the headline itself
+        if world > 1 and graphed is not None and B % world == 0:
+            share = B // world
+            g_s = GraphedTrainStep(eng, share, args.q)
+            if g_s.graphs_u:
+                g_s.prime()
+            nst = max(min(args.steps, 64), 4)
+            o_s = np.concatenate([rng.permutation(args.blocks) for _ in range(nst * B // args.blocks + 2)])[:nst * B]
+            whole_s = o_s.reshape(nst, B).astype(np.int64)
+            npts_s = counts[whole_s].sum(axis=1).astype(np.float64)
+
+            def strong_steps():
+                g_s.load_schedule((whole_s[:, rank::world], npts_s))
+                g_s.replay_all()
+            dts = timed(strong_steps, 3) / nst
+            extra[f"train_step_B{B}_global_strong"] = {
+                "blocks_per_s": round(B / dts, 1), "ms_per_step": round(dts * 1e3, 4), "global_batch": B,
+                "blocks_per_gpu": share, "scaling": "strong (the reference's batch of %d split over the ranks, one all-reduce "
+                                                    "of the decoder gradients per step)" % B,
+                "frac_of_fp32_peak": frac(B / dts, 6.0 * fwd_macs)}
+            del g_s
         b2 = 256
         order2 = np.concatenate([rng.permutation(args.blocks) for _ in range(14 * b2 * world // args.blocks + 2)])
         it = [0]

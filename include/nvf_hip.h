@@ -673,7 +673,7 @@ int nvf_step_head(const void* table_dev, int nlayers, int q, uint64_t seed, uint
                   const NvfRateJob* rate /* may be NULL: see nvf_weight_rate_batch_final */, void* stream);
 
 /* nvf_step_head AND nvf_stem_latent_fwd (latent generator + quantiser + up0 / IGDN / conv0 of the mini-batch) in ONE
- * launch, narrow decoder (c0 = 8, c1 = 16, ch <= 8, rows <= 32): the stem's workgroups derive their effective weights
+ * launch, (c0, c1) = (8, 16) or (16, 32), ch <= 8, rows <= 32: the stem's workgroups derive their effective weights
  * from the raw parameters of layer-table rows lat_row / up0_row / conv0_row themselves (network.py:611-620, 735-740:
  * the arithmetic of nvf_prepare_weights, element by element) and fetch their latents as emb[idx[b]], so nothing in the
  * launch waits for anything else.  Same results as the two calls, bit for bit.  block ids of the latent noise = idx. */

@@ -1201,7 +1201,7 @@ struct StemRawW {
     // raw [ci = C0][co = C1][125]: per input channel the run of this part's NCG * COG output channels (a multiple of 4
     // elements long and starting at one: 125 * COG * k with COG = 4)
     constexpr int NCG = C0 / 8, RUN = NCG * COG * 125;
-    static_assert(RUN % 4 == 0 && (COG * 125) % 4 == 0, "16-byte pieces");
+    static_assert(RUN % 4 == 0 && (C1 * 125) % 4 == 0, "16-byte pieces: runs start and end on multiples of four elements");
     for (int t = tid; t < C0 * (RUN / 4); t += NT) {
       const int ci = t / (RUN / 4), r0 = 4 * (t - ci * (RUN / 4));
       float w[4];
@@ -1279,7 +1279,8 @@ extern "C" int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uin
                                   void* stream) {
   if (!table_dev || nlayers <= 0 || !idx || npack < 0 || !stem) return NVF_EINVAL;
   const NvfStemHead sj = *stem;
-  if (sj.c0 != 8 || sj.c1 != 16 || sj.ch <= 0 || sj.ch > kStemFwdMaxCh || rows <= 0 || rows > 32) return NVF_EINVAL;
+  const bool narrow = sj.c0 == 8 && sj.c1 == 16, wide = sj.c0 == 16 && sj.c1 == 32;
+  if (!(narrow || wide) || sj.ch <= 0 || sj.ch > kStemFwdMaxCh || rows <= 0 || rows > 32) return NVF_EINVAL;
   if (sj.lat_row < 0 || sj.lat_row >= nlayers || sj.up0_row < 0 || sj.up0_row >= nlayers || sj.conv0_row < 0 ||
       sj.conv0_row >= nlayers || (sj.mode != 0 && sj.mode != 1))
     return NVF_EINVAL;
@@ -1300,8 +1301,10 @@ extern "C" int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uin
   long wg = 0;
   const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
   if (rc != NVF_OK) return rc;
-  wg = (wg + 1) / 2;                   // 512-thread workgroups: half as many as nvf_step_head's for the same threads
-  const int wpl = 32;
+  // 512-thread (wide decoder: 1024-thread) workgroups: a half (quarter) as many as nvf_step_head's for the same threads
+  const int tscale = narrow ? 2 : 4;
+  wg = (wg + tscale - 1) / tscale;
+  const int wpl = narrow ? 32 : 32;    // (nvf_step_head: 64 of 256 threads; 128 for the wide decoder's kernels)
   RateInHead rate{};
   if (rate_job) {
     if (!rate_job->sigma || !rate_job->mu || !rate_job->part) return NVF_EINVAL;
@@ -1310,10 +1313,14 @@ extern "C" int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uin
     rate.sigma = rate_job->sigma; rate.mu = rate_job->mu; rate.part = rate_job->part; rate.g = rate_job->g;
     rate.nwg = rate.b.first_wg[rate.b.nlayers];
   }
-  constexpr int COG = 4, PARTS = 16 / COG;
-  const unsigned grid = 1 + rows * PARTS + rate.nwg + wpl * nlayers + wpl * npack + (unsigned)(wg * n);
-  step_head_stem_kernel<8, 16, COG><<<grid, 512, 0, nvf_stream(stream)>>>(
-      (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl, rate, sj);
+  const int parts = narrow ? 16 / 4 : 32 / (2 * 2);          // conv0 channel parts per block (COG 4; wide: 2 x 2 groups)
+  const unsigned grid = 1 + rows * parts + rate.nwg + wpl * nlayers + wpl * npack + (unsigned)(wg * n);
+  if (narrow)
+    step_head_stem_kernel<8, 16, 4><<<grid, 512, 0, nvf_stream(stream)>>>(
+        (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl, rate, sj);
+  else
+    step_head_stem_kernel<16, 32, 2><<<grid, 1024, 0, nvf_stream(stream)>>>(
+        (const NvfLayerDesc*)table_dev, nlayers, q, seed, step, step_dev, pk, g, idx, rows, (int)wg, wpl, rate, sj);
   NVF_LAUNCH_CHECK();
   return NVF_OK;
 }

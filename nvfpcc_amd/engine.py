@@ -335,17 +335,18 @@ class TrainEngine:
                 (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_int * n)(*[s[0].numel() for s in srcs]), n,
                 idx_dev.data_ptr(), rows, ctypes.byref(self._rate_job()[0]) if with_rate else None)
         self._stem_pre = None
-        if (stem_mode is not None and _STEM_IN_HEAD and self.narrow and self.fused_stem and self.fused_latent_stem
+        if (stem_mode is not None and _STEM_IN_HEAD and (self.narrow or self.wide) and self.fused_stem and self.fused_latent_stem
                 and self.ch <= 8 and rows <= 32 and _NAIVE_OFF()):
             # ... and the stem's forward of this mini-batch (forward() picks the tensors up instead of launching it)
             from ._lib import NvfStemHead
             net = self.net
             g2, ec, ig = net.latent_gen.gdn_2, net.entropy_coder, net.reconstructor.activation
             dev, ch = self.dev, self.ch
+            c0, c1 = self.channels[0], self.channels[1]
             o = {"h": torch.empty(rows, ch, 2, 2, 2, device=dev), "lat": torch.empty(rows, ch, 2, 2, 2, device=dev),
                  "x0": torch.empty(rows, ch, 2, 2, 2, device=dev), "lbits": torch.empty(1, device=dev),
-                 "a0": torch.empty(rows, 8, 4, 4, 4, device=dev), "h0": torch.empty(rows, 8, 4, 4, 4, device=dev),
-                 "y1": torch.empty(rows, 16, 8, 8, 8, device=dev)}
+                 "a0": torch.empty(rows, c0, 4, 4, 4, device=dev), "h0": torch.empty(rows, c0, 4, 4, 4, device=dev),
+                 "y1": torch.empty(rows, c1, 8, 8, 8, device=dev)}
             sj = NvfStemHead()
             sj.emb, sj.lat_beta_hat, sj.lat_gamma_hat = self.emb.data_ptr(), g2.beta.data_ptr(), g2.gamma.data_ptr()
             sj.sigma, sj.mu = ec.sigma.data_ptr(), ec.mu.data_ptr()
@@ -353,7 +354,7 @@ class TrainEngine:
             sj.h, sj.lat, sj.x_rounded, sj.bits = (o[k].data_ptr() for k in ("h", "lat", "x0", "lbits"))
             sj.a0, sj.h0, sj.y1 = (o[k].data_ptr() for k in ("a0", "h0", "y1"))
             sj.lat_row, sj.up0_row, sj.conv0_row = self._rows["latent"], self._rows["up0"], self._rows["conv0"]
-            sj.mode, sj.ch, sj.c0, sj.c1 = (0 if stem_mode == "train" else 1), ch, 8, 16
+            sj.mode, sj.ch, sj.c0, sj.c1 = (0 if stem_mode == "train" else 1), ch, c0, c1
             check(lib().nvf_step_head_stem(*args, ctypes.byref(sj), torch.cuda.current_stream().cuda_stream),
                   "nvf_step_head_stem")
             self._stem_pre = (idx_dev.data_ptr(), stem_mode, o)

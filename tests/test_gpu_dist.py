@@ -17,15 +17,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(world, out, n, batch, epochs, extra_env=None):
+def launch(world, out, n, batch, epochs, extra_env=None, backend="gloo"):
+    """One child process per rank (the parent never joins the group).  backend "gloo": every rank on GPU 0, the host
+    side reduces; "nccl" = RCCL, rank r on GPU r.  A rank that hangs (a collective that never completes) is killed by the
+    watchdog below -- a child process, never a re-exec of a process that touched the GPU -- and the test fails."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
         env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NVF_DIST_BACKEND="gloo", NVF_DEVICE_OVERRIDE="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NVF_DIST_BACKEND=backend,
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if backend == "gloo":
+            env["NVF_DEVICE_OVERRIDE"] = "0"
+        else:
+            env.pop("NVF_DEVICE_OVERRIDE", None)
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, WORKER, out, str(n), str(batch), str(epochs)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -76,6 +83,31 @@ def test_two_ranks_through_a_real_collective_equal_one_rank(tmp_path):
     assert (two["stats"][:, 7] == 3).all() and (two["stats"][:, 5:7] == 0).all()
 
 
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("collective", ["host", "graph"])
+def test_two_ranks_rccl(tmp_path, collective):
+    """BASELINE.json configs[3] on real hardware, the moment a box has two devices: two ranks over RCCL (backend "nccl",
+    rank r on GPU r, the production engine and EpochDriver) against the one-rank run -- with the all-reduce launched from
+    the host behind the step graph ("host", the default) and captured as a node of the step graph
+    (NVF_GRAPH_COLLECTIVE=graph: 4-step and 1-step graphs replayed with peers).  Skips itself on one-GPU boxes: nothing in
+    this repo has run RCCL with more than one rank yet (SCALE_r01-r04 were skipped), and this is the test that will."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (RCCL refuses two ranks on one)")
+    N, B, E = 17, 8, 2
+    one = launch(1, str(tmp_path / "w1.pt"), N, B, E)
+    two = launch(2, str(tmp_path / "w2.pt"), N, B, E, backend="nccl", extra_env={"NVF_GRAPH_COLLECTIVE": collective})
+    assert two["world"] == 2 and two["graphs"] == [(4, 1), (4, 2)]
+    assert one["noise_step"] == two["noise_step"] == E * 4 and one["opt_step"] == two["opt_step"] == E * 3
+    for g1, g2 in zip(one["grads"], two["grads"]):
+        assert (g1 - g2).abs().max().item() < 2e-5 * g1.abs().max().item()
+    dp = (one["flat_p"] - two["flat_p"]).abs()
+    de = (one["emb"] - two["emb"]).abs()
+    assert (dp > 1e-6).float().mean().item() < 1e-3 and dp.max().item() < 6 * 2e-3, (dp.max().item(), (dp > 1e-6).sum())
+    assert de.max().item() < 1e-5, de.max().item()
+    np.testing.assert_allclose(one["stats"][:, 0:5], two["stats"][:, 0:5], rtol=2e-4)
+    assert (two["stats"][:, 7] == 3).all() and (two["stats"][:, 5:7] == 0).all()
+
+
 @pytest.mark.timeout(600)
 def test_bench_gpus_2_launches_two_ranks_and_reports_the_live_world_size(tmp_path):
     """`python bench.py --gpus 2` with no torchrun environment: the script starts its two ranks itself (here over gloo,
@@ -90,7 +122,7 @@ def test_bench_gpus_2_launches_two_ranks_and_reports_the_live_world_size(tmp_pat
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
                         "--epochs", "1", "--blocks", "61", "--distinct", "61", "--no-pmc", "--no-cpu-baseline",
-                        "--sweep-blocks", "300"],
+                        "--sweep-blocks", "300", "--sustained-s", "0.2"],
                        env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -105,6 +137,10 @@ def test_bench_gpus_2_launches_two_ranks_and_reports_the_live_world_size(tmp_pat
     # batch 256 per GPU (weak), the full-batch latent step and a big latent step + eval sharded over the ranks (strong)
     sw = d["sweep"]
     assert sw["train_step_B256_per_gpu"]["global_batch"] == 512 and sw["train_step_B256_per_gpu"]["blocks_per_s"] > 0
+    # ... and the strong-scaling line: the reference's own mini-batch of 16 split over the two ranks
+    st = sw["train_step_B16_global_strong"]
+    assert st["global_batch"] == 16 and st["blocks_per_gpu"] == 8 and st["blocks_per_s"] > 0
+    assert "direct_form" in d and d["direct_form"]["blocks_per_s"] > 0 and d["sustained"]["steps"] > 0
     assert sw["latent_step_N61"]["blocks_per_s"] > 0
     assert sw["latent_step_N300"]["blocks_per_gpu"] == 150 and sw["eval_forward_N300"]["blocks_per_s"] > 0
     assert all(0 < v["frac_of_fp32_peak"] < 1 for v in sw.values())

@@ -811,18 +811,18 @@ def test_stem_backward_inside_the_five_gradient_launch(gpu, monkeypatch, batch):
 
 
 @pytest.mark.parametrize("q", [1, 2])
-@pytest.mark.parametrize("batch", [16, 5])
-def test_stem_forward_inside_the_step_head_launch(gpu, monkeypatch, batch, q):
+@pytest.mark.parametrize("tag,batch", [("S", 16), ("S", 5), ("W", 16), ("W", 3)])
+def test_stem_forward_inside_the_step_head_launch(gpu, monkeypatch, tag, batch, q):
     """Round 5: the step head (effective weights, MFMA packings, row gather, weight-rate partials) and the stem's forward
     (latent generator + quantiser + up0 / IGDN / conv0) are ONE launch (nvf_step_head_stem): the stem's workgroups derive
     their weights from the raw parameters with the arithmetic of the weight preparation and fetch their latents through
     the index vector, so they wait for nothing.  Against the two-launch form: every saved activation, the latent bits, the
-    loss and every gradient are the same BITS (q = 1: the same counter-RNG draws)."""
+    loss and every gradient are the same BITS (q = 1: the same counter-RNG draws).  Both decoders of BASELINE.json."""
     from nvfpcc_amd import engine as E
     got = {}
     for merged in (True, False):
         monkeypatch.setattr(E, "_STEM_IN_HEAD", merged)
-        net, eng, gt, dist, emb = make("S", gpu, nblk=40)
+        net, eng, gt, dist, emb = make(tag, gpu, nblk=40)
         ids = np.random.default_rng(7).permutation(40)[:batch]
         a = eng.train_step(ids, q, update=False)
         torch.cuda.synchronize()
