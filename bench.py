@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each (value = the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes for roofline.traffic")
+    ap.add_argument("--prime-rounds", type=int, default=1, help="passes over the captured graphs before the warm-up steps")
     ap.add_argument("--no-direct", action="store_true", help="skip the `direct_form` object (the same region with TrainEngine(winograd=False))")
     ap.add_argument("--sustained-s", type=float, default=5.5, help="length of the `sustained` region in seconds (0: skip)")
     ap.add_argument("--no-sweep", action="store_true",
@@ -402,9 +403,17 @@ def run(args):
     graphed = None
     primed_steps = 0
     if not args.no_graph and args.mode == "step":
-        graphed = GraphedTrainStep(eng, B, args.q)
-        graphed.prime()      # setup, like the capture itself: every graph launched once before the W warm-up steps
-        primed_steps = sum(u for u in graphed.unrolls if u in graphed.graphs_u) + 1      # real optimiser steps
+        # Steps per replayed graph: the engine's 16 / 8 / 4 / 2 -- and K itself when the timed region is short (K <= 64) and
+        # not a multiple of 16: switching from one graph to a DIFFERENT one costs ~40 us of idle GPU on this stack
+        # (tools/region_overhead.py: a 4-step + a 16-step graph = 20 steps + 70 us, one graph + 24 us), which a 20-step
+        # region would carry as 2 us per step; NVFPCC.py train replays the same 16-step graph 57 times per epoch.
+        unroll = None
+        if args.steps <= 64 and args.steps % 16 != 0 and args.steps > 1:
+            unroll = tuple(sorted(set(GraphedTrainStep.UNROLL) | {args.steps}, reverse=True))
+        graphed = GraphedTrainStep(eng, B, args.q, unroll=unroll)
+        # setup, like the capture itself: every graph launched before the W warm-up steps (real optimiser steps, reported
+        # as config.primed_steps).  --prime-rounds > 1 keeps the GPU busy for that many passes over the graphs first.
+        primed_steps = graphed.prime(args.prime_rounds)
 
     def shares(i):
         ids, whole = nd.shard_minibatch(order, i, B * world, rank, world)

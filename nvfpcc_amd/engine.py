@@ -1249,15 +1249,20 @@ class GraphedTrainStep:
             eng.last["n_pts"] = n_pts
         return self.out
 
-    def prime(self):
-        """Replay every captured graph once (real training steps on block ids 0..): the first launch of a graph pays a
-        one-off upload that a measurement should not hold.  For benchmarks; training does not need it."""
+    def prime(self, rounds=1):
+        """Replay every captured graph `rounds` times (real training steps on block ids 0..): the first launch of a graph
+        pays a one-off upload that a measurement should not hold.  For benchmarks; training does not need it.  Returns the
+        number of optimiser steps run."""
         B, N = self.batch, self.eng.N_leaf
         sizes = [u for u in self.unrolls if u in self.graphs_u] + [1]
-        for u in sizes:
-            self.load_schedule([((np.arange(B) + k * B) % N, None) for k in range(u)])
-            self.replay_all()
+        n = 0
+        for _ in range(max(int(rounds), 1)):
+            for u in sizes:
+                self.load_schedule([((np.arange(B) + k * B) % N, None) for k in range(u)])
+                self.replay_all()
+                n += u
         torch.cuda.synchronize()
+        return n
 
     def __call__(self, idx_host, n_pts=None):
         """One step with its own one-row schedule (tests; the training loop loads an epoch at a time)."""
