@@ -1,3 +1,2 @@
-for r in 1 1 1; do
-  timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-sweep --no-cpu-baseline --no-pmc --no-epoch --no-direct --sustained-s 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('K20', d['value'], d['repeats']['ms_per_step'], d['config']['primed_steps'], d['config']['launch'][:60])"
-done
+run() { timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-sweep --no-cpu-baseline --no-pmc --no-epoch --no-direct --sustained-s 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['repeats']['ms_per_step'])"; }
+run base; HSA_ENABLE_INTERRUPT=0 run nointr; run base; HSA_ENABLE_INTERRUPT=0 run nointr
