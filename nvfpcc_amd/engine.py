@@ -1182,8 +1182,10 @@ class GraphedTrainStep:
         host[:nw] = rows[0]                       # the step buffer starts as row 0 ...
         host[nw], host[nw + 1] = 1, 0             # ... and the cursor at 1: the tail of the first step fetches row 1
         self.pin_gen[slot] += 1                   # a handle owns its slot only until the slot is staged again
-        return {"_staged": True, "slot": slot, "gen": self.pin_gen[slot], "n": n, "npts": npts.tolist(),
-                "words": nw + 2 + (n + 1) * nw, "state": (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1)}
+        m = nw + 2 + (n + 1) * nw
+        return {"_staged": True, "slot": slot, "gen": self.pin_gen[slot], "n": n, "npts": npts.tolist(), "words": m,
+                "src": self.pins[slot][:m], "dst": self.sched[:m],          # (sliced here, not inside a timed region)
+                "state": (eng.noise_step, eng.opt_step, eng.lr, eng.lmbda, eng.w1)}
 
     def load_schedule(self, steps):
         """steps: [(block ids of this rank [batch], n_pts of the whole mini-batch or None)] in replay order (at most
@@ -1201,7 +1203,7 @@ class GraphedTrainStep:
             raise ValueError("load_schedule: stale handle -- its staging slot has been filled again since (ring=%d)"
                              % len(self.pins))
         self.pending.extend(h["npts"])
-        self.sched[:m].copy_(self.pins[slot][:m], non_blocking=True)
+        h["dst"].copy_(h["src"], non_blocking=True)
         ev = self.pin_events[slot]
         if ev is None:
             ev = self.pin_events[slot] = torch.cuda.Event()

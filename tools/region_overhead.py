@@ -10,7 +10,7 @@ args = bench.parse_args() if hasattr(bench, "parse_args") else None
 args.blocks, args.distinct = 917, 128
 dev = torch.device("cuda")
 eng = bench.build_engine(args, dev, 1)
-g = GraphedTrainStep(eng, 16, 1, unroll=(16, 8, 4, 2))
+g = GraphedTrainStep(eng, 16, 1, unroll=(20, 16, 8, 4, 2))
 g.prime(4)
 rng = np.random.default_rng(0)
 
@@ -43,6 +43,9 @@ def region(sizes, reps=7):
 
 step = (region([16] * 8)[0] - region([16] * 4)[0]) / 64
 print(f"steady step {step:.2f} us")
-for sizes in ([1], [2], [4], [16], [4, 16], [2, 2, 16], [1, 1, 2, 16], [1, 2, 1, 16], [1, 4, 16]):
+region([1, 4], reps=1)
+tot, tl, tr = region([20], reps=1)
+print(f"[20] right after [1, 4] (the bench's first region): + {tot - 20 * step:6.1f} us fixed")
+for sizes in ([1], [4], [16], [20], [20], [4, 16], [2, 2, 16]):
     tot, tl, tr = region(sizes)
     print(f"{str(sizes):18s} total {tot:8.1f} us = {sum(sizes)} steps + {tot - sum(sizes) * step:6.1f} us fixed   (host: load_schedule {tl:5.1f}, replays {tr:6.1f})")
