@@ -46,6 +46,6 @@ print(f"steady step {step:.2f} us")
 region([1, 4], reps=1)
 tot, tl, tr = region([20], reps=1)
 print(f"[20] right after [1, 4] (the bench's first region): + {tot - 20 * step:6.1f} us fixed")
-for sizes in ([1], [4], [16], [20], [20], [4, 16], [2, 2, 16]):
+for sizes in ([20], [4] * 5, [2] * 10, [20], [4] * 5, [2] * 10, [1] * 20):
     tot, tl, tr = region(sizes)
     print(f"{str(sizes):18s} total {tot:8.1f} us = {sum(sizes)} steps + {tot - sum(sizes) * step:6.1f} us fixed   (host: load_schedule {tl:5.1f}, replays {tr:6.1f})")
