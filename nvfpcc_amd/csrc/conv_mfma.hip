@@ -451,14 +451,14 @@ __global__ __launch_bounds__(C::NW * 64) void conv_k4_mfma(const float* __restri
   }
 }
 
+// (an immutable per-device constant, initialised once and thread-safely: the only process-wide value the library keeps)
 static int nvf_cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+  static const int n = [] {
+    int dev = 0, cus = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    return cus > 0 ? cus : 256;
+  }();
   return n;
 }
 
