@@ -605,7 +605,9 @@ def test_engine_reproduces_the_reference_training_trajectory(use_graph, gpu, gol
         # training step run in the Winograd form, and one of the 336 entries does exactly that in epoch 0.  Allowed: 1 % of
         # the entries, by at most 2 lr_emb per latent step so far)
         outliers = emb_err > 5e-4
-        assert np.median(emb_err) <= 2e-5 and outliers.mean() <= 0.01 and emb_err.max() <= 2 * 5e-3 * (epoch + 1) + 1e-6, (
+        print(f"epoch {epoch}: {int(outliers.sum())} of {emb_err.size} latent entries beyond the strict 5e-4 (allowed: 3)")
+        # (the strict bound for all but a fixed, explicit count of entries -- 3 of 336; measured: 1 in epoch 0)
+        assert np.median(emb_err) <= 2e-5 and int(outliers.sum()) <= 3 and emb_err.max() <= 2 * 5e-3 * (epoch + 1) + 1e-6, (
             np.sort(emb_err)[-5:], (emb_err > 2e-5).sum())
         errs = []
         for key in [k for k in G.files if k.startswith(f"epoch{epoch}/param/")]:
