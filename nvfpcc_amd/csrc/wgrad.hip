@@ -796,6 +796,19 @@ struct WgMfma3 {                 // jobs 0-2: conv2, up2, conv1; job 3 (n[3] may
 using WgUp1 = TWCfg<2, 2, 8, 2>;
 constexpr int wg_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
+#ifdef NVF_WG_STAMP
+// tuning builds (tools/wg_timeline.py): start / end of every workgroup of the five-gradient launch on the 100 MHz clock
+__device__ unsigned long long g_wg_stamps[2 * 4096];
+struct WgStamp {
+  int b;
+  __device__ explicit WgStamp(int b_) : b(b_) { if (threadIdx.x == 0 && b < 4096) g_wg_stamps[2 * b] = __builtin_amdgcn_s_memrealtime(); }
+  __device__ ~WgStamp() { if (threadIdx.x == 0 && b < 4096) g_wg_stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime(); }
+};
+extern "C" int nvf_debug_wg_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * (size_t)(n < 8192 ? n : 8192));
+}
+#endif
+
 // floats of LDS the latent tail needs when the stem's backward rides in the same launch: + its copy of dx0
 constexpr int kTailStemLds = kTailLds + kStemCoopMaxBatch * kStemMaxCh * 8;
 
@@ -815,6 +828,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
 #define NVF_WG_SKIP 0                  // tuning builds: bit j set = job j does nothing (results are then meaningless)
 #endif
   int bid = blockIdx.x;
+#ifdef NVF_WG_STAMP
+  WgStamp stamp_(blockIdx.x);
+#endif
   if (STEM) {
     // the stem's backward (stem_bwd.h): conv0's backward-data partials over (block, channel pair) workgroups, then one
     // workgroup per block for IGDN / up0 -- producers first (lowest ids), each stage signals the next through arrival
@@ -1020,6 +1036,11 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
       return NVF_EINVAL;
     ctx->stem_pending = ctx->tail_pending = 0;
     const int nstem = ctx->stem.batch * 8 + ctx->stem.nwg;
+#ifdef NVF_WG_STAMP
+    fprintf(stderr, "[wg_stamp] grid %d: stem_dh %d stem %d tail 1 conv2 %d up2 %d conv1 %d up1 %d tiles %d %d heads %d sums %d\n",
+            nstem + 1 + grid, ctx->stem.batch * 8, ctx->stem.nwg, m.n[0], m.n[1], m.n[2], m.n[3], u.nx[0] * u.ny[0],
+            u.nx[1] * u.ny[1], hw.n[0] + hw.n[1] + hw.n[2], sd.total_channels * sd.nchunk);
+#endif
     wgrad_mfma3_kernel<C0, T1, C2, U0, U1, true, true><<<nstem + 1 + grid, 256, 0, nvf_stream(stream)>>>(
         m, u, ctx->tail, hw, sd, spart, csrc, clive, ctx->stem);
   } else if (nvf_ctx_ok(ctx) && ctx->tail_pending) {
