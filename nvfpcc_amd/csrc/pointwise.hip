@@ -1304,7 +1304,7 @@ extern "C" int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uin
   // 512-thread (wide decoder: 1024-thread) workgroups: a half (quarter) as many as nvf_step_head's for the same threads
   const int tscale = narrow ? 2 : 4;
   wg = (wg + tscale - 1) / tscale;
-  const int wpl = narrow ? 32 : 32;    // (nvf_step_head: 64 of 256 threads; 128 for the wide decoder's kernels)
+  const int wpl = 32;                  // (nvf_step_head: 64 workgroups of 256 threads per layer; 128 for the wide decoder's kernels)
   RateInHead rate{};
   if (rate_job) {
     if (!rate_job->sigma || !rate_job->mu || !rate_job->part) return NVF_EINVAL;
