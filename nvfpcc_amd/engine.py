@@ -376,9 +376,10 @@ class TrainEngine:
         if L.wp_t16 is not None:
             return ops.convT3d_k5s2_mfma16(x, L.wp_t16, L.b_eff, act, cout=L.cout, pad=L.pad)
         if L.wp_t is not None:
-            # batch <= 64: eight waves with one column tile each (variant 5: two waves per SIMD; up1 19.3 -> 15.6 us, up2
-            # 34.0 -> 30.7 at batch 16; every variant runs the same per-output fmaf chain: bit-identical)
-            var = _VAR["UP1F" if L.cin == 16 else "UP2F"] or (5 if x.shape[0] <= 64 else None)
+            # eight waves with one column tile each (variant 5: two waves per SIMD; up1 19.3 -> 15.6 us, up2 34.0 -> 30.7 at
+            # batch 16 -- and at batch 917 (the full-batch latent step; r05 sweep): up2 1115 -> 916 us, up1 389 -> 310;
+            # every variant runs the same per-output fmaf chain: bit-identical)
+            var = _VAR["UP1F" if L.cin == 16 else "UP2F"] or 5
             return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act, variant=var)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
@@ -391,9 +392,10 @@ class TrainEngine:
             osz = tuple(s - 3 for s in x.shape[2:])
             return ops.conv3d_g16_mfma(x, L.wp_gf, L.b_eff, L.cout, 4, 1, 0, osz, act)
         if L.wp_f is not None:
-            # conv1 at large batch: four planes per wave (variant 2: 124 vs 141 us at batch 256).  Every variant runs
+            # conv1 at large batch: 8 rows x 4 planes on eight waves (variant 5: 34.2 vs 39.4 us at batch 64, 107 vs 120
+            # (variant 2) at 256, 402 vs 443 at 917; at batch 16 the default tile: 12.7 vs 17.6).  Every variant runs
             # the same per-output fmaf chain, so the bits -- and encode-at-any-batch == decode-at-batch-1 -- do not change
-            var = 2 if (x.shape[-1] == 19 and x.shape[0] > 64) else None
+            var = 5 if (x.shape[-1] == 19 and x.shape[0] >= 64) else None
             if x.shape[-1] == 35 and _CONV2_FWD_VAR:
                 var = _CONV2_FWD_VAR
             if x.shape[-1] == 19 and _VAR["C1F"] and x.shape[0] <= 64:
@@ -540,10 +542,11 @@ class TrainEngine:
             return ops.conv3d_g16_mfma(g_out, L.wp_gb, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                        mask=mask)
         if L.wp_s is not None:
-            # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256)
-            # up2 at batch <= 64: 8 rows x 2 planes on eight waves (variant 6: 25.3 -> 22.8 us at batch 16; bit-identical)
+            # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256; 173 vs 184 at 917)
+            # up2 at batch <= 64: 8 rows x 2 planes on eight waves (variant 6: 25.3 -> 22.8 us at batch 16; bit-identical);
+            # above: 4 rows x 4 planes on eight waves (variant 5: 1027 vs 1149 us at batch 917)
             var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else (
-                _VAR["UP1B" if L.cin == 16 else "UP2B"] or (6 if (L.cin == 8 and g_out.shape[0] <= 64) else None))
+                _VAR["UP1B" if L.cin == 16 else "UP2B"] or ((6 if g_out.shape[0] <= 64 else 5) if L.cin == 8 else None))
             return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask, variant=var)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)
