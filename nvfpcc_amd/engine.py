@@ -37,6 +37,17 @@ _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forwa
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
 # (conv1's training FORWARD in that form: measured slower at batch 16 -- 19.1 us two-set / 16.7 us one-set kernel against
 # 12.2 us for the direct kernel, r05 A/B -- 16^3 outputs do not amortise the transforms; not wired)
+_WINO1 = 1 << 16                                         # ppc bit: the one-accumulator-set kernels (conv_wino1.hip)
+
+
+def _wino_bwd_ppc(g_out):
+    """Plane pairs per work unit of the Winograd backward-data at a full batch (0: the kernel's batch-16 default).  Every
+    choice gives the same bits; batch 917: conv2 2182 -> 1975 us with 9, conv1 569 -> 466 us with 5 (tools/wino_ppc_sweep.py)."""
+    if g_out.shape[0] <= 64:
+        return 0
+    return _WINO1 | (9 if g_out.shape[-1] == 32 else 5)
+
+
 _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
 # ... bias sums of the layer below from its backward-data epilogue: measured neutral (the reduction launch 48.9 -> 44.0 us
 # without its 51 MB of re-reads, the two epilogues + 2.7 / + 2.1 us): off by default
@@ -387,7 +398,9 @@ class TrainEngine:
         if train and L.wp_wf is not None and act == R:
             if self.wide:
                 return ops.conv3d_k4_wino16_fwd(x, L.wp_wf, L.b_eff)
-            return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff)
+            # (a full-batch launch has workgroups to spare: more plane pairs per work unit repeat fewer plane transforms --
+            # conv2 at batch 917: 1667 -> 1481 us with 8 pairs per unit; the same bits, tools/wino_ppc_sweep.py)
+            return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff, ppc=(_WINO1 | 8) if x.shape[0] > 64 else 0)
         if L.wp_gf is not None:
             osz = tuple(s - 3 for s in x.shape[2:])
             return ops.conv3d_g16_mfma(x, L.wp_gf, L.b_eff, L.cout, 4, 1, 0, osz, act)
@@ -517,8 +530,8 @@ class TrainEngine:
                     dx, nparts = ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask, bias_part=base)
                     self._wg.add_job(base, bias_out, nparts, 8)
                     return dx, True
-                return ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask), False
-            return ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask)
+                return ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask, ppc=_wino_bwd_ppc(g_out)), False
+            return ops.conv3d_k4_wino_bwd(g_out, L.wp_w, mask, ppc=_wino_bwd_ppc(g_out))
         if L.wp_b is not None and g_out.shape[0] <= L.bwd_max_batch:
             var = _CONV2_BWD_VAR if (g_out.shape[-1] == 32 and _CONV2_BWD_VAR) else None
             if g_out.shape[-1] == 16 and _VAR["C1B"]:
