@@ -13,6 +13,12 @@
 // conflict-free ds_read_b32, and 18- or 10-cell rows cost no padding columns.  The (ez, ey) parity
 // classes are separate accumulators; one B fragment feeds every (plane parity, row parity) that uses it.
 // Per output the accumulation order is fixed: (ci group, jy, jx, jz).
+//
+// REPAIR (training steps behind the engine's `winograd` switch; pack kind 12): the x-edge taps (jx = 2: kx = 4, which
+// only the even outputs have) run on rows (co, ey) instead -- one product serves both row parities of a plane parity,
+// 15 fragments per channel group instead of 25 half-empty ones (65 instead of 75 in all).  Their sums are kept in
+// accumulators of their own and added to the even outputs in the epilogue, so an even output's sum ends with its
+// kx = 4 taps: another order, other bits (evaluation, encode and decode keep the 75-fragment form).
 #include "nvf_common.h"
 #include <type_traits>
 
@@ -33,6 +39,13 @@ __host__ __device__ constexpr int a_index(int ez, int ey, int jz, int jy, int jx
   return base + (jz * (3 - ey) + jy) * 3 + jx;
 }
 
+constexpr int kAPerGroupR = 65;       // REPAIR: 50 (classes x [jz][jy][jx < 2]) + 15 x-edge fragments (ez; [jz][jy])
+__host__ __device__ constexpr int a_index_r(int ez, int ey, int jz, int jy, int jx) {
+  const int base = ez == 0 ? (ey == 0 ? 0 : 18) : (ey == 0 ? 30 : 42);
+  return base + (jz * (3 - ey) + jy) * 2 + jx;
+}
+__host__ __device__ constexpr int a_index_edge(int ez, int jz, int jy) { return 50 + (ez ? 9 : 0) + jz * 3 + jy; }
+
 __global__ void pack_convT_mfma_kernel(const float* __restrict__ wf /* [cin][125][8] */, float* __restrict__ wp,
                                        int cin) {
   const int total = (cin / 4) * kAPerGroup * 64;
@@ -49,9 +62,11 @@ __global__ void pack_convT_mfma_kernel(const float* __restrict__ wf /* [cin][125
   }
 }
 
-template <int CIN_, int NIN_, int NCT_, int NSPLIT_, int NW_ = 4>
+template <int CIN_, int NIN_, int NCT_, int NSPLIT_, int NW_ = 4, bool REPAIR_ = false>
 struct TMCfg {
   static constexpr int CIN = CIN_, NIN = NIN_, NCT = NCT_, NSPLIT = NSPLIT_;
+  static constexpr bool REPAIR = REPAIR_;
+  static constexpr int KA = REPAIR_ ? kAPerGroupR : kAPerGroup;   // A fragments per channel group
   static constexpr int NCELL = NIN + 2;                        // cells per axis; outputs 2 NIN + 3
   static constexpr int NPT = (NCELL * NCELL + 15) / 16;        // column tiles of a cell plane
   static constexpr int NW = NW_, NTH = NW_ * 64, CPW = NW * NCT;  // waves, threads, column tiles per workgroup
@@ -61,7 +76,7 @@ struct TMCfg {
   static constexpr int CS = cs_for(3 * PLANE);                 // channel stride: second channel -> banks 16..31
   static constexpr int NG = CIN / 4;
   static constexpr int XS = CIN * CS;                          // input image
-  static constexpr int AS = NG * kAPerGroup * 64;              // A fragments
+  static constexpr int AS = NG * KA * 64;                      // A fragments
   static_assert((XS + AS) * 4 <= 160 * 1024, "LDS");
 };
 
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
   const int j = lane & 15, kq = lane >> 4;
   const size_t cstride = (size_t)NOUT * NOUT * NOUT;
   // ---- epilogue of one item: lane holds rows i = 4 kq + r -> co = 2 kq + (r >> 1), ex = r & 1 of cell p
-  auto epilogue = [&](int item, const f32x4 (&res)[NCT][2][2]) {
+  auto epilogue = [&](int item, const f32x4 (&res)[NCT][2][2], const f32x4 (&edge)[NCT][2]) {
     int b, cz, split;
     convT_item<NIN>(item, T::NSPLIT, batch, b, cz, split);
 #pragma unroll
@@ -162,7 +177,9 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
             const int co = 2 * kq + (r >> 1), ox = 2 * cx;
             const float bv = bias ? bias[co] : 0.f;
             float* o = y + ((size_t)b * 8 + co) * cstride + ((size_t)oz * NOUT + oy) * NOUT + ox;
-            const float v0 = nvf_act(res[c][ez][ey][r] + bv, act), v1 = nvf_act(res[c][ez][ey][r + 1] + bv, act);
+            // (REPAIR: the lane's x-edge rows are (co, ey) of the same two channels: row r + ey)
+            const float even = T::REPAIR ? res[c][ez][ey][r] + edge[c][ez][r + ey] : res[c][ez][ey][r];
+            const float v0 = nvf_act(even + bv, act), v1 = nvf_act(res[c][ez][ey][r + 1] + bv, act);
             if (NVF_CT_DBG & 2) { if (v0 == 12345.f) o[0] = v1; continue; }
             if (ox + 1 < NOUT) *(nvf_f2u*)o = nvf_f2u{v0, v1};
             else if (ox < NOUT) o[0] = v0;
@@ -194,6 +211,9 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[c][e >> 1][e & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 edge[NCT][2];                                        // REPAIR only (else never touched: no registers)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) edge[c][0] = edge[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     int colbase[NCT];
     // YM: bit jy set = some cell of one of this wave's column tiles reads an input row that exists (cy - jy in [0, NIN)).
     // The first / last tiles of a cell plane lie in the rows cy = 0, 1 / NIN, NIN + 1, where one or two of the three jy taps
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
 #pragma unroll 1
       for (int g = 0; g < NG; ++g) {
         const float* xg = xs + g * 4 * CS;
-        const float* ag = as + g * kAPerGroup * 64 + lane;
+        const float* ag = as + g * T::KA * 64 + lane;
 #pragma unroll
         for (int jy = 0; jy < 3; ++jy) {
           if (!((ym >> jy) & 1)) continue;                     // (scalar branch around 9 - 27 MFMAs)
@@ -228,12 +248,27 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
 #pragma unroll
             for (int jz = 0; jz < 3; ++jz) {
               if (!((MASK >> jz) & 1)) continue;
+              if (T::REPAIR && jx == 2) {                      // x-edge taps: rows (co, ey), one product per plane parity
+                float ae[2];
+#pragma unroll
+                for (int ez = 0; ez < 2; ++ez) ae[ez] = jz <= 2 - ez ? ag[a_index_edge(ez, jz, jy) * 64] : 0.f;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                  const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];
+#pragma unroll
+                  for (int ez = 0; ez < 2; ++ez)
+                    if (jz <= 2 - ez && !(NVF_CT_DBG & 1))
+                      edge[c][ez] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[ez], bv, edge[c][ez], 0, 0, 0);
+                }
+                continue;
+              }
               float a[2][2];
 #pragma unroll
               for (int ez = 0; ez < 2; ++ez)
 #pragma unroll
                 for (int ey = 0; ey < 2; ++ey)
-                  a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey) ? ag[a_index(ez, ey, jz, jy, jx) * 64] : 0.f;
+                  a[ez][ey] = (jz <= 2 - ez && jy <= 2 - ey)
+                                  ? ag[(T::REPAIR ? a_index_r(ez, ey, jz, jy, jx) : a_index(ez, ey, jz, jy, jx)) * 64] : 0.f;
 #pragma unroll
               for (int c = 0; c < NCT; ++c) {
                 const float bv = xg[colbase[c] + (2 - jz) * PLANE - jy * NCELL - jx];   // input plane cz - jz
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(T::NTH) void convT_k5s2_mfma(const float* __restric
         default: mfma_phase(std::integral_constant<int, 4>{}); break;
       }
     }
-    epilogue(item, acc);
+    epilogue(item, acc, edge);
   }
 }
 
@@ -308,6 +343,8 @@ extern "C" int nvf_convT3d_k5s2_mfma(const float* x, const float* wp, const floa
   NVF_TM(5, 16, 8, 1, 1, 8)  // up1: eight waves, one column tile each (two waves per SIMD instead of one on 160 CUs)
   NVF_TM(5, 8, 16, 1, 3, 8)  // up2: eight waves x one tile, three splits
   NVF_TM(6, 8, 16, 2, 2, 8)  // up2: eight waves x two tiles = 16 of 21 column tiles, two splits (11 empty slots of 32)
+  NVF_TM(15, 16, 8, 1, 1, 8, true)   // variant 5 with the x-edge taps on rows (co, ey): wp = pack kind 12 (training steps)
+  NVF_TM(15, 8, 16, 1, 3, 8, true)
 #undef NVF_TM
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();

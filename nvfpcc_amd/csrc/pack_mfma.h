@@ -120,6 +120,26 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
       const int co = i >> 1, ex = i & 1, ci = 4 * g + k;
       const int kz = ez + 2 * jz, ky = ey + 2 * jy, kx = ex + 2 * jx;
       if (kx < 5) v = src(job, (ci * 125 + (kz * 5 + ky) * 5 + kx) * 8 + co);
+    } else if (kind == 12) {                         // ... with the kx = 4 taps on rows (co, ey): [g][50 + 15 fragments][lane]
+      // (convt_mfma.hip, REPAIR: training steps only.)  Fragments 0..49: the classes (ez, ey) = (0,0) (0,1) (1,0) (1,1),
+      // inside a class [jz][jy][jx = 0, 1], rows (co, ex); 50..64: the x-edge taps (jx = 2: kx = 4, even outputs only),
+      // ez = 0 then 1, [jz][jy = 0..2], rows (co, ey) -- the odd row parity has no ky = 5 tap (jy = 2: zero)
+      int f = r % 65;
+      const int g = r / 65, ci = 4 * g + k, co = i >> 1, par = i & 1;
+      if (f < 50) {
+        int ez = 0, ey = 0;
+        if (f >= 42) { ez = 1; ey = 1; f -= 42; }
+        else if (f >= 30) { ez = 1; f -= 30; }
+        else if (f >= 18) { ey = 1; f -= 18; }
+        const int jx = f % 2, jy = (f / 2) % (3 - ey), jz = f / (2 * (3 - ey));
+        v = src(job, (ci * 125 + ((ez + 2 * jz) * 5 + ey + 2 * jy) * 5 + par + 2 * jx) * 8 + co);
+      } else {
+        f -= 50;
+        const int ez = f >= 9 ? 1 : 0;
+        if (ez) f -= 9;
+        const int jy = f % 3, jz = f / 3, ky = par + 2 * jy;
+        if (ky < 5) v = src(job, (ci * 125 + ((ez + 2 * jz) * 5 + ky) * 5 + 4) * 8 + co);
+      }
     } else if (kind == 11) {                         // transposed conv forward, 16 output channels: [g][125][lane]
       int f = r % 125, cls = 0;
       const int g = r / 125;
@@ -150,7 +170,7 @@ __device__ __forceinline__ void pack_mfma_body(const PackJobs& m, int job, int b
   }
 }
 
-// kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin);
+// kinds: 0 / 2 = nvf_pack_mfma_k4 with that pair axis (c0 = cin); 10 = nvf_pack_convT_mfma (c0 = cin); 12 = its training-step form with the kx = 4 taps on rows (co, ey) (65 fragments per channel group);
 // 11 = nvf_pack_convT16_mfma (c0 = cin, c1 = cout); 20 = nvf_pack_s2k5_mfma (c0 = cig, c1 = cog); 30 / 31 = nvf_pack_g16_mfma with k = 4 / 5 (c0 = cin, c1 = cout); 40 = Winograd form of a 4^3 conv (c0 = c1 = 8; conv_wino.hip); 41 = the same with 16 -> 16 channels (conv16_wino.hip).
 // Fills m (sources optional: the step head derives them).
 static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, const int* kinds, const int* c0s,
@@ -161,6 +181,7 @@ static inline int pack_jobs_desc(const float* const* srcs, float* const* dsts, c
     m.src[j] = srcs ? srcs[j] : nullptr; m.dst[j] = dsts[j]; m.kind[j] = kinds[j]; m.c0[j] = c0s[j]; m.c1[j] = c1s[j];
     if (kinds[j] == 0 || kinds[j] == 2) m.total[j] = (c0s[j] / 4) * 4 * (kinds[j] == 0 ? 5 : 4) * (kinds[j] == 2 ? 5 : 4) * 64;
     else if (kinds[j] == 10) m.total[j] = (c0s[j] / 4) * 75 * 64;
+    else if (kinds[j] == 12) m.total[j] = (c0s[j] / 4) * 65 * 64;
     else if (kinds[j] == 40 && c0s[j] == 8 && c1s[j] == 8) m.total[j] = 2 * 5 * 25 * 64;
     else if (kinds[j] == 41 && c0s[j] == 16 && c1s[j] == 16) m.total[j] = 4 * 4 * 25 * 64;
     else if (kinds[j] == 11 && c1s[j] > 0 && c1s[j] % 16 == 0) m.total[j] = (c1s[j] / 16) * (c0s[j] / 4) * 125 * 64;

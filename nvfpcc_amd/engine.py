@@ -37,6 +37,7 @@ _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forwa
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
 # (conv1's training FORWARD in that form: measured slower at batch 16 -- 19.1 us two-set / 16.7 us one-set kernel against
 # 12.2 us for the direct kernel, r05 A/B -- 16^3 outputs do not amortise the transforms; not wired)
+_CONVT_EDGE = os.environ.get("NVF_CONVT_EDGE", "1") != "0"   # up1 / up2 training forward: kx = 4 taps on rows (co, ey)
 _WINO1 = 1 << 16                                         # ppc bit: the one-accumulator-set kernels (conv_wino1.hip)
 
 
@@ -89,7 +90,7 @@ class _NullCtx:
 
 class _Layer:
     __slots__ = ("name", "mod", "kind", "k", "w_fwd", "w_bwd", "b_eff", "gk", "gb", "cin", "cout", "pad", "wp_f",
-                 "wp_b", "wp_t", "wp_s", "wp_gf", "wp_gb", "wp_t16", "wp_w", "wp_wf", "bwd_pair", "bwd_max_batch")
+                 "wp_b", "wp_t", "wp_tr", "wp_s", "wp_gf", "wp_gb", "wp_t16", "wp_w", "wp_wf", "bwd_pair", "bwd_max_batch")
 
 
 class TrainEngine:
@@ -213,12 +214,17 @@ class TrainEngine:
             L.b_eff = torch.empty(m.b.numel(), device=self.dev)
             L.gk, L.gb = self._g(prefix + ".kernel").view(m.kernel.shape), self._g(prefix + ".b")
             L.cin, L.cout, L.pad = m.in_channels, m.out_channels, m.padding
-            L.wp_f = L.wp_b = L.wp_t = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = L.wp_w = L.wp_wf = None
+            L.wp_f = L.wp_b = L.wp_t = L.wp_tr = L.wp_s = L.wp_gf = L.wp_gb = L.wp_t16 = L.wp_w = L.wp_wf = None
             L.bwd_pair, L.bwd_max_batch = 2, 0
             if self.narrow and L.k == 5 and L.cin % 4 == 0 and L.cout == 8 and L.pad == 0 and name in ("up1", "up2"):
                 # matrix-core form of the padding-0 transposed convolutions: forward, and backward-data (a
                 # stride-2 gather convolution with cin output channels)
                 L.wp_t = torch.empty(int(lib().nvf_pack_convT_mfma_floats(L.cin)), device=self.dev)
+                if self.winograd and _CONVT_EDGE:
+                    # the forward of TRAINING steps with the kx = 4 taps on rows (co, ey): 65 instead of 75 A fragments per
+                    # channel group, another summation order for the even x outputs (pack kind 12, kernel variant 15);
+                    # evaluation / encode / decode keep wp_t
+                    L.wp_tr = torch.empty((L.cin // 4) * 65 * 64, device=self.dev)
                 if L.cin in (8, 16):
                     L.wp_s = torch.empty(int(lib().nvf_pack_s2k5_mfma_floats(L.cout, L.cin)), device=self.dev)
             if self.narrow and L.k == 4 and L.cin % 4 == 0 and L.cout == 8 and L.cin == 8 and L.pad == 0:
@@ -283,6 +289,8 @@ class TrainEngine:
         meta += [(row[nm], 0) for nm, L in named if L.wp_wf is not None]
         jobs += [(L.w_fwd, L.wp_t, 10, L.cin, 8) for _, L in named if L.wp_t is not None]
         meta += [(row[nm], 0) for nm, L in named if L.wp_t is not None]
+        jobs += [(L.w_fwd, L.wp_tr, 12, L.cin, 8) for _, L in named if L.wp_tr is not None]
+        meta += [(row[nm], 0) for nm, L in named if L.wp_tr is not None]
         jobs += [(L.w_bwd, L.wp_s, 20, L.cout, L.cin) for _, L in named if L.wp_s is not None]
         meta += [(row[nm], 1) for nm, L in named if L.wp_s is not None]
         # 16-row gather forms: kind 30 (k = 4) / 31 (k = 5), c0 = input channels of the gather, c1 = its output channels
@@ -383,7 +391,7 @@ class TrainEngine:
             ops.pack_mfma_all(self._mfma_jobs)      # conv1, conv2, up1, up2: every MFMA weight layout, one launch
 
     # ------------------------------------------------------------------ forward
-    def _convT(self, L, x, act):
+    def _convT(self, L, x, act, train=False):
         if L.wp_t16 is not None:
             return ops.convT3d_k5s2_mfma16(x, L.wp_t16, L.b_eff, act, cout=L.cout, pad=L.pad)
         if L.wp_t is not None:
@@ -391,6 +399,8 @@ class TrainEngine:
             # batch 16 -- and at batch 917 (the full-batch latent step; r05 sweep): up2 1115 -> 916 us, up1 389 -> 310;
             # every variant runs the same per-output fmaf chain: bit-identical)
             var = _VAR["UP1F" if L.cin == 16 else "UP2F"] or 5
+            if train and L.wp_tr is not None and var == 5:
+                return ops.convT3d_k5s2_mfma(x, L.wp_tr, L.b_eff, act, variant=15)
             return ops.convT3d_k5s2_mfma(x, L.wp_t, L.b_eff, act, variant=var)
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
@@ -461,13 +471,13 @@ class TrainEngine:
             self._fork()
             with self._on_side():                   # the two coarse heads run beside the trunk
                 a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
-        a["y2"] = self._convT(Ls["up1"], a["y1"], R)
+        a["y2"] = self._convT(Ls["up1"], a["y1"], R, train=(mode == "train"))
         a["y3"] = self._conv(Ls["conv1"], a["y2"], R)
         if not self.heads3:
             self._fork()
             with self._on_side():
                 a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
-        a["y4"] = self._convT(Ls["up2"], a["y3"], R)
+        a["y4"] = self._convT(Ls["up2"], a["y3"], R, train=(mode == "train"))
         a["y5"] = self._conv(Ls["conv2"], a["y4"], R, train=(mode == "train"))
         if self.heads3:                             # all three heads in one launch, after the trunk
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]

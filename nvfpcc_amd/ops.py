@@ -373,9 +373,17 @@ def convT3d_k5s2_fwd(x, w_fwd, bias, cout, pad, act=ACT_NONE, out=None):
     return y
 
 
-def pack_convT_mfma(w_fwd, cin, out=None):
-    """MFMA A-fragments of a k5 s2 transposed-conv weight in the packed forward layout [cin][125][8]."""
+def pack_convT_mfma(w_fwd, cin, out=None, edge_rows=False):
+    """MFMA A-fragments of a k5 s2 transposed-conv weight in the packed forward layout [cin][125][8].  ``edge_rows``: the
+    training-step form (kernel variant 15: the kx = 4 taps on rows (co, ey), 65 fragments per channel group; pack kind 12)."""
     _f32(w_fwd, out)
+    if edge_rows:
+        n = (cin // 4) * 65 * 64
+        wp = out if out is not None else torch.empty(n, device=w_fwd.device)
+        if w_fwd.numel() != cin * 125 * 8 or wp.numel() != n:
+            raise RuntimeError("pack_convT_mfma: weight size does not match (cin, 5, 8)")
+        pack_mfma_all([(w_fwd, wp, 12, cin, 8)])
+        return wp
     n = int(lib().nvf_pack_convT_mfma_floats(cin))
     wp = out if out is not None else torch.empty(n, device=w_fwd.device)
     if w_fwd.numel() != cin * 125 * 8 or wp.numel() != n:

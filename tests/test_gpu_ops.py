@@ -105,6 +105,34 @@ def test_conv_transpose_k5s2_mfma_forward(ops, cin, n, B):
         assert torch.equal(yi[0], y[i])
 
 
+@pytest.mark.parametrize("cin,n,B", [(8, 16, 1), (8, 16, 5), (8, 16, 16), (16, 8, 1), (16, 8, 5), (16, 8, 16)])
+def test_conv_transpose_k5s2_mfma_forward_training_form(ops, cin, n, B):
+    """The training-step form of up1 / up2 (variant 15, pack kind 12: the kx = 4 taps of the even x outputs run on rows
+    (co, ey) and are added at the end of their sums) against torch's float64 conv_transpose3d.  Odd x outputs have no kx = 4
+    tap: they are the BITS of the evaluation form (variant 5); even ones differ by a re-association only.  Batch invariant."""
+    g = gen(5100 + cin + n + B)
+    x = torch.randn(B, cin, n, n, n, generator=g)
+    w = torch.randn(cin, 8, 5, 5, 5, generator=g) / (cin * 125 / 8) ** 0.5
+    b = torch.randn(8, generator=g)
+    y_ref = F.conv_transpose3d(x.double(), w.double(), b.double(), stride=2)
+    wf, _ = ops.pack_convT_weight(dev(w))
+    wp, wpr = ops.pack_convT_mfma(wf, cin), ops.pack_convT_mfma(wf, cin, edge_rows=True)
+    xd = dev(x)
+    y5 = ops.convT3d_k5s2_mfma(xd, wp, dev(b), ops.ACT_NONE, variant=5)
+    y15 = ops.convT3d_k5s2_mfma(xd, wpr, dev(b), ops.ACT_NONE, variant=15)
+    scale = y_ref.abs().max().item()
+    e5, e15 = (y5.cpu().double() - y_ref).abs().max().item() / scale, (y15.cpu().double() - y_ref).abs().max().item() / scale
+    print(f"convT training form cin={cin} B={B}: max err / max vs float64: evaluation form {e5:.2e}, training form {e15:.2e}")
+    assert e15 < 1e-6 and e15 < 2 * e5 + 1e-7
+    assert torch.equal(y15[..., 1::2], y5[..., 1::2])
+    assert (y15[..., 0::2] - y5[..., 0::2]).abs().max().item() / scale < 1e-6
+    yr = ops.convT3d_k5s2_mfma(xd, wpr, dev(b), ops.ACT_RELU, variant=15)
+    assert torch.equal(yr, torch.relu(y15))
+    for i in (0, B - 1):
+        yi = ops.convT3d_k5s2_mfma(xd[i:i + 1].contiguous(), wpr, dev(b), ops.ACT_NONE, variant=15)
+        assert torch.equal(yi[0], y15[i])
+
+
 @pytest.mark.parametrize("cin,n,B", [(8, 16, 2), (16, 8, 3)])
 def test_conv_transpose_k5s2_mfma_backward_data(ops, cin, n, B):
     """Matrix-core backward-data of up1 / up2 against torch's autograd (with the fused addend and ReLU mask)."""
