@@ -73,7 +73,8 @@ def main():
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(os.path.join(base, "sq", "b16_kernel_trace.csv"))):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    ker = sorted(dur, key=lambda k: -st.median(dur[k]))[:12]
+    step = [k for k in dur if len(dur[k]) >= 10 and not k.startswith("void at::")]     # the step's kernels, not the set-up's
+    ker = sorted(step, key=lambda k: -st.median(dur[k]))[:18]
     lines = ["SQ counters (rocprofv3 --pmc, one pass) of `python3 bench.py --steps 20 --no-cpu-baseline --no-pmc --no-epoch --no-graph`, batch 16; "
              "medians per dispatch.",
              "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 "
