@@ -283,6 +283,18 @@ int nvf_heads3_loss_bwd_data_bias(const float* const* ps, const float* const* gt
                                   const float* const* masks, const int* cs, const int* ss, int batch,
                                   float* const* bias_outs, void* workspace, size_t workspace_bytes, NvfStepCtx* ctx,
                                   void* stream);
+/* nvf_heads3_fwd (ps[h] = act(conv(xs[h], ws[h]) + biases[h]): network.py:4761-4768 in mode 'train') and
+ * nvf_heads3_loss_bwd_data_bias on those ps (NVFPCC.py:166-184 and the heads' autograd backward-data) in ONE launch: the
+ * forward workgroups hand p to the loss workgroups of their block through device-scope stores and arrival counters.  Same
+ * bits as the two calls.  flags: 6 * batch * 64 32-bit words (one 256-byte line per counter), zero before the first call; a call leaves them zero (one buffer per
+ * stream).  batch <= 32; NVF_EINVAL for other head shapes than nvf_heads3_fwd's. */
+int nvf_heads3_fwd_loss_bwd_data(const float* const* xs, const float* const* ws, const float* const* biases,
+                                 float* const* ps, int act, const float* const* gts, const float* const* dists,
+                                 const float* alphas, const float* betas, const int* slots, float* loss,
+                                 float* const* dls, const float* const* wbs, float* const* dxs,
+                                 const float* const* masks, const int* cs, const int* ss, int batch,
+                                 float* const* bias_outs, void* workspace, size_t workspace_bytes, uint32_t* flags,
+                                 NvfStepCtx* ctx, void* stream);
 /* partial sums only: slabs[h] receives nslabs[h] (<= max_slabs) slabs of cs[h] * 27 floats, to be added by
  * nvf_wgrad_reduce_multi */
 int nvf_heads3_wgrad_partial(const float* const* dlogits, const float* const* xs, float* const* slabs, const int* cs,

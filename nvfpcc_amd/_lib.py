@@ -60,6 +60,7 @@ PROTOTYPES = {
     "nvf_heads3_bwd_data": (I, [P, P, P, P, P, P, I, P]),
     "nvf_heads3_loss_bwd_data": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, Z, P, P]),
     "nvf_heads3_loss_bwd_data_bias": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, Z, P, P]),
+    "nvf_heads3_fwd_loss_bwd_data": (I, [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, Z, P, P, P]),
     "nvf_heads3_wgrad_partial": (I, [P, P, P, P, P, I, I, P, P]),
     "nvf_stem_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "nvf_stem_latent_fwd": (I, [P] * 12 + [I, U, U, P] + [P] * 9 + [I, I, I, I, P]),

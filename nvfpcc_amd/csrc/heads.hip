@@ -14,6 +14,7 @@
 //     reads) feeds 12 FMAs per input channel.
 #include "nvf_common.h"
 #include "step_ctx.h"
+#include "stem_bwd.h"      // nvf_coop_signal / device-scope accesses
 #include <cstdlib>
 
 int nvf_heads3_wgrad_mfma_launch(const float* const* dls, const float* const* xs, float* const* slabs, int narrow,
@@ -95,11 +96,39 @@ struct HPCfg {
 template <class H>
 struct HFwdSmem { static constexpr int WORDS = 2 * H::CPS * H::WORDS + H::C * 9 * 4; };
 
-template <class H>
+// 16-byte device-scope accesses (sc1: the store goes through to memory, the load never hits a stale line of this XCD's
+// L2) for values that cross workgroups INSIDE a launch (heads3_fwd_loss_bwd_data_kernel).  The compiler does not track an
+// asm load: the caller waits (nvf_wait_dev4) before it touches the registers.
+constexpr int kHeadFlagStride = 64;     // words between two counters: 256 B, so the pollers of different blocks hit different lines
+#ifndef NVF_HC_SLEEP
+#define NVF_HC_SLEEP 32                 // s_sleep argument of a polling consumer (x 64 cycles)
+#endif
+
+#ifndef NVF_HC_DBG
+#define NVF_HC_DBG 0     // tuning builds (wrong results): 1 = plain stores / loads, 2 = consumers do not wait, 4 = no signal
+#endif
+__device__ __forceinline__ void nvf_store_dev4(float* p, hf4 v) {
+  if (NVF_HC_DBG & 1) { *(hf4*)p = v; return; }
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void nvf_load_dev4_issue(hf4& v, const float* p) {
+  if (NVF_HC_DBG & 1) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); return; }
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void nvf_wait_dev4(hf4 (&v)[N]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));      // (ordered behind the wait: volatile asms keep their order)
+}
+
+// COOP (the forward inside the launch that also runs the loss and the backward-data): p leaves with device-scope stores
+// and the workgroup signals done[b] -- every thread reaches the signal, so no early return.
+template <class H, bool COOP = false>
 __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
                                               const float* __restrict__ bias, float* __restrict__ y,
                                               const float* __restrict__ addend, const float* __restrict__ mask, int act,
-                                              int bid, float* smem) {
+                                              int bid, float* smem, unsigned* done = nullptr) {
   constexpr int C = H::C, S = H::S, TZ = H::TZ, TY = H::TY, IY = H::IY, XG = H::XG, NT = H::NT, NIT = H::NIT,
                 WORDS = H::WORDS, CPS = H::CPS;
   float* xs = smem;
@@ -177,6 +206,16 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ x, const
       }
     }
   }
+  if (COOP) {
+    if (active) {
+      const float bv = bias ? bias[0] : 0.f;
+      const size_t off = (((size_t)b * S + z0 + tz) * S + y0 + ty) * S + 4 * xg;
+      nvf_store_dev4(y + off, hf4{nvf_act(acc[0] + bv, act), nvf_act(acc[1] + bv, act), nvf_act(acc[2] + bv, act),
+                                  nvf_act(acc[3] + bv, act)});
+    }
+    if (!(NVF_HC_DBG & 4)) nvf_coop_signal(done + b * kHeadFlagStride);
+    return;
+  }
   if (!active) return;
   const float bv = bias ? bias[0] : 0.f;
   const size_t off = (((size_t)b * S + z0 + tz) * S + y0 + ty) * S + 4 * xg;
@@ -215,9 +254,28 @@ struct HeadLoss {
   float* part;             // loss partials of this term: one per workgroup
   float* bias_part;        // or null: the sum of the workgroup's own dl values (the head's bias gradient), one per workgroup
   float alpha, beta;
+  // COOP only (p is produced by the forward workgroups of the SAME launch): done[b] counts the nprod forward workgroups of
+  // block b, used[b] the ncons workgroups that have seen them all -- the last of those zeroes both for the next launch
+  unsigned* done;
+  unsigned* used;
+  unsigned nprod, ncons;
 };
 
-template <int S, int TZ, int TY, int RS, int NT>
+// every thread of a consumer workgroup calls it before its first device-scope load of what the nprod producers wrote
+__device__ __forceinline__ void nvf_coop_wait_many(unsigned* counter, unsigned target, unsigned* used, unsigned ncons) {
+  if (threadIdx.x == 0 && !(NVF_HC_DBG & 2)) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+      __builtin_amdgcn_s_sleep(NVF_HC_SLEEP);
+    // (a consumer counts itself only after its wait has ended, so when the last one arrives nobody polls `counter` any more)
+    if (__hip_atomic_fetch_add(used, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ncons - 1) {
+      __hip_atomic_store(used, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+
+template <int S, int TZ, int TY, int RS, int NT, bool COOP = false>
 __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, float* red, int tid, int b, int z0, int y0,
                                                 int wg) {
   constexpr int XG = S / 4, IZ = TZ + 2, IY = TY + 2, ITEMS = IZ * IY * XG;
@@ -226,6 +284,31 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
   float s = 0.f, sb = 0.f;
   constexpr int U = (ITEMS + NT - 1) / NT;                    // every load of the thread in flight before any is used
   float4 pv[U], gv[U], dv[U];
+  hf4 pdev[COOP ? U : 1];
+  if (COOP) {
+    // the targets and distances do not depend on the forward: their loads are in flight while the workgroup waits for
+    // block b's forward workgroups; then p by device-scope loads
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid + u * NT;
+      const int xq = i % XG, r = i / XG, yi = r % IY, zi = r / IY;
+      const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
+      const bool ok = i < ITEMS && gz >= 0 && gz < S && gy >= 0 && gy < S;
+      const size_t off = ok ? b * vol + ((size_t)gz * S + gy) * S + 4 * xq : 0;
+      gv[u] = *(const float4*)(f.gt + off);
+      dv[u] = *(const float4*)((f.dist ? f.dist : f.gt) + off);
+    }
+    nvf_coop_wait_many(f.done + b * kHeadFlagStride, f.nprod, f.used + b * kHeadFlagStride, f.ncons);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = tid + u * NT;
+      const int xq = i % XG, r = i / XG, yi = r % IY, zi = r / IY;
+      const int gz = z0 - 1 + zi, gy = y0 - 1 + yi;
+      const bool ok = i < ITEMS && gz >= 0 && gz < S && gy >= 0 && gy < S;
+      nvf_load_dev4_issue(pdev[u], f.p + (ok ? b * vol + ((size_t)gz * S + gy) * S + 4 * xq : 0));
+    }
+    nvf_wait_dev4(pdev);
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int i = tid + u * NT;
@@ -235,8 +318,10 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
     const size_t off = ok ? b * vol + ((size_t)gz * S + gy) * S + 4 * xq : 0;
     // (unconditional loads from a valid address, then a select: `ok ? *p : zero` becomes a select of ADDRESSES -- a
     // private zero against the global pointer -- i.e. four flat_load_dword per element instead of one global_load_dwordx4)
-    const float4 pl = *(const float4*)(f.p + off), gl = *(const float4*)(f.gt + off);
-    const float4 dl4 = *(const float4*)((f.dist ? f.dist : f.p) + off);
+    const float4 pl = COOP ? make_float4(pdev[COOP ? u : 0].x, pdev[COOP ? u : 0].y, pdev[COOP ? u : 0].z, pdev[COOP ? u : 0].w)
+                           : *(const float4*)(f.p + off);
+    const float4 gl = COOP ? gv[u] : *(const float4*)(f.gt + off);
+    const float4 dl4 = COOP ? dv[u] : *(const float4*)((f.dist ? f.dist : f.p) + off);
     // (component selects: `ok ? pl : z4` on the float4 STRUCT is a select of two memory copies -- both values went
     // through scratch memory and came back by a flat load)
     const bool okd = ok && f.dist;
@@ -280,7 +365,7 @@ __device__ __forceinline__ void head_stage_loss(const HeadLoss& f, float* ds, fl
 template <class H>
 struct HBwdSmem { static constexpr int WORDS = (H::IZ * H::IY * H::RS + 3) / 4 * 4 + 27 * H::C + 16; };   // + block-sum scratch
 
-template <class H>
+template <class H, bool COOP = false>
 __device__ __forceinline__ void head_bwd_data_body(const float* __restrict__ dl, const float* __restrict__ wb,
                                                    const float* __restrict__ bias, float* __restrict__ dx,
                                                    const float* __restrict__ addend, const float* __restrict__ mask,
@@ -293,7 +378,7 @@ __device__ __forceinline__ void head_bwd_data_body(const float* __restrict__ dl,
   const int tile = bid % (TILES_Y * TILES_Z), b = bid / (TILES_Y * TILES_Z);
   const int y0 = (tile % TILES_Y) * TY, z0 = (tile / TILES_Y) * TZ;
   for (int i = tid; i < 27 * C; i += NT) ws[i] = wb[i];
-  if (loss) head_stage_loss<S, TZ, TY, RS, NT>(*loss, ds, ws + 27 * C, tid, b, z0, y0, bid);
+  if (loss) head_stage_loss<S, TZ, TY, RS, NT, COOP>(*loss, ds, ws + 27 * C, tid, b, z0, y0, bid);
   else head_stage<1, S, IZ, IY, RS, NT>(dl + (size_t)b * S * S * S, ds, tid, z0, y0);
   __syncthreads();
   if (tid >= H::NACT) return;
@@ -701,6 +786,119 @@ extern "C" int nvf_heads3_loss_bwd_data(const float* const* ps, const float* con
                                         void* workspace, size_t workspace_bytes, NvfStepCtx* ctx, void* stream) {
   return nvf_heads3_loss_bwd_data_bias(ps, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, cs, ss, batch,
                                        nullptr, workspace, workspace_bytes, ctx, stream);
+}
+
+// ---- forward + loss + backward-data of the three heads in ONE launch ---------------------------------------------------
+// The forward workgroups (lowest ids: they wait for nothing) write p with device-scope stores and count themselves into
+// done[head][block]; a loss / backward-data workgroup of (head, block) issues its target / distance loads, waits until all
+// of that block's forward workgroups have arrived, and reads p with device-scope loads.  Same bodies, same arithmetic:
+// p, dls, dxs, the loss and the bias partials are the BITS of nvf_heads3_fwd + nvf_heads3_loss_bwd_data_bias.  Any number
+// of resident slots is enough: consumers are dispatched after every producer (in-order dispatch), so a waiting consumer
+// never holds a slot a producer needs.
+constexpr int cmax2(int a, int b) { return a > b ? a : b; }
+
+// MINW = waves per SIMD the register allocation must allow: 4 for the narrow heads (128 registers, no spill -- the loss
+// workgroups then all fit beside the forward ones: 1024 slots for 592 + 800 workgroups at batch 16, the 800 in ONE round
+// once the forward has left; with the forward body's 134 registers there were 768 slots and a second round of 32), 2 for
+// the wide ones (212 registers)
+template <class F0, class F1, class F2, class H0, class H1, class H2, int MINW>
+__global__ __launch_bounds__(256, MINW) void heads3_fwd_loss_bwd_data_kernel(Heads3 mf, Heads3 m, Heads3Loss f, unsigned* done,
+                                                                        int batch) {
+  __shared__ __attribute__((aligned(16))) float
+      smem[cmax2(cmax3(HFwdSmem<F0>::WORDS, HFwdSmem<F1>::WORDS, HFwdSmem<F2>::WORDS),
+                 cmax3(HBwdSmem<H0>::WORDS, HBwdSmem<H1>::WORDS, HBwdSmem<H2>::WORDS))];
+  int bid = blockIdx.x;
+  const int nf = mf.n[0] + mf.n[1] + mf.n[2];
+  if (bid < nf) {                   // forward: the small heads' few workgroups first (the longest chains of steps)
+    if (bid < mf.n[0])
+      head_fwd_body<F0, true>(mf.a[0], mf.w[0], mf.bias[0], mf.out[0], nullptr, nullptr, mf.act, bid, smem, done);
+    else if (bid < mf.n[0] + mf.n[1])
+      head_fwd_body<F1, true>(mf.a[1], mf.w[1], mf.bias[1], mf.out[1], nullptr, nullptr, mf.act, bid - mf.n[0], smem,
+                              done + batch * kHeadFlagStride);
+    else
+      head_fwd_body<F2, true>(mf.a[2], mf.w[2], mf.bias[2], mf.out[2], nullptr, nullptr, mf.act, bid - mf.n[0] - mf.n[1],
+                              smem, done + 2 * batch * kHeadFlagStride);
+    return;
+  }
+  bid -= nf;
+  if (bid < m.n[2])
+    head_bwd_data_body<H2, true>(nullptr, m.w[2], nullptr, m.out[2], nullptr, m.mask[2], 0, bid, smem, &f.h[2]);
+  else if (bid < m.n[2] + m.n[1])
+    head_bwd_data_body<H1, true>(nullptr, m.w[1], nullptr, m.out[1], nullptr, m.mask[1], 0, bid - m.n[2], smem, &f.h[1]);
+  else
+    head_bwd_data_body<H0, true>(nullptr, m.w[0], nullptr, m.out[0], nullptr, m.mask[0], 0, bid - m.n[2] - m.n[1], smem,
+                                 &f.h[0]);
+}
+
+template <class F0, class F1, class F2, class H0, class H1, class H2, int MINW>
+static int heads3_fwd_loss_bwd_data_t(const float* const* xs, const float* const* ws, const float* const* biases,
+                                      float* const* ps, int act, const float* const* gts, const float* const* dists,
+                                      const float* alphas, const float* betas, const int* slots, float* loss,
+                                      float* const* dls, const float* const* wbs, float* const* dxs,
+                                      const float* const* masks, int batch, void* workspace, unsigned* flags,
+                                      NvfStepCtx* ctx, void* stream, float* const* bias_outs) {
+  static_assert(H0::NT == 256 && H1::NT == 256 && H2::NT == 256 && F0::NT == 256 && F1::NT == 256 && F2::NT == 256,
+                "one workgroup size");
+  Heads3 mf{}, m{};
+  Heads3Loss f{};
+  FocalMulti fm{};
+  const int nprod[3] = {head_tiles<F0>(), head_tiles<F1>(), head_tiles<F2>()};
+  const int ncons[3] = {head_tiles<H0>(), head_tiles<H1>(), head_tiles<H2>()};
+  for (int h = 0; h < 3; ++h) {
+    mf.n[h] = batch * nprod[h];
+    m.n[h] = batch * ncons[h];
+    if (!xs[h] || !ws[h] || !ps[h] || !gts[h] || !dls[h] || !wbs[h] || !dxs[h] || slots[h] < 0 || slots[h] > 2 ||
+        m.n[h] > kLossMaxWG)
+      return NVF_EINVAL;
+    mf.a[h] = xs[h]; mf.w[h] = ws[h]; mf.bias[h] = biases[h]; mf.out[h] = ps[h];
+    m.w[h] = wbs[h]; m.out[h] = dxs[h]; m.mask[h] = masks[h];
+    f.h[h].p = ps[h]; f.h[h].gt = gts[h]; f.h[h].dist = dists[h]; f.h[h].dl = dls[h];
+    f.h[h].part = (float*)workspace + slots[h] * kLossMaxWG;
+    f.h[h].bias_part = bias_outs ? (float*)workspace + (3 + h) * kLossMaxWG : nullptr;
+    f.h[h].alpha = alphas[h]; f.h[h].beta = betas[h];
+    f.h[h].done = flags + h * batch * kHeadFlagStride; f.h[h].used = flags + (3 + h) * batch * kHeadFlagStride;
+    f.h[h].nprod = (unsigned)nprod[h]; f.h[h].ncons = (unsigned)ncons[h];
+    fm.nwg[slots[h]] = m.n[h];
+  }
+  mf.act = act;
+  if (slots[0] == slots[1] || slots[0] == slots[2] || slots[1] == slots[2]) return NVF_EINVAL;
+  const int grid = mf.n[0] + mf.n[1] + mf.n[2] + m.n[0] + m.n[1] + m.n[2];
+  heads3_fwd_loss_bwd_data_kernel<F0, F1, F2, H0, H1, H2, MINW><<<grid, 256, 0, nvf_stream(stream)>>>(mf, m, f, flags, batch);
+  NVF_LAUNCH_CHECK();
+  if (bias_outs) {
+    const int rc = nvf_finals_run_head_bias(ctx, (const float*)workspace + 3 * kLossMaxWG, bias_outs, m.n, stream);
+    if (rc != NVF_OK) return rc;
+  }
+  return nvf_finals_run_focal(ctx, fm, (const float*)workspace, loss, 3, stream);
+}
+
+// nvf_heads3_fwd (ps[h] = act(conv(xs[h], ws[h]) + biases[h])) and nvf_heads3_loss_bwd_data_bias on those ps in one
+// launch.  flags: 6 * batch * 64 unsigned words (one 256-byte line per counter), ZERO before the first call; every call leaves them zero (the last consumer of
+// a block resets its counters), so one buffer serves every step of a stream -- not two streams at once.
+extern "C" int nvf_heads3_fwd_loss_bwd_data(const float* const* xs, const float* const* ws, const float* const* biases,
+                                            float* const* ps, int act, const float* const* gts,
+                                            const float* const* dists, const float* alphas, const float* betas,
+                                            const int* slots, float* loss, float* const* dls, const float* const* wbs,
+                                            float* const* dxs, const float* const* masks, const int* cs, const int* ss,
+                                            int batch, float* const* bias_outs, void* workspace, size_t workspace_bytes,
+                                            uint32_t* flags, NvfStepCtx* ctx, void* stream) {
+  if (!xs || !ws || !biases || !ps || !gts || !dists || !alphas || !betas || !slots || !loss || !dls || !wbs || !dxs ||
+      !masks || !cs || !ss || !workspace || !flags || batch <= 0)
+    return NVF_EINVAL;
+  if (bias_outs && (!bias_outs[0] || !bias_outs[1] || !bias_outs[2])) return NVF_EINVAL;
+  if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
+  const int t = heads3_tuple(cs, ss);
+  if (t == 0)
+    return heads3_fwd_loss_bwd_data_t<HPCfg<16, 8, 8, 8, 4>, HPCfg<8, 16, 8, 8, 2>, HPCfg<8, 32, 4, 8>, HCfg<16, 8, 4, 8>,
+                                      HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>, 4>(
+        xs, ws, biases, ps, act, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, flags, ctx,
+        stream, bias_outs);
+  if (t == 1)
+    return heads3_fwd_loss_bwd_data_t<HPCfg<32, 8, 8, 8, 4>, HPCfg<16, 16, 8, 8, 2>, HPCfg<16, 32, 4, 8>,
+                                      HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 4, 8>, 2>(
+        xs, ws, biases, ps, act, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, flags, ctx,
+        stream, bias_outs);
+  return NVF_EINVAL;
 }
 
 // partial sums of the three weight gradients: slabs[h] receives nslabs[h] slabs of cs[h] * 27 floats (<= max_slabs)

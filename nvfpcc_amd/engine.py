@@ -55,6 +55,7 @@ _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^
 _WINO16_BIAS = os.environ.get("NVF_WINO16_BIAS", "0") != "0"
 _WINO16_WGRAD = tuple(int(v) for v in os.environ.get("NVF_WINO16_WGRAD", "32,16").split(",") if v)   # ... weight gradients (dY extents)
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
+_HEADS_FWD_IN_LOSS = os.environ.get("NVF_HEADS_FWD_IN_LOSS", "1") != "0"   # heads' forward inside the loss launch
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
 _HEADS_IN_TRUNK5 = os.environ.get("NVF_HEADS_IN_TRUNK5", "1") != "0"   # heads' weight gradients as workgroups of the five-gradient launch
@@ -427,8 +428,10 @@ class TrainEngine:
         osz = tuple(s + 2 * L.pad - L.k + 1 for s in x.shape[2:])
         return ops.conv3d_gather(x, L.w_fwd, L.b_eff, L.cout, L.k, 1, L.pad, osz, act)
 
-    def forward(self, e, mode, block_ids):
-        """e [B,ch,2,2,2] latents-before-latent_gen.  Returns the dict of saved activations."""
+    def forward(self, e, mode, block_ids, defer_heads=False):
+        """e [B,ch,2,2,2] latents-before-latent_gen.  Returns the dict of saved activations.  ``defer_heads``: the caller
+        runs backward() next -- at mini-batch sizes the heads' forward then rides in the launch of their loss and
+        backward-data (a["p0"..] stay None until then)."""
         net, Ls = self.net, self.layers
         a = {"e": e}
         g2 = net.latent_gen.gdn_2
@@ -479,7 +482,10 @@ class TrainEngine:
                 a["p1"] = self._conv(Ls["conv1_cls"], a["y3"], S)
         a["y4"] = self._convT(Ls["up2"], a["y3"], R, train=(mode == "train"))
         a["y5"] = self._conv(Ls["conv2"], a["y4"], R, train=(mode == "train"))
-        if self.heads3:                             # all three heads in one launch, after the trunk
+        if (self.heads3 and defer_heads and _HEADS_FWD_IN_LOSS and e.shape[0] <= 32 and _NAIVE_OFF()
+                and not self.allow_overlap):
+            a["p0"] = a["p1"] = a["p2"] = None      # nvf_heads3_fwd_loss_bwd_data (backward)
+        elif self.heads3:                           # all three heads in one launch, after the trunk
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
             a["p0"], a["p1"], a["p2"] = ops.heads3_fwd([a["y1"], a["y3"], a["y5"]], [L.w_fwd for L in hl],
                                                        [L.b_eff for L in hl])
@@ -606,16 +612,31 @@ class TrainEngine:
         if not fused_loss:
             dl2, dl0, dl1 = ops.focal_loss_multi([(a["p2"], gt, dist, 0.9, 1.0), (a["p0"], gt8, None, 0.85, 0.0),
                                                   (a["p1"], gt16, None, 0.85, 0.0)], loss, ctx=ctx)
-        if self.epoch_acc is not None and want_w:
+        def step_metrics():
             # logging counts of NVFPCC.py:174-179, 190-221 (tp / ap / tn / an of the main output and of both heads at 0.5,
             # sse / denom at 0.6): one partial-sum launch, the final pass rides in the finals launch; nvf_step_tail turns
             # them into the per-step ratios behind the all-reduce
-            ops.metrics3([a["p2"], a["p0"], a["p1"]], [gt, gt8, gt16], [dist, None, None], 0.5, 0.6,
-                         out=self.step_counts, ctx=ctx)
+            if self.epoch_acc is not None and want_w:
+                ops.metrics3([a["p2"], a["p0"], a["p1"]], [gt, gt8, gt16], [dist, None, None], 0.5, 0.6,
+                             out=self.step_counts, ctx=ctx)
+        heads_deferred = a.get("p2") is None
+        if not heads_deferred:
+            step_metrics()
         ev_t1 = ev_t0 = None
         if self.heads3:
             hl = [Ls["conv0_cls"], Ls["conv1_cls"], Ls["conv2_cls"]]
-            if fused_loss:      # the three focal terms, their logit gradients and the heads' backward-data: one launch
+            if heads_deferred:
+                # the heads' forward, the three focal terms, their logit gradients and the heads' backward-data: ONE launch
+                # (forward() left p0 / p1 / p2 to this call)
+                assert fused_loss and defer
+                (a["p0"], a["p1"], a["p2"]), (dl0, dl1, dl2), (t0, t1, g5) = ops.heads3_fwd_loss_bwd_data(
+                    [a["y1"], a["y3"], a["y5"]], [L.w_fwd for L in hl], [L.b_eff for L in hl], [gt8, gt16, gt],
+                    [None, None, dist], [0.85, 0.85, 0.9], [0.0, 0.0, 1.0], [1, 2, 0], loss, [L.w_bwd for L in hl],
+                    [None, None, a["y5"]], self.ctx,
+                    bias_outs=[L.gb for L in hl] if (want_w and _HEAD_BIAS_IN_LOSS) else None)
+                head_bias_done = want_w and _HEAD_BIAS_IN_LOSS
+                step_metrics()
+            elif fused_loss:    # the three focal terms, their logit gradients and the heads' backward-data: one launch
                 (dl0, dl1, dl2), (t0, t1, g5) = ops.heads3_loss_bwd_data(
                     [a["p0"], a["p1"], a["p2"]], [gt8, gt16, gt], [None, None, dist], [0.85, 0.85, 0.9],
                     [0.0, 0.0, 1.0], [1, 2, 0], loss, [L.w_bwd for L in hl], [L.cin for L in hl], [None, None, a["y5"]],
@@ -966,7 +987,7 @@ class TrainEngine:
                 n_pts = float(self.counts[idx_host].sum())
             gt, dist, gt16, gt8, e = self.batch_and_prepare(idx_dev, q, with_rate=not self.allow_overlap,
                                                             stem_mode="train")
-            a = self.forward(e, "train", idx_dev)
+            a = self.forward(e, "train", idx_dev, defer_heads=True)
             tail = None
             if update and self.grad_hook is None and not self.allow_overlap:
                 # single GPU: the optimiser rides in the slab reduction and the finals launch (no all-reduce in between)
@@ -1141,7 +1162,7 @@ class GraphedTrainStep:
         eng = self.eng
         gt, dist, gt16, gt8, e = eng.batch_and_prepare(self.idx, self.q, with_rate=not eng.allow_overlap,
                                                        stem_mode="train")
-        a = eng.forward(e, "train", self.idx)
+        a = eng.forward(e, "train", self.idx, defer_heads=True)
         spec = None
         if tail and eng.grad_hook is None and not eng.allow_overlap:      # single GPU: no launch of its own for the tail
             spec = dict(coef_dev=self.coef, inv_npts_dev=self.inv_npts, sched=(self.buf, self.rows, self.cursor, self.nw))

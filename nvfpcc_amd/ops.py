@@ -657,6 +657,34 @@ def heads3_loss_bwd_data(ps, gts, dists, alphas, betas, slots, loss, w_bwds, cs,
     return dls, dxs
 
 
+def heads3_fwd_loss_bwd_data(xs, w_fwds, biases, gts, dists, alphas, betas, slots, loss, w_bwds, masks, ctx,
+                             bias_outs=None, act=ACT_SIGMOID):
+    """heads3_fwd + heads3_loss_bwd_data in ONE launch (the forward workgroups hand p to their block's loss workgroups
+    inside the launch): returns (ps, dls, dxs), the bits of the two calls.  batch <= 32; ``ctx`` (StepCtx) keeps the
+    arrival counters."""
+    import ctypes
+    _f32(*xs, *w_fwds, *biases, *gts, *[d for d in dists if d is not None], *w_bwds,
+         *[m for m in masks if m is not None], loss)
+    B = xs[0].shape[0]
+    cs = [x.shape[1] for x in xs]
+    ps = [torch.empty((B, 1) + tuple(x.shape[2:]), device=x.device) for x in xs]
+    dls = [torch.empty_like(p) for p in ps]
+    dxs = [torch.empty_like(x) for x in xs]
+    ws = workspace(lib().nvf_reduce_workspace(), xs[0].device, "reduce", ctx)
+    flags = ctx._ws.get("heads_flags")
+    if flags is None:     # one 256-byte line per counter, batch <= 32
+        flags = ctx._ws["heads_flags"] = torch.zeros(6 * 32 * 64, dtype=torch.int32, device=xs[0].device)
+    if bias_outs is not None:
+        _f32(*bias_outs)
+    check(lib().nvf_heads3_fwd_loss_bwd_data(
+        _parr(xs), _parr(w_fwds), _parr(biases), _parr(ps), int(act), _parr(gts), _parr(dists),
+        (ctypes.c_float * 3)(*alphas), (ctypes.c_float * 3)(*betas), _iarr(slots), _ptr(loss), _parr(dls), _parr(w_bwds),
+        _parr(dxs), _parr(masks), _iarr(cs), _iarr([x.shape[-1] for x in xs]), B,
+        None if bias_outs is None else _parr(bias_outs), _ptr(ws), ws.numel(), flags.data_ptr(), _ctx(ctx), _stream()),
+        "nvf_heads3_fwd_loss_bwd_data")
+    return ps, dls, dxs
+
+
 class WgradBatch:
     """Weight gradients of one backward pass with a single reduction launch: ``add`` launches only the partial
     sums (each gradient keeps its own slab region until ``finish``), ``finish`` adds all slabs in one kernel."""

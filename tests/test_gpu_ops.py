@@ -879,6 +879,47 @@ def test_heads_loss_and_backward_data_in_one_launch(ops, which):
                                  wbs, cs, [None, None, None])
 
 
+@pytest.mark.parametrize("which,B", [("narrow", 16), ("narrow", 5), ("narrow", 32), ("wide", 16), ("wide", 3)])
+def test_heads_forward_loss_and_backward_data_in_one_launch(ops, which, B):
+    """nvf_heads3_fwd_loss_bwd_data (the heads' forward workgroups hand p to their block's loss / backward-data workgroups
+    INSIDE the launch: device-scope stores, arrival counters) against nvf_heads3_fwd + nvf_heads3_loss_bwd_data_bias: p,
+    the logit gradients, the input gradients, the loss terms and the bias gradients are the same BITS -- on every one of
+    several back-to-back calls with fresh inputs (the last consumer of a block resets its counters for the next call)."""
+    g = gen(7100 + B)
+    shapes = HEAD_TUPLES[which]
+    cs = [c for c, s in shapes]
+    ws = [torch.randn(1, c, 3, 3, 3, generator=g) * 0.1 for c, s in shapes]
+    bs = [dev(torch.randn(1, generator=g)) for _ in shapes]
+    packed = [ops.pack_conv_weight(dev(w)) for w in ws]
+    ctx = ops.StepCtx()
+    args = ([0.85, 0.85, 0.9], [0.0, 0.0, 1.0], [1, 2, 0])
+    for rep in range(4):
+        xs = [dev(torch.randn(B, c, s, s, s, generator=g)) for c, s in shapes]
+        gts = [dev((torch.rand(B, 1, s, s, s, generator=g) > 0.75).float()) for c, s in shapes]
+        dist = dev(torch.rand(B, 1, 32, 32, 32, generator=g))
+        masks = [None, None, xs[2]]
+        ps_ref = ops.heads3_fwd(xs, [p[0] for p in packed], bs)
+        loss_ref, gb_ref = torch.empty(4, device="cuda"), [torch.zeros(1, device="cuda") for _ in range(3)]
+        dls_ref, dxs_ref = ops.heads3_loss_bwd_data(ps_ref, gts, [None, None, dist], *args, loss_ref,
+                                                    [p[1] for p in packed], cs, masks, bias_outs=gb_ref)
+        loss, gbs = torch.empty(4, device="cuda"), [torch.zeros(1, device="cuda") for _ in range(3)]
+        ctx.begin()
+        ps, dls, dxs = ops.heads3_fwd_loss_bwd_data(xs, [p[0] for p in packed], bs, gts, [None, None, dist], *args, loss,
+                                                    [p[1] for p in packed], masks, ctx, bias_outs=gbs)
+        ctx.flush()
+        torch.cuda.synchronize()
+        for name, got, ref in (("p", ps, ps_ref), ("dl", dls, dls_ref), ("dx", dxs, dxs_ref), ("bias", gbs, gb_ref)):
+            for h in range(3):
+                assert torch.equal(got[h], ref[h]), (name, h, rep)
+        assert torch.equal(loss[:3], loss_ref[:3]), rep
+        assert int(ctx._ws["heads_flags"].abs().sum()) == 0          # every counter back at zero
+    with pytest.raises(RuntimeError):          # one loss partial per workgroup: batch <= 32
+        big = [torch.rand(33, c, s, s, s, device="cuda") for c, s in shapes]
+        bg = [torch.rand(33, 1, s, s, s, device="cuda") for c, s in shapes]
+        ops.heads3_fwd_loss_bwd_data(big, [p[0] for p in packed], bs, bg, [None, None, None], *args, loss,
+                                     [p[1] for p in packed], [None, None, None], ctx)
+
+
 @pytest.mark.parametrize("c,B", [(3, 16), (8, 5), (3, 40)])
 def test_latent_tail_inside_the_slab_reduction_launch(ops, c, B):
     """nvf_latent_tail_queue (one workgroup of the nvf_wgrad_reduce_multi_and_sums launch) against nvf_latent_rate +

@@ -1,42 +1,37 @@
-"""Times the three-head launches (forward / backward-data / weight gradient) of the narrow decoder."""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+#!/usr/bin/env python3
+"""Times the heads' forward + loss / backward-data as two launches and as the one cooperative launch (batch 16, narrow)."""
+import os, sys
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nvfpcc_amd import ops
+from tools.wino_bench import timeit
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+shapes = [(16, 8), (8, 16), (8, 32)]
+g = torch.Generator().manual_seed(1)
+dev = lambda t: t.cuda()
+xs = [dev(torch.randn(B, c, s, s, s, generator=g)) for c, s in shapes]
+gts = [dev((torch.rand(B, 1, s, s, s, generator=g) > 0.75).float()) for c, s in shapes]
+dist = dev(torch.rand(B, 1, 32, 32, 32, generator=g))
+ws = [torch.randn(1, c, 3, 3, 3, generator=g) * 0.1 for c, s in shapes]
+bs = [dev(torch.randn(1, generator=g)) for _ in shapes]
+packed = [ops.pack_conv_weight(dev(w)) for w in ws]
+wf, wb = [p[0] for p in packed], [p[1] for p in packed]
+cs = [c for c, s in shapes]
+masks = [None, None, xs[2]]
+args = ([0.85, 0.85, 0.9], [0.0, 0.0, 1.0], [1, 2, 0])
+loss = torch.empty(4, device="cuda")
+ctx = ops.StepCtx()
 
 
-def timeit(fn, reps=30):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+def two():
+    ps = ops.heads3_fwd(xs, wf, bs)
+    ops.heads3_loss_bwd_data(ps, gts, [None, None, dist], *args, loss, wb, cs, masks)
 
 
-def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    dev = torch.device("cuda")
-    shapes = [(16, 8), (8, 16), (8, 32)]
-    xs = [torch.randn(B, c, s, s, s, device=dev) for c, s in shapes]
-    ws = [torch.randn(1, c, 3, 3, 3, device=dev) for c, s in shapes]
-    packs = [ops.pack_conv_weight(w) for w in ws]
-    bs = [torch.randn(1, device=dev) for _ in shapes]
-    dls = [torch.randn(B, 1, s, s, s, device=dev) for c, s in shapes]
-    print("heads3_fwd      %.1f us" % timeit(lambda: ops.heads3_fwd(xs, [p[0] for p in packs], bs)))
-    print("heads3_bwd_data %.1f us" % timeit(lambda: ops.heads3_bwd_data(dls, [p[1] for p in packs], [c for c, s in shapes], xs)))
-    wb = ops.WgradBatch(dev)
-    outs = [torch.empty(1, c, 3, 3, 3, device=dev) for c, s in shapes]
-
-    def wg():
-        wb.add_heads3(dls, xs, outs)
-        wb.finish()
-    print("heads3_wgrad+reduce %.1f us" % timeit(wg))
+def one():
+    ops.heads3_fwd_loss_bwd_data(xs, wf, bs, gts, [None, None, dist], *args, loss, wb, masks, ctx)
 
 
-if __name__ == "__main__":
-    main()
+print(f"two launches: {timeit(two, 50):7.1f} us", flush=True)
+print(f"one launch:   {timeit(one, 50):7.1f} us", flush=True)
