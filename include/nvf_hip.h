@@ -346,7 +346,7 @@ int nvf_stem_bwd_partial(const float* g1, const float* x0, const float* a0, cons
  * in that launch (autograd backward of network.py:4759-4760, gdn_3d.py:137-159).  Needs an open finals queue
  * (nvf_finals_begin).  Outputs as nvf_stem_bwd_partial (same sums, same order, same bits), plus *bias_slabs: `batch`
  * slabs of c0 floats inside `workspace` whose sum is up0's bias gradient (a jtotal = c0 job of nvf_wgrad_reduce_multi*).
- * da0 / dx0 exist once that launch has run.  flags: batch + 1 uint32 words of device memory, zero before the first use
+ * da0 / dx0 exist once that launch has run.  flags: (batch + 1) * 64 uint32 words of device memory (one 256-byte line per arrival counter), zero before the first use
  * (the launch leaves them zero).  NVF_EINVAL: another shape, no open queue, or a stem backward already queued.
  * nvf_latent_tail_cancel also drops a queued stem backward. */
 int nvf_stem_bwd_queue(NvfStepCtx* ctx, const float* g1, const float* x0, const float* a0, const float* conv0_w_bwd,

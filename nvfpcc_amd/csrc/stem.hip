@@ -235,7 +235,7 @@ extern "C" int nvf_stem_bwd_partial(const float* g1, const float* x0, const floa
 // finals queue (nvf_finals_begin: the IGDN parameter gradients are a deferred final pass, as in nvf_stem_bwd_partial).
 // Narrow decoder only (c0 = 8, c1 = 16), batch <= kStemCoopMaxBatch.  Outputs as nvf_stem_bwd_partial, plus
 // *bias_slabs = `batch` slabs of c0 channel sums of da0 (up0's bias gradient: a jtotal = c0 job of the slab reduction).
-// da0 / dx0 exist after that launch.  flags: batch + 1 uint32 words, zero before the first use; the launch leaves them zero.
+// da0 / dx0 exist after that launch.  flags: (batch + 1) * 64 uint32 words (one 256-byte line per counter), zero before the first use; the launch leaves them zero.
 extern "C" int nvf_stem_bwd_queue(NvfStepCtx* ctx, const float* g1, const float* x0, const float* a0,
                                   const float* conv0_w_bwd, const float* up0_w_bwd, const float* beta_hat,
                                   const float* gamma_hat, float* da0, float* dx0, float* dbeta_hat, float* dgamma_hat,
@@ -256,7 +256,7 @@ extern "C" int nvf_stem_bwd_queue(NvfStepCtx* ctx, const float* g1, const float*
   StemBwdJob j{};
   j.g1 = g1; j.w1b = conv0_w_bwd; j.x0 = x0; j.a0 = a0; j.w0b = up0_w_bwd; j.beta_hat = beta_hat; j.gamma_hat = gamma_hat;
   j.part = part; j.da0 = da0; j.dx0 = dx0; j.slab_gdn = slab_gdn; j.slab_w = slab_w;
-  j.coop.dh_done = flags; j.coop.stem_done = flags + batch; j.coop.bias_slab = bias;
+  j.coop.dh_done = flags; j.coop.stem_done = flags + batch * kStemFlagStride; j.coop.bias_slab = bias;
   j.batch = batch; j.ch = ch; j.nwg = batch;
   ctx->stem = j;
   ctx->stem_pending = 1;

@@ -17,6 +17,8 @@
 #include "nvf_common.h"
 
 constexpr int kStemMaxCh = 8;
+constexpr int kStemFlagStride = 64;      // words between two arrival counters: one 256-byte line each (a shared line made the
+                                         // producers' adds queue behind the consumers' polls: heads.hip measured 52 vs 30 us)
 constexpr int kStemCoopMaxBatch = 32;    // 9 workgroups per block + the tail inside the first dispatch round (< 512)
 
 __device__ __forceinline__ void nvf_store_dev(float* p, float v) {
@@ -183,7 +185,7 @@ __device__ __forceinline__ void stem_bwd_dh_body(const float* __restrict__ g1, c
           slab0[((size_t)b * C0 + ci) * C1 * 125 + (2 * cp + cc) * 125 + r * 5 + kx] = a[cc][kx];
     }
   }
-  if (COOP) nvf_coop_signal(coop.dh_done + b);
+  if (COOP) nvf_coop_signal(coop.dh_done + b * kStemFlagStride);
 }
 
 // ---- per-block stage: dh0 = sum of the channel-pair partials -> IGDN backward (da0, slabs of d beta / d gamma) -> up0
@@ -230,7 +232,7 @@ __device__ __forceinline__ void stem_bwd_body(const float* __restrict__ part, co
   __syncthreads();
 
   for (int b = wg; b < batch; b += nwg) {
-    if (COOP) nvf_coop_wait(coop.dh_done + b, C1 / 2);
+    if (COOP) nvf_coop_wait(coop.dh_done + b * kStemFlagStride, C1 / 2);
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
       const int t = tid + r * NT, c = t >> 6, v = t & 63;

@@ -578,10 +578,8 @@ def stem_bwd_queue(g1, x0, a0, conv0_w_bwd, up0_w_bwd, beta_hat, gamma_hat, dbet
     c0, c1 = a0.shape[1], g1.shape[1]
     ws = workspace(lib().nvf_stem_bwd_workspace_for(B, ch, c0, c1), x0.device, "stem", ctx)
     flags = ctx._ws.get("stem_flags")
-    if flags is None or flags.numel() < B + 1:
-        if flags is not None:
-            ctx._retired.append(flags)
-        flags = ctx._ws["stem_flags"] = torch.zeros(64, dtype=torch.int32, device=x0.device)
+    if flags is None:     # one 256-byte line per arrival counter, batch <= 32 (kStemCoopMaxBatch)
+        flags = ctx._ws["stem_flags"] = torch.zeros(33 * 64, dtype=torch.int32, device=x0.device)
     slabs, nsl, bias = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_void_p()
     check(lib().nvf_stem_bwd_queue(ctx.ptr, _ptr(g1), _ptr(x0), _ptr(a0), _ptr(conv0_w_bwd), _ptr(up0_w_bwd),
                                    _ptr(beta_hat), _ptr(gamma_hat), _ptr(da0), _ptr(dx0), _ptr(dbeta_out),
