@@ -889,12 +889,15 @@ extern "C" int nvf_heads3_fwd_loss_bwd_data(const float* const* xs, const float*
   if (workspace_bytes < nvf_reduce_workspace()) return NVF_EWORKSPACE;
   const int t = heads3_tuple(cs, ss);
   if (t == 0)
-    return heads3_fwd_loss_bwd_data_t<HPCfg<16, 8, 8, 8, 4>, HPCfg<8, 16, 8, 8, 2>, HPCfg<8, 32, 4, 8>, HCfg<16, 8, 4, 8>,
+#ifndef NVF_H2_CPS
+#define NVF_H2_CPS 1      // channels per pipeline step of the big head's forward inside the merged launch (tuning)
+#endif
+    return heads3_fwd_loss_bwd_data_t<HPCfg<16, 8, 8, 8, 4>, HPCfg<8, 16, 8, 8, 2>, HPCfg<8, 32, 4, 8, NVF_H2_CPS>, HCfg<16, 8, 4, 8>,
                                       HCfg<8, 16, 4, 4>, HCfg<8, 32, 4, 8>, 4>(
         xs, ws, biases, ps, act, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, flags, ctx,
         stream, bias_outs);
   if (t == 1)
-    return heads3_fwd_loss_bwd_data_t<HPCfg<32, 8, 8, 8, 4>, HPCfg<16, 16, 8, 8, 2>, HPCfg<16, 32, 4, 8>,
+    return heads3_fwd_loss_bwd_data_t<HPCfg<32, 8, 8, 8, 4>, HPCfg<16, 16, 8, 8, 2>, HPCfg<16, 32, 4, 8, NVF_H2_CPS>,
                                       HCfg<32, 8, 4, 8>, HCfg<16, 16, 4, 4>, HCfg<16, 32, 4, 8>, 2>(
         xs, ws, biases, ps, act, gts, dists, alphas, betas, slots, loss, dls, wbs, dxs, masks, batch, workspace, flags, ctx,
         stream, bias_outs);
