@@ -192,6 +192,125 @@ __global__ __launch_bounds__(C::NTH) void conv_s2k5_mfma(const float* __restrict
   }
 }
 
+// ---- up1's backward-data with the two channel groups of g on DIFFERENT waves (training steps behind the engine's
+// `winograd` switch; variant 7).  The kernel above runs up1 (16 output channels, 8^3 outputs, batch 16) as 128 workgroups of
+// four waves, 250 MFMAs each, the two channel groups one after the other: half the chip idles and the MFMA phase is 3.3 us
+// of a 12 us launch.  Here a workgroup owns 2 rows x 2 planes (256 workgroups at batch 16), wave = (plane, channel group):
+// both groups' tiles and A fragments are staged at once, every wave issues 125 MFMAs, and the second group's sums are added
+// to the first's through LDS -- (group 0's chain) + (group 1's chain) instead of one chain over both: other bits.
+template <int NIN_, int NOUT_, int RS_>
+struct S2KCfg {
+  static constexpr int NIN = NIN_, NOUT = NOUT_, RS = RS_, COG = 16, KEX = 5, XSTEP = 2;
+  static constexpr int NTH = 256, OY = 2, OZ = 2;
+  static constexpr int IZ = 2 * (OZ - 1) + 5, IY = 2 * (OY - 1) + 5, IZW = 5;
+  static constexpr int PS = IY * RS, CS = (IZ * PS) | 1, XW = 4 * CS, NFR = 25 * KEX, AW = NFR * 64;
+  static constexpr int ROWCH = (NIN + 3) / 4, XITEMS = 4 * IZ * IY * ROWCH;
+  static constexpr int NX4 = (XITEMS + NTH - 1) / NTH, NA4 = (AW / 4 + NTH - 1) / NTH;
+  static_assert(RS >= NIN && 2 * (XW + AW) * 4 <= 160 * 1024 && NOUT % 2 == 0, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTH) void conv_s2k5_mfma_ks2(const float* __restrict__ g, const float* __restrict__ wp,
+                                                          float* __restrict__ dx, const float* __restrict__ addend,
+                                                          const float* __restrict__ mask) {
+  constexpr int NIN = C::NIN, NOUT = C::NOUT, RS = C::RS, PS = C::PS, CS = C::CS, KEX = C::KEX, IZ = C::IZ, IY = C::IY,
+                ROWCH = C::ROWCH, NX4 = C::NX4, NA4 = C::NA4, COG = C::COG;
+  __shared__ __attribute__((aligned(16))) float xs[2 * C::XW];
+  __shared__ __attribute__((aligned(16))) float as[2 * C::AW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wz = wave & 1, kg = wave >> 1;                  // output plane of the pair, channel group of g
+  constexpr int TY = NOUT / C::OY, TZ = NOUT / C::OZ;
+  const int tile = blockIdx.x % (TY * TZ), b = blockIdx.x / (TY * TZ);
+  const int oy0 = (tile % TY) * C::OY, oz0 = (tile / TY) * C::OZ;
+  const int j = lane & 15, kq = lane >> 4, yy = j >> 3, m = j & 7;
+  const int colbase = kq * CS + (2 * wz) * PS + (2 * yy) * RS + C::XSTEP * m;
+  const float* gb = g + (size_t)b * 8 * NIN * NIN * NIN;
+  const int gz0 = 2 * oz0, gy0 = 2 * oy0;
+  // staging: as in the kernel above, for both channel groups at once
+  float4 xv[2][NX4], av[2][NA4];
+  const int xsoff = ((gz0 * NIN + gy0) * NIN) * 4;
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gb + (size_t)grp * 4 * NIN * NIN * NIN), 0, 4 * NIN * NIN * NIN * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * C::NTH;
+      const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
+      const bool ok = i < C::XITEMS && gz0 + zi < NIN && gy0 + yi < NIN;
+      const int voff = ok ? (((c * NIN + zi) * NIN + yi) * NIN + 4 * xq) * 4 : 0x7ffffff0;
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 w = __builtin_amdgcn_raw_buffer_load_b128(rg, voff, xsoff, 0);
+      float4 v = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+      if (4 * xq + 1 >= NIN) v.y = 0.f;
+      if (4 * xq + 2 >= NIN) v.z = 0.f;
+      if (4 * xq + 3 >= NIN) v.w = 0.f;
+      xv[grp][u] = v;
+    }
+    const float4* ap = (const float4*)(wp + (size_t)grp * C::AW);
+#pragma unroll
+    for (int u = 0; u < NA4; ++u) {
+      const int i = tid + u * C::NTH;
+      av[grp][u] = i < C::AW / 4 ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) {
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int i = tid + u * C::NTH;
+      if (i < C::XITEMS) {
+        const int xq = i % ROWCH, r = i / ROWCH, yi = r % IY, t = r / IY, zi = t % IZ, c = t / IZ;
+        float* d = xs + grp * C::XW + c * CS + zi * PS + yi * RS + 4 * xq;
+        d[0] = xv[grp][u].x;
+        if (4 * xq + 1 < RS) d[1] = xv[grp][u].y;
+        if (4 * xq + 2 < RS) d[2] = xv[grp][u].z;
+        if (4 * xq + 3 < RS) d[3] = xv[grp][u].w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NA4; ++u) {
+      const int i = tid + u * C::NTH;
+      if (i < C::AW / 4) ((float4*)(as + grp * C::AW))[i] = av[grp][u];
+    }
+  }
+  __syncthreads();
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* al = as + kg * C::AW + lane;
+    const float* xg = xs + kg * C::XW;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int tx = 0; tx < KEX; ++tx) {
+        float a[5];
+#pragma unroll
+        for (int kz = 0; kz < 5; ++kz) a[kz] = al[((kz * 5 + ky) * KEX + tx) * 64];
+#pragma unroll
+        for (int zi = 0; zi < 5; ++zi)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[zi], xg[colbase + zi * PS + ky * RS + tx], acc, 0, 0, 0);
+      }
+  }
+  // ---- the second group's sums join the first's: through LDS (the tiles are no longer read)
+  __syncthreads();
+  f32x4* red = (f32x4*)xs;
+  if (kg == 1) red[wz * 64 + lane] = acc;
+  __syncthreads();
+  if (kg == 1) return;
+  const f32x4 other = red[wz * 64 + lane];
+  const size_t vol = (size_t)NOUT * NOUT * NOUT;
+  const int oy = oy0 + yy, oz = oz0 + wz;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                     // channel 4 kq + r, output x = m
+    const size_t o = ((size_t)b * COG + 4 * kq + r) * vol + ((size_t)oz * NOUT + oy) * NOUT + m;
+    float v = acc[r] + other[r];
+    if (addend) v += addend[o];
+    if (mask) v = mask[o] > 0.f ? v : 0.f;
+    dx[o] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t nvf_pack_s2k5_mfma_floats(int cig, int cog) { return (size_t)(cig / 4) * 25 * (cog == 8 ? 7 : 5) * 64; }
@@ -228,6 +347,11 @@ extern "C" int nvf_conv3d_s2k5_mfma(const float* g, const float* wp, float* dx, 
   NVF_S2(6, 8, 8, 35, 16, 4, 2, 1, 37)     // up2: 8 rows x 2 planes on eight waves
   NVF_S2(5, 8, 16, 19, 8, 4, 2, 1, 24)     // up1: 8 rows x 2 planes on eight waves (64 workgroups)
 #undef NVF_S2
+  if (rc == 1 && variant == 7 && cig == 8 && cog == 16 && din == 19) {     // up1, channel groups on different waves
+    using C = S2KCfg<19, 8, 24>;
+    conv_s2k5_mfma_ks2<C><<<batch * (8 / C::OY) * (8 / C::OZ), C::NTH, 0, s>>>(g, wp, dx, addend, mask);
+    rc = NVF_OK;
+  }
   if (rc == 1) return NVF_EINVAL;
   NVF_LAUNCH_CHECK();
   return rc;

@@ -55,6 +55,7 @@ _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^
 _WINO16_BIAS = os.environ.get("NVF_WINO16_BIAS", "0") != "0"
 _WINO16_WGRAD = tuple(int(v) for v in os.environ.get("NVF_WINO16_WGRAD", "32,16").split(",") if v)   # ... weight gradients (dY extents)
 _GRAPH_LAST = os.environ.get("NVF_GRAPH_LAST_BATCH", "1") != "0"     # the short last mini-batch of an epoch as a graph too
+_UP1B_KSPLIT = os.environ.get("NVF_UP1B_KSPLIT", "1") != "0"   # up1's backward-data: channel groups on different waves
 _HEADS_FWD_IN_LOSS = os.environ.get("NVF_HEADS_FWD_IN_LOSS", "1") != "0"   # heads' forward inside the loss launch
 _HEAD_BIAS_IN_LOSS = os.environ.get("NVF_HEAD_BIAS_IN_LOSS", "1") != "0"   # heads' bias gradients from the loss launch
 _SUMS_IN_TRUNK5 = os.environ.get("NVF_SUMS_IN_TRUNK5", "1") != "0"   # partial bias sums inside the five-gradient launch
@@ -574,8 +575,11 @@ class TrainEngine:
             # up1 at large batch: two planes per wave (variant 2: 55 vs 63 us at batch 256; 173 vs 184 at 917)
             # up2 at batch <= 64: 8 rows x 2 planes on eight waves (variant 6: 25.3 -> 22.8 us at batch 16; bit-identical);
             # above: 4 rows x 4 planes on eight waves (variant 5: 1027 vs 1149 us at batch 917)
+            # up1 in training steps of the default engine: the two channel groups of g on different waves, 256 workgroups of
+            # 2 rows x 2 planes (variant 7: another summation order, so not in the strict-trajectory engine)
             var = 2 if (L.cin == 16 and g_out.shape[0] > 64) else (
-                _VAR["UP1B" if L.cin == 16 else "UP2B"] or ((6 if g_out.shape[0] <= 64 else 5) if L.cin == 8 else None))
+                _VAR["UP1B" if L.cin == 16 else "UP2B"] or ((6 if g_out.shape[0] <= 64 else 5) if L.cin == 8 else
+                                                            (7 if (self.winograd and _UP1B_KSPLIT) else None)))
             return ops.conv3d_s2k5_mfma(g_out, L.wp_s, L.cin, addend=addend, mask=mask, variant=var)
         return ops.conv3d_gather(g_out, L.w_bwd, None, L.cin, 5, 2, L.pad, tuple(x_in.shape[2:]), addend=addend,
                                  mask=mask)

@@ -74,7 +74,10 @@ def test_two_ranks_through_a_real_collective_equal_one_rank(tmp_path):
     dp = (one["flat_p"] - two["flat_p"]).abs()
     de = (one["emb"] - two["emb"]).abs()
     assert (dp > 1e-6).float().mean().item() < 1e-3 and dp.max().item() < 6 * 2e-3, (dp.max().item(), (dp > 1e-6).sum())
-    assert de.max().item() < 1e-5, de.max().item()
+    # (latent table: lr_emb = 5e-3, two sharded latent steps; the two worlds sum their gradients in different orders, and an
+    # entry's first Adam steps are lr * g / |g| (1 + O(rounding of g / g)): measured 0.4e-5 .. 1.1e-5 over this round's
+    # kernels = 0.2 % of one step; the bound is 3 x that, not a sign flip's 5e-3)
+    assert de.max().item() < 3e-5, de.max().item()
     # the epoch's log sums (engine.read_epoch_stats): focal terms, b_latent, b_net; the per-step accuracy RATIOS are
     # those of the whole mini-batch on both worlds, because the counts ride in the all-reduce of the gradients
     np.testing.assert_allclose(one["stats"][:, 0:5], two["stats"][:, 0:5], rtol=2e-4)

@@ -154,6 +154,34 @@ def test_conv_transpose_k5s2_mfma_backward_data(ops, cin, n, B):
     assert torch.equal(one[0], dx[1])
 
 
+@pytest.mark.parametrize("B", [1, 5, 16])
+def test_up1_backward_data_with_channel_groups_on_different_waves(ops, B):
+    """Variant 7 of nvf_conv3d_s2k5_mfma (up1's backward-data in training steps: the two channel groups of g on different
+    waves, their sums added through LDS) against torch's float64 autograd, with the fused addend and ReLU mask; against the
+    fixed-order kernel (variant 0) it differs by that one re-association only.  Batch invariant."""
+    g = gen(6100 + B)
+    x = torch.randn(B, 16, 8, 8, 8, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(16, 8, 5, 5, 5, generator=g) / (16 * 125 / 8) ** 0.5
+    y = F.conv_transpose3d(x, w.double(), None, stride=2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    mask, add = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+    _, wb = ops.pack_convT_weight(dev(w))
+    wp = ops.pack_s2k5_mfma(wb, 8, 16)
+    ref = ((x.grad + add.double()) * (mask > 0)).float()
+    d0 = ops.conv3d_s2k5_mfma(dev(gy), wp, 16, addend=dev(add), mask=dev(mask), variant=0)
+    d7 = ops.conv3d_s2k5_mfma(dev(gy), wp, 16, addend=dev(add), mask=dev(mask), variant=7)
+    e0, e7 = rel_err(d0, ref), rel_err(d7, ref)
+    print(f"up1 backward-data B={B}: rel err vs float64: fixed order {e0:.2e}, channel groups on different waves {e7:.2e}")
+    assert e7 < 3e-6 and e7 < 2 * e0 + 1e-7
+    assert rel_err(d7, d0.cpu()) < 3e-6
+    plain = ops.conv3d_s2k5_mfma(dev(gy), wp, 16, variant=7)
+    assert rel_err(plain, x.grad.float()) < 3e-6
+    one = ops.conv3d_s2k5_mfma(dev(gy)[B - 1:B].contiguous(), wp, 16, addend=dev(add)[B - 1:B].contiguous(),
+                               mask=dev(mask)[B - 1:B].contiguous(), variant=7)
+    assert torch.equal(one[0], d7[B - 1])
+
+
 HEAD_TUPLES = {"narrow": [(16, 8), (8, 16), (8, 32)], "wide": [(32, 8), (16, 16), (16, 32)]}
 
 
