@@ -43,10 +43,12 @@ _WINO1 = 1 << 16                                         # ppc bit: the one-accu
 
 def _wino_bwd_ppc(g_out):
     """Plane pairs per work unit of the Winograd backward-data at a full batch (0: the kernel's batch-16 default).  Every
-    choice gives the same bits; batch 917: conv2 2182 -> 1975 us with 9, conv1 569 -> 466 us with 5 (tools/wino_ppc_sweep.py)."""
+    choice gives the same bits; batch 917: conv2 2182 -> 1975 us with 9, conv1 569 -> 387 us (tools/wino_ppc_sweep.py)."""
     if g_out.shape[0] <= 64:
         return 0
-    return _WINO1 | (9 if g_out.shape[-1] == 32 else 5)
+    # (conv1: the two-set kernel of conv_wino.hip, all ten plane pairs per unit -- 387 us against 466 for the one-set kernel
+    # with 5 at batch 917, tools/wino_bench.py --fwd --batch 917; the same bits)
+    return (_WINO1 | 9) if g_out.shape[-1] == 32 else 10
 
 
 _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
@@ -241,9 +243,11 @@ class TrainEngine:
                     # backward-data in the reduced-multiplication form (Winograd over (y, x), z pairs on the matrix
                     # cores: 52 us against 85 for the direct form at batch 16)
                     L.wp_w = torch.empty(int(lib().nvf_pack_wino_k4_floats()), device=self.dev)
-                if self.winograd and _WINO_FWD and name == "conv2":
+                if self.winograd and _WINO_FWD and name in ("conv2", "conv1"):
                     # ... and the forward of TRAINING steps (mode 'train': NVFPCC.py:160, 234); the eval / encode / decode
-                    # forward keeps the direct fixed-order kernel (bit-exact batch invariance, the occupancy contract)
+                    # forward keeps the direct fixed-order kernel (bit-exact batch invariance, the occupancy contract).
+                    # conv1 only above batch 64 (the full-batch latent step: 207 us against 375 for the direct kernel at
+                    # batch 917; at batch 16 its 16^3 outputs do not amortise the transforms: 16.7 against 12.2 us)
                     L.wp_wf = torch.empty(int(lib().nvf_pack_wino_k4_floats()), device=self.dev)
             # wide decoder (16 / 32 channels): the output channels are the MFMA rows (conv16_mfma.hip) -- conv1 / conv2
             # forward and backward-data, and the backward-data of up2 / up1 (stride-2 gather with cin output channels)
@@ -407,9 +411,11 @@ class TrainEngine:
         return ops.convT3d_k5s2_fwd(x, L.w_fwd, L.b_eff, L.cout, L.pad, act)
 
     def _conv(self, L, x, act, train=False):
-        if train and L.wp_wf is not None and act == R:
+        if train and L.wp_wf is not None and act == R and (self.wide or x.shape[-1] == 35 or x.shape[0] > 64):
             if self.wide:
                 return ops.conv3d_k4_wino16_fwd(x, L.wp_wf, L.b_eff)
+            if x.shape[-1] == 19:      # conv1 at a full batch: the two-set kernel, all eight plane pairs per unit
+                return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff, ppc=8)
             # (a full-batch launch has workgroups to spare: more plane pairs per work unit repeat fewer plane transforms --
             # conv2 at batch 917: 1667 -> 1481 us with 8 pairs per unit; the same bits, tools/wino_ppc_sweep.py)
             return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff, ppc=(_WINO1 | 8) if x.shape[0] > 64 else 0)
@@ -476,7 +482,7 @@ class TrainEngine:
             with self._on_side():                   # the two coarse heads run beside the trunk
                 a["p0"] = self._conv(Ls["conv0_cls"], a["y1"], S)
         a["y2"] = self._convT(Ls["up1"], a["y1"], R, train=(mode == "train"))
-        a["y3"] = self._conv(Ls["conv1"], a["y2"], R)
+        a["y3"] = self._conv(Ls["conv1"], a["y2"], R, train=(mode == "train"))
         if not self.heads3:
             self._fork()
             with self._on_side():

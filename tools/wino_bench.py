@@ -46,12 +46,15 @@ def main():
     out = torch.empty(B, 8, 35, 35, 35, device=dev)
     macs = B * 8 * 8 * 64 * 32 ** 3
     d = ops.conv3d_k4_mfma(gy, wp_d, None, 3, 0, ops.ACT_NONE, mask=mask)
-    us = timeit(lambda: ops.conv3d_k4_mfma(gy, wp_d, None, 3, 0, ops.ACT_NONE, mask=mask, out=out, bias_part=slabs.data_ptr()), a.reps)
+    us = timeit(lambda: ops.conv3d_k4_mfma(gy, wp_d, None, 3, 0, ops.ACT_NONE, mask=mask, out=out,
+                                           bias_part=slabs.data_ptr() if B <= 32 else None), a.reps)
     print(f"direct  (conv_k4_mfma flat x-pair): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic")
     for ppc in [int(v) for v in a.ppc.split(",")]:
         wv = ops.conv3d_k4_wino_bwd(gy, wp_w, mask, ppc=ppc)
         err = float((wv - d).abs().max() / d.abs().max()) if ppc < 256 else float("nan")
-        us = timeit(lambda: ops.conv3d_k4_wino_bwd(gy, wp_w, mask, out=out, bias_part=slabs.data_ptr(), ppc=ppc), a.reps)
+        # (the slab buffer holds 4096 units' sums: enough for batch <= 32 only -- beyond that an out-of-bounds write)
+        bp = slabs.data_ptr() if B <= 32 else None
+        us = timeit(lambda: ops.conv3d_k4_wino_bwd(gy, wp_w, mask, out=out, bias_part=bp, ppc=ppc), a.reps)
         print(f"winograd (conv_k4_wino_bwd, ppc {ppc & 255:2d} dbg {ppc >> 8:2d}): {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF algorithmic   max|d| / max = {err:.2e}")
 
 
