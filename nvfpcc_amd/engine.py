@@ -36,19 +36,20 @@ _WINO = os.environ.get("NVF_WINO", "1") != "0"   # conv2's / conv1's backward-da
 _WINO_FWD = os.environ.get("NVF_WINO_FWD", "1") != "0"   # ... and conv2's forward in TRAINING steps (never in eval)
 _WINO_C1 = os.environ.get("NVF_WINO_C1", "1") != "0"     # conv1's backward-data as well
 # (conv1's training FORWARD in that form: measured slower at batch 16 -- 19.1 us two-set / 16.7 us one-set kernel against
-# 12.2 us for the direct kernel, r05 A/B -- 16^3 outputs do not amortise the transforms; not wired)
+# 12.2 us for the direct kernel, r05 A/B -- 16^3 outputs do not amortise the transforms; used above batch 64 only)
 _CONVT_EDGE = os.environ.get("NVF_CONVT_EDGE", "1") != "0"   # up1 / up2 training forward: kx = 4 taps on rows (co, ey)
-_WINO1 = 1 << 16                                         # ppc bit: the one-accumulator-set kernels (conv_wino1.hip)
 
 
 def _wino_bwd_ppc(g_out):
-    """Plane pairs per work unit of the Winograd backward-data at a full batch (0: the kernel's batch-16 default).  Every
-    choice gives the same bits; batch 917: conv2 2182 -> 1975 us with 9, conv1 569 -> 387 us (tools/wino_ppc_sweep.py)."""
+    """Plane pairs per work unit of the Winograd backward-data at a full batch (0: the kernel's batch-16 default; an explicit
+    count without bit 16 = the two-set kernel of conv_wino.hip).  Every choice gives the same bits; batch 917: conv2
+    2182 -> 1945 us, conv1 569 -> 387 us (tools/wino_ppc_sweep.py, tools/wino_bench.py --batch 917)."""
     if g_out.shape[0] <= 64:
         return 0
     # (conv1: the two-set kernel of conv_wino.hip, all ten plane pairs per unit -- 387 us against 466 for the one-set kernel
     # with 5 at batch 917, tools/wino_bench.py --fwd --batch 917; the same bits)
-    return (_WINO1 | 9) if g_out.shape[-1] == 32 else 10
+    # (conv2 likewise: all 18 pairs in the two-set kernel 1945 us, one-set kernel with 9 / 18: 2203 / 2098 in the same run)
+    return 18 if g_out.shape[-1] == 32 else 10
 
 
 _WINO16 = os.environ.get("NVF_WINO16", "1") != "0"       # the wide decoder's 4^3 layers in that form (conv16_wino.hip)
@@ -418,7 +419,8 @@ class TrainEngine:
                 return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff, ppc=8)
             # (a full-batch launch has workgroups to spare: more plane pairs per work unit repeat fewer plane transforms --
             # conv2 at batch 917: 1667 -> 1481 us with 8 pairs per unit; the same bits, tools/wino_ppc_sweep.py)
-            return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff, ppc=(_WINO1 | 8) if x.shape[0] > 64 else 0)
+            # (above batch 64 the two-set kernel with all 16 pairs: 1480 us against 1507 for the one-set kernel with 8)
+            return ops.conv3d_k4_wino_fwd(x, L.wp_wf, L.b_eff, ppc=16 if x.shape[0] > 64 else 0)
         if L.wp_gf is not None:
             osz = tuple(s - 3 for s in x.shape[2:])
             return ops.conv3d_g16_mfma(x, L.wp_gf, L.b_eff, L.cout, 4, 1, 0, osz, act)

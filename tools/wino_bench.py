@@ -72,7 +72,7 @@ def fwd_main(B, reps):
         d = ops.conv3d_k4_mfma(x, wp_d, b, 0, 0, ops.ACT_RELU)
         us = timeit(lambda: ops.conv3d_k4_mfma(x, wp_d, b, 0, 0, ops.ACT_RELU, out=out), reps)
         print(f"fwd {n} direct:            {us:7.1f} us  {2 * macs / us / 1e6:6.1f} TF")
-        for ppc in ((4, 2, 6, 8, 65538, 65540, 65537) if n == 35 else (2, 4, 8, 65537, 65538)):   # bit 16: conv_wino1.hip
+        for ppc in ((4, 2, 6, 8, 16, 65538, 65540, 65544, 65537) if n == 35 else (2, 4, 8, 65537, 65538)):   # bit 16: conv_wino1.hip
             y = ops.conv3d_k4_wino_fwd(x, wp_w, b, ppc=ppc)
             err = float((y - d).abs().max() / d.abs().max())
             us = timeit(lambda: ops.conv3d_k4_wino_fwd(x, wp_w, b, out=out, ppc=ppc), reps)
