@@ -1302,9 +1302,10 @@ extern "C" int nvf_step_head_stem(const void* table_dev, int nlayers, int q, uin
   const int rc = gather_multi_desc(srcs, dsts, widths, n, rows, g, wg);
   if (rc != NVF_OK) return rc;
   // 512-thread (wide decoder: 1024-thread) workgroups: a half (quarter) as many as nvf_step_head's for the same threads
-  const int tscale = narrow ? 2 : 4;
+  const int tscale = (narrow ? 2 : 4) * nvf_tune_int("NVF_HS_GSCALE", 1);
   wg = (wg + tscale - 1) / tscale;
-  const int wpl = 32;                  // (nvf_step_head: 64 workgroups of 256 threads per layer; 128 for the wide decoder's kernels)
+  // (nvf_step_head: 64 workgroups of 256 threads per layer; 128 for the wide decoder's kernels.  Tuning builds: NVF_HS_WPL)
+  const int wpl = nvf_tune_int("NVF_HS_WPL", 32) > 0 ? nvf_tune_int("NVF_HS_WPL", 32) : 32;
   RateInHead rate{};
   if (rate_job) {
     if (!rate_job->sigma || !rate_job->mu || !rate_job->part) return NVF_EINVAL;
