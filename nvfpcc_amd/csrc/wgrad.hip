@@ -185,6 +185,7 @@ struct WgTiled2 {
   float* slabs[2];
   WgDims d[2];
   int32_t nx[2], ny[2];
+  int32_t conv0_mfma;      // > 0: job 1 (conv0) runs on the matrix cores instead: this many workgroups (5 per block), one slab per block
 };
 
 template <class C0, class C1>
@@ -809,6 +810,68 @@ extern "C" int nvf_debug_wg_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+// ---- conv0's weight gradient (8 -> 16 channels, 4^3 -> 8^3, k 5 s 2 padding 2) on the matrix cores -------------------------
+//   dw[ci][co][k] = sum_{b, i} h0[b, ci, i] g1[b, co, 2 i - 2 + k]
+// 16.4 M multiply-adds, but as the VALU tile job of this launch it held 128 slots for 16 us each (6 % of the launch's slot
+// time).  Five workgroups (256 threads; one per ky) and one slab per block; v_mfma_f32_16x16x4_f32 with rows = the 16 output channels,
+// K = four positions i, columns = (ci, s): column s = 1 reads h0 one z plane lower, which makes its product the tap kz + 2
+// of the same (ky, kx) -- the pair trick of the other layers, 75 products for the 125 taps.  A wave owns 3-4 of them for
+// all 20 K steps (accumulators in registers); an A operand is g1 through a bounds check (no padded copy: 33 KB of LDS, not
+// 110).  Per output the sum runs over the block's positions in ascending order; the slab reduction adds the blocks.
+// Another summation order than the tile job's: the caller's context keeps the tile job for the direct forms.
+struct Conv0WLds { static constexpr int GCS = 513, HCS = 65, FLOATS = 16 * GCS + 8 * HCS; };   // odd strides: no bank conflicts
+
+__device__ __forceinline__ void conv0_wgrad_mfma_body(const float* __restrict__ h0, const float* __restrict__ g1,
+                                                      float* __restrict__ slab, int b, int ky, float* lds) {
+  typedef float c0_f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int GCS = Conv0WLds::GCS, HCS = Conv0WLds::HCS;
+  float* s_g = lds;
+  float* s_h = lds + 16 * GCS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < 16 * 512; e += 256) s_g[(e >> 9) * GCS + (e & 511)] = g1[(size_t)b * 16 * 512 + e];
+  for (int e = tid; e < 8 * 64; e += 256) s_h[(e >> 6) * HCS + (e & 63)] = h0[(size_t)b * 8 * 64 + e];
+  __syncthreads();
+  const int j = lane & 15, kq = lane >> 4;
+  const int ci = j >> 1, sft = j & 1;
+  constexpr int NPROD = 15, PER = (NPROD + 3) / 4;              // this workgroup's (kx, z pair) products; per wave
+  const int t0 = wave * PER, t1 = min(t0 + PER, NPROD);
+  c0_f32x4 acc[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) acc[u] = c0_f32x4{0.f, 0.f, 0.f, 0.f};
+  // (five z planes of positions: the shifted column s = 1 meets h0's last plane at iz = 4, where column s = 0 has none)
+#pragma unroll 1
+  for (int ks = 0; ks < 20; ++ks) {
+    const int i = 4 * ks + kq, iz = i >> 4, iy = (i >> 2) & 3, ix = i & 3;
+    const float bv = (unsigned)(iz - sft) < 4u ? s_h[ci * HCS + i - 16 * sft] : 0.f;      // B[k = kq][col = (ci, s)]
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = t0 + u;                                     // wave-uniform
+      if (t < t1) {
+        const int zp = t % 3, kx = t / 3;
+        const int kz = zp == 2 ? 4 : zp;                        // pairs (0, 2) (1, 3) (4, -)
+        const int qz = 2 * iz - 2 + kz, qy = 2 * iy - 2 + ky, qx = 2 * ix - 2 + kx;
+        const bool ok = (unsigned)qz < 8u && (unsigned)qy < 8u && (unsigned)qx < 8u;
+        const float av = ok ? s_g[j * GCS + (qz * 8 + qy) * 8 + qx] : 0.f;     // A[row = co = j][k = kq]
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[u], 0, 0, 0);
+      }
+    }
+  }
+  float* out = slab + (size_t)b * (8 * 16 * 125);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int t = t0 + u;
+    if (t < t1) {
+      const int zp = t % 3, kx = t / 3;
+      const int kz = (zp == 2 ? 4 : zp) + 2 * sft;
+      if (kz < 5) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(ci * 16 + 4 * kq + r) * 125 + kz * 25 + ky * 5 + kx] = acc[u][r];
+      }
+    }
+  }
+}
+
 // floats of LDS the latent tail needs when the stem's backward rides in the same launch: + its copy of dx0
 constexpr int kTailStemLds = kTailLds + kStemCoopMaxBatch * kStemMaxCh * 8;
 
@@ -823,7 +886,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
                                                             wg_max3(wg_max3(kTailStemLds, U0::LDSF, U1::LDSF),
                                                                     wg_max3(HeadW0::SMEM, HeadW1::SMEM, HeadW2::SMEM),
                                                                     wg_max3(WgUp1::LDSF, StemBwdLds<8>::FLOATS,
-                                                                            StemDhLds<8, 16>::FLOATS)))];
+                                                                            wg_max3(StemDhLds<8, 16>::FLOATS,
+                                                                                    Conv0WLds::FLOATS, 0))))];
 #ifndef NVF_WG_SKIP
 #define NVF_WG_SKIP 0                  // tuning builds: bit j set = job j does nothing (results are then meaningless)
 #endif
@@ -864,6 +928,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
     }
     --bid;
   }
+  // conv0 on the matrix cores (five short workgroups per block: in the first dispatch round, not behind the long ones)
+  if (bid < u.conv0_mfma) { conv0_wgrad_mfma_body(u.p[1], u.q[1], u.slabs[1], bid / 5, bid % 5, lds); return; }
+  bid -= u.conv0_mfma;
   if (bid < m.n[0]) {                  // conv2: the Winograd (y, x) form when the job says so (tiles_z = its z split)
     if (NVF_WG_SKIP & 1) return;
     if (m.d[0].tiles_z > 0) wgrad_k4_wino_body<WgWino2>(m.p[0], m.q[0], m.slabs[0], m.d[0], bid, lds, kWgRegion);
@@ -884,6 +951,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma3_kernel(WgMfma3 m, WgTiled2 u,
   // its multiply-adds (measured by skipping it); the stride-2 body with two row blocks of eight input channels
   if (bid < m.n[3]) { if (!(NVF_WG_SKIP & 8)) wgrad_s2k5_mfma_body<WgUp1>(m.p[3], m.q[3], m.slabs[3], m.d[3], bid, lds); return; }
   bid -= m.n[3];
+
   if (NVF_WG_SKIP & (8 | 64)) { if (bid < u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return; }     // 64: the tile jobs only
   if ((NVF_WG_SKIP & 16) && bid >= u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1]) return;
   // the two small transposed convolutions' gradients (VALU kernels, latency-bound on their own) fill the slots the
@@ -1009,6 +1077,14 @@ static int launch_trunk_wgrads(const float* const* ps, const float* const* qs, f
       grid += n;
     }
 #endif
+    // conv0's gradient on the matrix cores too (conv0_wgrad_mfma_body: one workgroup and one slab per block) unless the
+    // caller's context asks for the direct forms (another summation order)
+    if (!(nvf_ctx_ok(ctx) && ctx->direct_forms) && nvf_tune_int("NVF_CONV0_WG_MFMA", 1)) {
+      u.conv0_mfma = 5 * batch;
+      u.nx[1] = 0;
+      nslabs[4] = batch;
+      grid += 5 * batch;
+    }
     grid += u.nx[0] * u.ny[0] + u.nx[1] * u.ny[1];
   }
   HeadsW3 hw{};
