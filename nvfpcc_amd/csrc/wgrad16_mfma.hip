@@ -194,6 +194,103 @@ int launch_w16(const float* p, const float* q, float* slabs, W16Dims d, int max_
   return NVF_OK;
 }
 
+// ---- up1 of the wide decoder (k 5, S 2: p = X [B,32,8^3], q = dY [B,16,19^3]) ---------------------------------------------
+// The kernel above walks four consecutive x positions per MFMA and reuses an A fragment along a tap row: with 8-wide rows
+// that is two uses, and the VALU tile kernel was faster (36 us against 50 at batch 16).  This one turns the loops around:
+// K = four positions of an (iy, ix) plane, rows = 16 p-channels, columns = the 16 q-channels -- every lane useful, no bounds
+// (2 i + k <= 18) -- and the ACCUMULATORS are the taps: a workgroup owns (block, half of the z planes, p-channel group, kz),
+// its waves four (ky, kx) taps each for all positions, so an A read feeds four MFMAs and a B read one.  One x plane (4 KB) and
+// one dY plane (23 KB) per step, the next pair fetched into registers under this step's MFMAs.  320 workgroups at batch 16,
+// two slabs per block (the ten workgroups of a (block, half) write disjoint parts of one slab): 8 MB of slabs instead of 33.
+struct U1W {
+  static constexpr int XS = 65, DS = 361, XW = 16 * XS, DW = 16 * DS, BUF = XW + DW, NTH = 512;
+  static constexpr int NX = (16 * 64 + NTH - 1) / NTH, ND = (16 * 361 + NTH - 1) / NTH;
+};
+
+template <int NH>      // z halves per block (workgroups per (block, channel group, kz)): NP = 8 / NH planes each
+__global__ __launch_bounds__(U1W::NTH) void wgrad16_up1_mfma(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ slabs) {
+  constexpr int NP = 8 / NH;
+  constexpr int XS = U1W::XS, DS = U1W::DS, XW = U1W::XW, BUF = U1W::BUF, NTH = U1W::NTH, NX = U1W::NX, ND = U1W::ND;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x / NH, half = blockIdx.x % NH;       // block, z planes NP half .. NP half + NP - 1 of x
+  const int ag = blockIdx.y / 5, kz = blockIdx.y % 5;          // group of 16 p-channels, z tap
+  const float* xb = x + ((size_t)b * 32 + ag * 16) * 512;
+  const float* db = dy + (size_t)b * 16 * 6859;
+  float xv[NX], dv[ND];
+  auto load = [&](int iz) {
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int e = tid + u * NTH;                               // (c, position of the plane)
+      xv[u] = xb[(size_t)(e >> 6) * 512 + iz * 64 + (e & 63)];
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int e = tid + u * NTH;
+      const int c = e / 361, r = e - c * 361;
+      dv[u] = e < 16 * 361 ? db[((size_t)c * 19 + 2 * iz + kz) * 361 + r] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+    float* xs = lds + buf * BUF;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int e = tid + u * NTH;
+      xs[(e >> 6) * XS + (e & 63)] = xv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int e = tid + u * NTH;
+      if (e < 16 * 361) xs[XW + e] = dv[u];                      // [c][361]: DS = 361
+    }
+  };
+  const int t0 = wave * 4, nt = t0 >= 25 ? 0 : (25 - t0 < 4 ? 25 - t0 : 4);   // this wave's taps (ky, kx) = t0 .. t0 + nt - 1
+  int toff[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int t = t0 + u < 25 ? t0 + u : 24;
+    toff[u] = (t / 5) * 19 + t % 5;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load(NP * half);
+  store(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int st = 0; st < NP; ++st) {
+    if (st + 1 < NP) load(NP * half + st + 1);
+    const float* xs = lds + (st & 1) * BUF;
+    const float* ds = xs + XW;
+    if (nt > 0) {
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const int i = 4 * ks + kq, iy = i >> 3, ix = i & 7;
+        const float av = xs[j * XS + i];                                    // A[row = p-channel j][k = kq]
+        const float* dp = ds + j * DS + (2 * iy) * 19 + 2 * ix;             // B[k = kq][col = q-channel j]
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < nt) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dp[toff[u]], acc[u], 0, 0, 0);
+      }
+    }
+    if (st + 1 < NP) {
+      store((st + 1) & 1);                                       // (the other buffer: last read one step ago, behind a barrier)
+      __syncthreads();
+    }
+  }
+  float* out = slabs + (size_t)(NH * b + half) * (32 * 16 * 125);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (u < nt) {
+      const int t = t0 + u, tap = kz * 25 + t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[((size_t)(ag * 16 + 4 * kq + r) * 16 + j) * 125 + tap] = acc[u][r];
+    }
+}
+
 }  // namespace
 
 // Partial sums of dw[a][16][k^3] (a = 16 or 32) into `slabs` (*nslab slabs of a * 16 * k^3 floats, <= max_slabs);
@@ -207,6 +304,14 @@ int nvf_wgrad16_launch(const float* p, const float* q, float* slabs, int batch, 
   if (k == 4 && stride == 1 && dp == 32) return launch_w16<W16<4, 1, 32, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
   if (k == 4 && stride == 1 && dp == 16) return launch_w16<W16<4, 1, 16, 4, 8>>(p, q, slabs, d, max_slabs, nslab, s);
   if (k == 5 && stride == 2 && dp == 16) return launch_w16<W16<5, 2, 16, 2, 8>>(p, q, slabs, d, max_slabs, nslab, s);
-  // (up1's 8-wide rows give an A fragment only two uses per tap row: 50 us against 36 us for the VALU tile kernel)
+  // (up1's 8-wide rows give an A fragment only two uses per tap row: 50 us against 36 us for the VALU tile kernel --
+  // wgrad16_up1_mfma keeps the taps in the accumulators instead)
+  if (k == 5 && stride == 2 && dp == 8 && a == 32 && max_slabs >= 2 * batch) {
+    const int nh = nvf_tune_int("NVF_U1W_NH", 2);
+    if (nh == 1) wgrad16_up1_mfma<1><<<dim3(batch, 10), U1W::NTH, 0, s>>>(p, q, slabs);
+    else wgrad16_up1_mfma<2><<<dim3(2 * batch, 10), U1W::NTH, 0, s>>>(p, q, slabs);
+    *nslab = (nh == 1 ? 1 : 2) * batch;
+    return NVF_OK;
+  }
   return 1;
 }
