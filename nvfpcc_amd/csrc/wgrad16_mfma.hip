@@ -199,7 +199,7 @@ int launch_w16(const float* p, const float* q, float* slabs, W16Dims d, int max_
 // that is two uses, and the VALU tile kernel was faster (36 us against 50 at batch 16).  This one turns the loops around:
 // K = four positions of an (iy, ix) plane, rows = 16 p-channels, columns = the 16 q-channels -- every lane useful, no bounds
 // (2 i + k <= 18) -- and the ACCUMULATORS are the taps: a workgroup owns (block, half of the z planes, p-channel group, kz),
-// its waves four (ky, kx) taps each for all positions, so an A read feeds four MFMAs and a B read one.  One x plane (4 KB) and
+// its waves three or four (ky, kx) taps each for all positions, so an A read feeds three or four MFMAs and a B read one.  One x plane (4 KB) and
 // one dY plane (23 KB) per step, the next pair fetched into registers under this step's MFMAs.  320 workgroups at batch 16,
 // two slabs per block (the ten workgroups of a (block, half) write disjoint parts of one slab): 8 MB of slabs instead of 33.
 struct U1W {
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(U1W::NTH) void wgrad16_up1_mfma(const float* __rest
       if (e < 16 * 361) xs[XW + e] = dv[u];                      // [c][361]: DS = 361
     }
   };
-  const int t0 = wave * 4, nt = t0 >= 25 ? 0 : (25 - t0 < 4 ? 25 - t0 : 4);   // this wave's taps (ky, kx) = t0 .. t0 + nt - 1
+  // this wave's taps (ky, kx) = t0 .. t0 + nt - 1: 4 for wave 0, 3 for the others -- 7 / 6 / 6 / 6 on the four SIMDs
+  const int t0 = wave == 0 ? 0 : 3 * wave + 1, nt = wave == 0 ? 4 : 3;
   int toff[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
